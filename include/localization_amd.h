@@ -1,0 +1,120 @@
+/*
+ * localization_amd — C ABI of the MI355X-native range-localization solver.
+ *
+ * The reference (sair-lab/localization) has no plugin/FFI seam: class Localization owns a
+ * g2o::SparseOptimizer by value (reference src/localization/localization.h:168) and calls it directly.
+ * The boundary cut here is exactly the set of g2o calls Localization/Robot make; every
+ * entry point below names the reference call site(s) it replaces.  Plain pointers and sizes only; no
+ * exceptions cross the ABI; every function returns a loc_status (0 = OK, <0 = error).
+ *
+ * There is NO CPU fallback: creating a solver without a usable HIP device fails with LOC_ERR_NO_DEVICE.
+ *
+ * Threading: like the reference (one ros::spin() thread, localization_node.cpp:98) a handle is not
+ * thread-safe; distinct handles are independent.  All device work of a handle is issued on the HIP stream
+ * the caller passes (or the handle's own stream when NULL).
+ */
+#ifndef LOCALIZATION_AMD_H
+#define LOCALIZATION_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LOC_ABI_VERSION 1
+
+typedef enum loc_status {
+    LOC_OK = 0,
+    LOC_ERR_INVALID = -1,      /* bad argument / shape */
+    LOC_ERR_NO_DEVICE = -2,    /* no HIP device: the product path refuses to run */
+    LOC_ERR_HIP = -3,          /* a HIP runtime call failed (see loc_last_error) */
+    LOC_ERR_UNKNOWN_NODE = -4, /* node id not in nodesId (reference: std::map::at throws, localization.cpp:306) */
+    LOC_ERR_UNSUPPORTED = -5,  /* shape outside what the kernels are built for */
+    LOC_ERR_SINGULAR = -6      /* non-invertible covariance (reference: MatrixXd::inverse, localization.cpp:277,601) */
+} loc_status;
+
+/* Range-edge Jacobian. The reference inherits g2o's numeric central difference (delta = 1e-9) because
+ * EdgeSE3Range does not override linearizeOplus (types_edge_se3range.h:45-74).  ANALYTIC is the exact
+ * derivative of the same residual (0 where the endpoints coincide, which is what the numeric form gives). */
+enum { LOC_JAC_ANALYTIC = 0, LOC_JAC_NUMERIC_G2O = 1 };
+
+const char* loc_last_error(void);  /* thread-local message of the last failing call */
+int32_t loc_abi_version(void);
+int32_t loc_device_count(void);    /* 0 when no HIP device is visible */
+
+/* ================================================================================================
+ * Batched snapshot solver — BASELINE config 2 (8-anchor UWB, B independent tags, 3-DoF position).
+ *
+ * One "update" = for one tag, ingest one epoch of M anchor ranges and run what the reference runs per
+ * solve: create_range_edge per range (information 1/err^2, RobustKernelCauchy delta 1;
+ * localization.cpp:608-627, :318), the outlier gate on the prior estimate (:306-313), then
+ * Localization::solve() = initializeOptimization + optimize(maximum_iteration) with g2o's
+ * Levenberg-Marquardt (:164-170), then optimizer.chi2() (:197).  With identity antenna offsets the
+ * 6-DoF g2o problem reduces exactly to a 3x3 one (SURVEY.md §8(a) note), which is what the kernel solves.
+ *
+ * Device layouts (all device pointers unless the name says host):
+ *   dist, err : float  [K][M4][B][4]   M4 = ceil(M/4); anchor m sits at [m/4][..][m%4]; padded lanes err = 0
+ *   pos       : double [3][B]          state carried across epochs (in: prior/initial estimate, out: last)
+ *   out_pos   : double [K][3][B]       estimate after each epoch's solve
+ *   out_chi2  : double [K][B]          optimizer.chi2() after each solve (non-robust, last evaluated state)
+ *   out_trials: uint8  [K][B] or NULL  number of LM trials (linear solves) spent
+ * ============================================================================================== */
+typedef struct loc_snapshot loc_snapshot;
+
+typedef struct loc_snapshot_params {
+    int32_t maximum_iteration;   /* optimizer/maximum_iteration, localization.cpp:65 (default 20; cfg yaml: 10) */
+    double distance_outlier;     /* robot/distance_outlier, localization.cpp:78; <= 0 disables the gate */
+    int32_t gate_warmup_epochs;  /* epochs after (re)initialisation that run un-gated: the reference gates only once
+                                    number_measurements > trajectory_length (localization.cpp:309). default 1 */
+    int32_t jacobian;            /* LOC_JAC_* */
+    int32_t lanes_per_instance;  /* 0 = library default; otherwise 1,2,4,8 (must divide the padded anchor count) */
+    int32_t block_threads;       /* 0 = default (256) */
+} loc_snapshot_params;
+
+void loc_snapshot_default_params(loc_snapshot_params* p);
+
+/* anchors_xyz_host: [M][3] doubles = /uwb/nodesPos of the static nodes (localization.cpp:86-108). */
+int loc_snapshot_create(loc_snapshot** out, int32_t device, int64_t batch, int32_t n_anchors,
+                        const double* anchors_xyz_host, const loc_snapshot_params* params);
+int loc_snapshot_destroy(loc_snapshot* s);
+
+int64_t loc_snapshot_batch(const loc_snapshot* s);
+int32_t loc_snapshot_anchor_groups(const loc_snapshot* s);         /* M4 */
+int32_t loc_snapshot_lanes_per_instance(const loc_snapshot* s);
+/* number of floats in a dist/err buffer for `epochs` epochs = epochs * M4 * B * 4 */
+size_t loc_snapshot_range_floats(const loc_snapshot* s, int32_t epochs);
+
+/* Robot::init estimate (robot.cpp:47) for every tag: host [3][B] doubles -> device state, and back.
+ * Setting positions restarts the gate warm-up (epoch counter = 0). */
+int loc_snapshot_set_positions(loc_snapshot* s, const double* pos_soa_host);
+int loc_snapshot_get_positions(loc_snapshot* s, double* pos_soa_host);
+void* loc_snapshot_positions_device(loc_snapshot* s); /* the [3][B] device state itself */
+int64_t loc_snapshot_epochs_done(const loc_snapshot* s);
+int loc_snapshot_set_epochs_done(loc_snapshot* s, int64_t epochs);
+
+/* Pack host ranges given as [K][M][B] (anchor-major SoA) into the device tile layout [K][M4][B][4]. */
+int loc_snapshot_pack_ranges_host(const loc_snapshot* s, int32_t epochs, const float* src_kmb, float* dst_tiles,
+                                  float pad_value);
+
+/* The hot path: K epochs for all B tags, inputs and outputs resident in HBM. Asynchronous on hip_stream. */
+int loc_snapshot_solve_device(loc_snapshot* s, int32_t epochs, const float* dist_dev, const float* err_dev,
+                              double* out_pos_dev, double* out_chi2_dev, uint8_t* out_trials_dev,
+                              void* hip_stream);
+
+/* Convenience: same, with host buffers in the tile layout (stages over PCIe, synchronous). */
+int loc_snapshot_solve_host(loc_snapshot* s, int32_t epochs, const float* dist_tiles_host,
+                            const float* err_tiles_host, double* out_pos_host, double* out_chi2_host,
+                            uint8_t* out_trials_host);
+
+/* HIP-event timing of the solve kernel on the stream it is launched on (bench.py's roofline leg).
+ * loc_snapshot_timing_begin() arms per-launch event pairs; _end() synchronises and returns the number of
+ * timed launches, their total and average duration in milliseconds. */
+int loc_snapshot_timing_begin(loc_snapshot* s, int32_t max_launches);
+int loc_snapshot_timing_end(loc_snapshot* s, int32_t* n_launches, double* total_ms, double* avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOCALIZATION_AMD_H */

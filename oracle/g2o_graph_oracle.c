@@ -698,7 +698,7 @@ double og_chi2(og_graph* g) {
  * ---------------------------------------------------------------------------------------------- */
 int og_snapshot_batch(int B, int K, int M, const double* anchors, const float* dist, const float* err,
                       double* pos, double* out_pos, double* out_chi2, unsigned char* out_trials,
-                      int iterations, double gate, int jac_mode) {
+                      int iterations, double gate, int gate_from_epoch, int jac_mode) {
     iso3 I;
     iso_identity(&I);
     for (int b = 0; b < B; ++b) {
@@ -715,7 +715,7 @@ int og_snapshot_batch(int B, int K, int M, const double* anchors, const float* d
                 double e = (double)err[o];
                 /* localization.cpp:306-313 outlier gate on vertex origins */
                 double dhat = sqrt((p[0] - a[0]) * (p[0] - a[0]) + (p[1] - a[1]) * (p[1] - a[1]) + (p[2] - a[2]) * (p[2] - a[2]));
-                if (gate > 0 && fabs(dhat - d) > gate) continue;
+                if (gate > 0 && k >= gate_from_epoch && fabs(dhat - d) > gate) continue;
                 if (!(e > 0) || !isfinite(e) || !isfinite(d)) continue; /* padded / invalid slot */
                 double cov = pow(e, 2);                                  /* :318 */
                 og_add_range_edge(g, 1000, m, d, 1.0 / cov, NULL, NULL, 1); /* :608-627 */

@@ -75,11 +75,12 @@ double og_cauchy_rho(double chi2, double* rho1);
 
 /* Batched 3-DoF snapshot driven through the general graph (one moving vertex, M fixed anchors,
  * M Cauchy range edges; rebuilt per update).  Layout: dist/err [K][M][B] float, pos [3][B] double
- * (in: prior, out: last), out_pos [K][3][B], out_chi2 [K][B].  gate <= 0 disables the outlier gate. */
+ * (in: prior, out: last), out_pos [K][3][B], out_chi2 [K][B].  gate <= 0 disables the outlier gate;
+ * epochs k < gate_from_epoch are un-gated (the reference gates only after warm-up, localization.cpp:309). */
 int og_snapshot_batch(int B, int K, int M, const double* anchors /*[M][3]*/,
                       const float* dist, const float* err, double* pos,
                       double* out_pos, double* out_chi2, unsigned char* out_trials,
-                      int iterations, double gate, int jac_mode);
+                      int iterations, double gate, int gate_from_epoch, int jac_mode);
 
 #ifdef __cplusplus
 }

@@ -70,7 +70,7 @@ def lib():
         L.og_cauchy_rho.argtypes = [C.c_double, dp]
         L.og_cauchy_rho.restype = C.c_double
         L.og_snapshot_batch.argtypes = [C.c_int, C.c_int, C.c_int, dp, C.POINTER(C.c_float), C.POINTER(C.c_float),
-                                        dp, dp, dp, C.POINTER(C.c_ubyte), C.c_int, C.c_double, C.c_int]
+                                        dp, dp, dp, C.POINTER(C.c_ubyte), C.c_int, C.c_double, C.c_int, C.c_int]
         L.lo_create.restype = C.c_void_p
         L.lo_create.argtypes = [C.POINTER(LoConfig), C.c_int, C.POINTER(C.c_int), dp, C.c_int, dp]
         L.lo_destroy.argtypes = [C.c_void_p]
@@ -148,7 +148,7 @@ class Graph:
         return self.L.og_chi2(self.h)
 
 
-def snapshot_batch(anchors, dist, err, pos, iterations=10, gate=1.0, jac_mode=JAC_NUMERIC_G2O):
+def snapshot_batch(anchors, dist, err, pos, iterations=10, gate=1.0, jac_mode=JAC_NUMERIC_G2O, gate_from_epoch=1):
     """dist/err: [K][M][B] float32, pos: [3][B] float64 prior. Returns (out_pos[K,3,B], chi2[K,B], trials[K,B], pos_last[3,B])."""
     anchors = np.ascontiguousarray(anchors, dtype=np.float64)
     dist = np.ascontiguousarray(dist, dtype=np.float32)
@@ -160,7 +160,7 @@ def snapshot_batch(anchors, dist, err, pos, iterations=10, gate=1.0, jac_mode=JA
     out_pos = np.zeros((K, 3, B)); out_chi2 = np.zeros((K, B)); trials = np.zeros((K, B), dtype=np.uint8)
     rc = lib().og_snapshot_batch(B, K, M, _dp(anchors), dist.ctypes.data_as(C.POINTER(C.c_float)),
                                  err.ctypes.data_as(C.POINTER(C.c_float)), _dp(p), _dp(out_pos), _dp(out_chi2),
-                                 trials.ctypes.data_as(C.POINTER(C.c_ubyte)), iterations, float(gate), jac_mode)
+                                 trials.ctypes.data_as(C.POINTER(C.c_ubyte)), iterations, float(gate), int(gate_from_epoch), jac_mode)
     assert rc == 0
     return out_pos, out_chi2, trials, p
 

@@ -1,0 +1,32 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Make sure the HIP library and the oracle are built (hipcc cross-compiles without a GPU)."""
+    import __graft_entry__ as g
+    import localization_amd
+    from oracle import oracle as O
+    if not os.path.exists(localization_amd.library_path()):
+        g.build()
+    O.build()
+    return True
+
+
+@pytest.fixture(scope="session")
+def gpu(built):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda", 0)
