@@ -129,7 +129,7 @@ def main():
 
     if rank == 0:
         trials_mean = float(out_trials[args.warmup * E:].float().mean().item())
-        rmse = float(((out_pos[-1] - stream["truth_last"]) ** 2).sum(dim=0).mean().sqrt().item())
+        err_last = ((out_pos[-1] - stream["truth_last"]) ** 2).sum(dim=0).sqrt()
         traffic = None
         prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(prof):
@@ -150,7 +150,8 @@ def main():
                        "lanes_per_tag": solver.lanes_per_instance, "sharding": f"tags split over {n_gpus} GPU(s), no collective"},
             "lm_iterations_per_s": value * 10,
             "mean_lm_trials_per_update": trials_mean,
-            "rmse_vs_truth_m": rmse,
+            "median_err_vs_truth_m": float(err_last.median().item()),
+            "frac_err_gt_0p5m": float((err_last > 0.5).double().mean().item()),
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS,
                          "traffic": traffic,
