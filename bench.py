@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--lpi", type=int, default=0, help="lanes per tag (0 = library default)")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--datagen", default="torch", choices=["torch", "numpy"],
+                    help="numpy: generate the stream on the host and copy it (PMC profiling runs: no torch kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tags", type=int, default=2048)
     ap.add_argument("--cpu-epochs", type=int, default=96)
@@ -87,7 +89,15 @@ def main():
     B, E, M = args.batch, args.epochs, 8
     total_steps = args.warmup + args.steps
     # one long stream: every step reads fresh epochs (inputs (W+K)*E*B*64 B resident in HBM)
-    stream = make_snapshot_stream_torch(B, E * total_steps, seed=args.seed + 1000 * rank, device=dev)
+    if args.datagen == "torch":
+        stream = make_snapshot_stream_torch(B, E * total_steps, seed=args.seed + 1000 * rank, device=dev)
+    else:
+        from localization_amd.synthetic import make_snapshot_stream
+        hs = make_snapshot_stream(B, E * total_steps, seed=args.seed + 1000 * rank)
+        stream = {"dist_tiles": torch.from_numpy(la.pack_ranges(hs["dist"])).to(dev),
+                  "err_tiles": torch.from_numpy(la.pack_ranges(hs["err"])).to(dev),
+                  "init": hs["init"], "truth_last": torch.from_numpy(hs["truth"][-1]).to(dev)}
+        del hs
     dist_t, err_t = stream["dist_tiles"], stream["err_tiles"]
     solver = la.SnapshotSolver(ANCHORS_8, B, maximum_iteration=10, distance_outlier=1.0, jacobian=args.jacobian,
                                lanes_per_instance=args.lpi, block_threads=args.block, device=local_rank)
@@ -128,8 +138,8 @@ def main():
     achieved_gbs = ALGO_BYTES_PER_UPDATE * updates_per_launch / (kern_ms_avg * 1e-3) / 1e9
 
     if rank == 0:
-        trials_mean = float(out_trials[args.warmup * E:].float().mean().item())
-        err_last = ((out_pos[-1] - stream["truth_last"]) ** 2).sum(dim=0).sqrt()
+        trials_mean = float(out_trials[args.warmup * E:].cpu().numpy().mean())
+        err_last = torch.from_numpy(np.sqrt(((out_pos[-1].cpu().numpy() - stream["truth_last"].cpu().numpy()) ** 2).sum(axis=0)))
         traffic = None
         prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(prof):

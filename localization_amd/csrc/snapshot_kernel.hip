@@ -15,14 +15,23 @@
 //   * LPI lanes cooperate on one tag (LPI = 1, 2, 4 or 8; APL = M_PAD / LPI anchors per lane).  The 9 entries of
 //     (H, b) plus the two chi sums are combined with DPP butterflies (quad_perm / row_half_mirror: VALU rate,
 //     no LDS); every lane of a tag then holds bit-identical sums, so the per-tag LM state machine needs no
-//     broadcast.  LPI trades redundant 3x3 solves for occupancy (B = 65 536 tags is only 1 wave per SIMD at LPI 1).
-//   * The nested g2o loops (outer iterations x LM trials) are flattened into one wave-uniform loop of
-//     "solve -> trial point -> evaluate residuals AND normal equations there"; an accepted trial's (H, b) is the
-//     next iteration's system (g2o recomputes exactly those numbers), a rejected trial only bumps lambda.
-//     Lanes carry their own (iteration, trial, lambda, nu, done) state; the wave runs until all are done.
+//     broadcast.
+//   * ONE wave-uniform loop of "passes".  A pass = [3x3 solve -> trial point -> residuals AND normal equations at the
+//     trial point -> per-lane LM bookkeeping].  The nested g2o loops (outer iterations x LM trials) become per-lane
+//     state (iteration, trial, lambda, nu); an accepted trial's (H, b) is the next iteration's system (g2o recomputes
+//     exactly those numbers), a rejected trial only bumps lambda.  The first evaluation of an update (at the prior,
+//     which also applies the outlier gate) is just another pass with a zero step.
+//   * Lanes are NOT synchronised per epoch: a tag that finishes its update stores its result and moves on to its next
+//     epoch while its wave-mates are still iterating (LM trial counts differ per tag; synchronising per epoch costs
+//     max-over-wave instead of mean: +22 % at 32 tags/wave, +39 % at 64).  A wave keeps a two-epoch window: the next
+//     epoch's ranges sit converted in registers (a transition is a handful of register moves), the one after is in
+//     flight from HBM as raw floats; float->(measurement, information) conversion runs once per epoch for the whole
+//     wave in lockstep, when the slowest lane leaves the window's first epoch.
 //   * sum_m log(1 + chi_m) is evaluated as log(prod_m (1 + chi_m)): one f64 log per pass instead of M.
-//   * HBM layout: ranges as float4 tiles [K][M4][B] so a wave reads 16 B per lane, unit stride over tags;
-//     position state double [3][B] stays in registers across the K epochs of a launch; outputs are SoA doubles.
+//     1/x and (sqrt x, 1/sqrt x) come from v_rcp_f64 / v_rsq_f64 + FMA refinement (~1 ulp) instead of the IEEE
+//     division/sqrt expansions (operands are ranges and 1 + chi: always normal, positive).
+//   * HBM layout: ranges as float4 tiles [K][M4][B] (16 B per lane, unit stride over tags); position state double
+//     [3][B] stays in registers across the K epochs of a launch; outputs are SoA doubles.
 //   * Every workgroup does identical, independent work on a private slice of B, and the only shared data is the
 //     192-byte anchor table, so there is no L2 reuse to steer: blockIdx -> XCD mapping is left to the dispatcher.
 #include "snapshot_kernel.h"
@@ -61,6 +70,36 @@ __device__ __forceinline__ double group_prod(double v) {
     return v;
 }
 
+// ---- f64 reciprocal / sqrt from the hardware seeds + FMA refinement ------------------------------------
+// v_rcp_f64 seed, two Newton steps: ~1 ulp for normal, non-zero d (no div_scale / div_fixup range handling).
+__device__ __forceinline__ double fast_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return r;
+}
+// n = sqrt(x), inv = 1/sqrt(x) for normal x > 0: v_rsq_f64 seed, one Goldschmidt step, two residual corrections of
+// the root (what the compiler's own sqrt lowering does), one Newton step on the reciprocal.
+__device__ __forceinline__ void sqrt_and_rsqrt(double x, double& n, double& inv) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double dd = __builtin_fma(-g, g, x);
+    g = __builtin_fma(dd, h, g);
+    dd = __builtin_fma(-g, g, x);
+    g = __builtin_fma(dd, h, g);
+    double i = h + h;
+    const double e = __builtin_fma(-g, i, 1.0);
+    i = __builtin_fma(i, e, i);
+    n = g;
+    inv = i;
+}
+
 struct System {
     double h00, h01, h02, h11, h12, h22;  // J^T (rho' Omega) J
     double b0, b1, b2;                    // -J^T rho' Omega e
@@ -68,20 +107,22 @@ struct System {
     double chi;                           // sum chi (what optimizer.chi2() reports)
 };
 
-// g2o's numeric Jacobian evaluates e(p +- delta e_d) with delta = 1e-9; keep those few operations un-contracted so
-// the difference quotient sees the same roundings as the CPU restatement.
+// g2o's numeric Jacobian evaluates e(p +- delta e_d) with delta = 1e-9; keep those few operations un-contracted and
+// on the IEEE sqrt so the difference quotient sees (nearly) the same roundings as a CPU build.
 #pragma clang fp contract(off)
 __device__ __forceinline__ double range_norm_plain(double dx, double dy, double dz) {
     return sqrt(dx * dx + dy * dy + dz * dz);
 }
 #pragma clang fp contract(fast)
 
-// Residuals, robust weights, normal equations and both chi sums at point p, for this lane's APL anchors,
-// then combined over the LPI lanes of the tag.
+// Residuals, robust weights, normal equations and both chi sums at point p, for this lane's APL anchors, combined
+// over the LPI lanes of the tag.  `gate_now`: this is the first evaluation of an update (at the prior estimate) and
+// the outlier gate is armed: ranges with | ||p - a|| - d | > gate lose their weight for the whole update.
 template <int LPI, int APL, int JAC>
 __device__ __forceinline__ System evaluate(const double px, const double py, const double pz,
                                            const double (&ax)[APL], const double (&ay)[APL], const double (&az)[APL],
-                                           const double (&d)[APL], const double (&w)[APL]) {
+                                           const double (&d)[APL], double (&w)[APL], const bool gate_now,
+                                           const double gate) {
     System s = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     double prod = 1.0;
 #pragma unroll
@@ -89,9 +130,10 @@ __device__ __forceinline__ System evaluate(const double px, const double py, con
         const double dx = px - ax[j], dy = py - ay[j], dz = pz - az[j];
         double n, jx, jy, jz;  // J = de/dp
         if constexpr (JAC == 0) {
-            const double n2 = dx * dx + dy * dy + dz * dz;
-            n = sqrt(n2);
-            const double inv = n > 0.0 ? 1.0 / n : 0.0;  // coincident endpoints: J = 0
+            // coincident endpoints: n2 = 0 is clamped, dx = dy = dz = 0 -> J = 0
+            const double n2 = fmax(dx * dx + dy * dy + dz * dz, 1e-300);
+            double inv;
+            sqrt_and_rsqrt(n2, n, inv);
             jx = -dx * inv; jy = -dy * inv; jz = -dz * inv;
         } else {
             constexpr double delta = 1e-9;
@@ -105,14 +147,16 @@ __device__ __forceinline__ System evaluate(const double px, const double py, con
             jz = scalar * ((d[j] - range_norm_plain(dx, dy, zp)) - (d[j] - range_norm_plain(dx, dy, zm)));
         }
         const double e = d[j] - n;
-        const double chi = e * (w[j] * e);
+        if (gate_now && fabs(e) > gate) w[j] = 0.0;  // |d_hat - d| > distance_outlier, localization.cpp:309
+        const double we = w[j] * e;
+        const double chi = e * we;
         const double aux = 1.0 + chi;
-        const double rho1 = 1.0 / aux;
+        const double rho1 = fast_rcp(aux);
         const double wr = rho1 * w[j];
-        const double wre = -wr * e;  // omega_r
-        s.h00 += wr * jx * jx; s.h01 += wr * jx * jy; s.h02 += wr * jx * jz;
-        s.h11 += wr * jy * jy; s.h12 += wr * jy * jz; s.h22 += wr * jz * jz;
-        s.b0 += jx * wre; s.b1 += jy * wre; s.b2 += jz * wre;
+        const double wjx = wr * jx, wjy = wr * jy, wjz = wr * jz;
+        s.h00 = __builtin_fma(wjx, jx, s.h00); s.h01 = __builtin_fma(wjx, jy, s.h01); s.h02 = __builtin_fma(wjx, jz, s.h02);
+        s.h11 = __builtin_fma(wjy, jy, s.h11); s.h12 = __builtin_fma(wjy, jz, s.h12); s.h22 = __builtin_fma(wjz, jz, s.h22);
+        s.b0 = __builtin_fma(-wjx, e, s.b0); s.b1 = __builtin_fma(-wjy, e, s.b1); s.b2 = __builtin_fma(-wjz, e, s.b2);
         prod *= aux;
         s.chi += chi;
     }
@@ -126,33 +170,75 @@ __device__ __forceinline__ System evaluate(const double px, const double py, con
 
 // (H + lambda I) x = b by LDL^T; false if not positive definite (g2o: Cholesky failure).
 __device__ __forceinline__ bool solve3(const System& s, double lambda, double& x0, double& x1, double& x2) {
-    const double a00 = s.h00 + lambda, a11 = s.h11 + lambda, a22 = s.h22 + lambda;
-    const double d0 = a00;
-    const double i0 = 1.0 / d0;
+    const double d0 = s.h00 + lambda, a11 = s.h11 + lambda, a22 = s.h22 + lambda;
+    const double i0 = fast_rcp(d0);
     const double l10 = s.h01 * i0, l20 = s.h02 * i0;
-    const double d1 = a11 - l10 * s.h01;
-    const double i1 = 1.0 / d1;
-    const double l21 = (s.h12 - l20 * s.h01) * i1;
-    const double d2 = a22 - l20 * s.h02 - l21 * (s.h12 - l20 * s.h01);
+    const double d1 = __builtin_fma(-l10, s.h01, a11);
+    const double i1 = fast_rcp(d1);
+    const double t21 = __builtin_fma(-l20, s.h01, s.h12);
+    const double l21 = t21 * i1;
+    const double d2 = __builtin_fma(-l21, t21, __builtin_fma(-l20, s.h02, a22));
+    const double i2 = fast_rcp(d2);
     const bool ok = (d0 > 0.0) && (d1 > 0.0) && (d2 > 0.0) && (d2 < DBL_MAX);
     const double y0 = s.b0;
-    const double y1 = s.b1 - l10 * y0;
-    const double y2 = s.b2 - l20 * y0 - l21 * y1;
-    x2 = y2 / d2;
-    x1 = y1 * i1 - l21 * x2;
-    x0 = y0 * i0 - l10 * x1 - l20 * x2;
+    const double y1 = __builtin_fma(-l10, y0, s.b1);
+    const double y2 = __builtin_fma(-l21, y1, __builtin_fma(-l20, y0, s.b2));
+    x2 = y2 * i2;
+    x1 = __builtin_fma(-l21, x2, y1 * i1);
+    x0 = __builtin_fma(-l20, x2, __builtin_fma(-l10, x1, y0 * i0));
     return ok;
+}
+
+// float ranges of one epoch for this lane (16 / 8 / 4 B per lane, unit stride over tags)
+template <int APL>
+__device__ __forceinline__ void load_epoch(const SnapshotArgs& a, long long k, int m0, long long inst,
+                                           float (&df)[APL], float (&sf)[APL]) {
+    const long long B = a.B;
+    if constexpr (APL % 4 == 0) {
+#pragma unroll
+        for (int q4 = 0; q4 < APL / 4; ++q4) {
+            const long long idx = (k * a.M4 + (m0 / 4 + q4)) * B + inst;
+            const float4 dv = reinterpret_cast<const float4*>(a.dist)[idx];
+            const float4 sv = reinterpret_cast<const float4*>(a.err)[idx];
+            df[4 * q4 + 0] = dv.x; df[4 * q4 + 1] = dv.y; df[4 * q4 + 2] = dv.z; df[4 * q4 + 3] = dv.w;
+            sf[4 * q4 + 0] = sv.x; sf[4 * q4 + 1] = sv.y; sf[4 * q4 + 2] = sv.z; sf[4 * q4 + 3] = sv.w;
+        }
+    } else if constexpr (APL == 2) {
+        const long long idx = ((k * a.M4 + m0 / 4) * B + inst) * 2 + (m0 % 4) / 2;
+        const float2 dv = reinterpret_cast<const float2*>(a.dist)[idx];
+        const float2 sv = reinterpret_cast<const float2*>(a.err)[idx];
+        df[0] = dv.x; df[1] = dv.y; sf[0] = sv.x; sf[1] = sv.y;
+    } else {
+        static_assert(APL == 1 || APL == 2 || APL % 4 == 0, "anchors per lane");
+        const long long idx = ((k * a.M4 + m0 / 4) * B + inst) * 4 + (m0 % 4);
+        df[0] = a.dist[idx]; sf[0] = a.err[idx];
+    }
+}
+// cost definition: measurement as double, information 1/err^2 (localization.cpp:318, :615-620); unusable slots get 0
+template <int APL>
+__device__ __forceinline__ void ingest(const float (&df)[APL], const float (&sf)[APL], double (&d)[APL], double (&w)[APL]) {
+#pragma unroll
+    for (int j = 0; j < APL; ++j) {
+        const double dd = (double)df[j], ss = (double)sf[j];
+        const bool valid = (ss > 0.0) && (ss < DBL_MAX) && (fabs(dd) < DBL_MAX);
+        const double cov = valid ? ss * ss : 1.0;
+        const double mask = valid ? 1.0 : 0.0;
+        d[j] = valid ? dd : 0.0;
+        w[j] = fast_rcp(cov) * mask;  // (multiply, not select: keeps the reciprocal out of a divergent branch)
+    }
 }
 
 template <int LPI, int APL, int JAC>
 __global__ void __launch_bounds__(256) snapshot_lm_kernel(const SnapshotArgs a) {
-    constexpr int M_PAD = LPI * APL;
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    long long inst = tid / LPI;
+    const long long inst = tid / LPI;
     const int g = (int)(tid % LPI);
-    const bool live = inst < a.B;
-    if (!live) inst = a.B - 1;  // keep the lane in the DPP butterflies; it stores nothing
     const long long B = a.B;
+    const int K = a.K;
+    // all LPI lanes of a tag share `inst`, so a group is live or dead as a whole
+    const bool live = (inst < B) && K > 0;
+    const long long ld_inst = live ? inst : 0;  // dead lanes load tag 0's ranges (in bounds) and never store
+    bool exhausted = !live;
 
     // anchors of this lane (uniform -> SGPRs when LPI == 1)
     double ax[APL], ay[APL], az[APL];
@@ -163,75 +249,71 @@ __global__ void __launch_bounds__(256) snapshot_lm_kernel(const SnapshotArgs a) 
         ay[j] = a.anchors[(m0 + j) * 3 + 1];
         az[j] = a.anchors[(m0 + j) * 3 + 2];
     }
-    (void)M_PAD;
-
-    double px = a.pos[0 * B + inst], py = a.pos[1 * B + inst], pz = a.pos[2 * B + inst];
 
     constexpr double tau = 1e-5, good_lo = 1.0 / 3.0, good_hi = 2.0 / 3.0;
     constexpr int max_trials = 10;
 
-    for (int k = 0; k < a.K; ++k) {
-        // ---- ingest this epoch's ranges: 16 B (or 8/4 B) per lane, unit stride over tags -------------
-        float df[APL], sf[APL];
-        if constexpr (APL % 4 == 0) {
+    // Epoch window [c, c+1]: every live lane of the wave works on epoch c or c+1.
+    //   d, w   : this lane's current epoch (k)
+    //   dn, wn : epoch c+1, already converted to (measurement, information) for ALL lanes
+    //   dfr,sfr: raw float ranges of epoch c+2, in flight from HBM
+    // A lane that finishes epoch c takes (dn, wn) with register moves; one that finishes c+1 early waits until the
+    // slowest lane has left epoch c, at which point the whole wave converts c+2 in lockstep and prefetches c+3.
+    double px = 0, py = 0, pz = 0;
+    double d[APL], w[APL], dn[APL], wn[APL];
+    float dfr[APL], sfr[APL];
 #pragma unroll
-            for (int q4 = 0; q4 < APL / 4; ++q4) {
-                const long long grp = m0 / 4 + q4;
-                const long long idx = ((long long)k * a.M4 + grp) * B + inst;
-                const float4 dv = reinterpret_cast<const float4*>(a.dist)[idx];
-                const float4 sv = reinterpret_cast<const float4*>(a.err)[idx];
-                df[4 * q4 + 0] = dv.x; df[4 * q4 + 1] = dv.y; df[4 * q4 + 2] = dv.z; df[4 * q4 + 3] = dv.w;
-                sf[4 * q4 + 0] = sv.x; sf[4 * q4 + 1] = sv.y; sf[4 * q4 + 2] = sv.z; sf[4 * q4 + 3] = sv.w;
-            }
-        } else if constexpr (APL == 2) {
-            const long long idx = (((long long)k * a.M4 + m0 / 4) * B + inst) * 2 + (m0 % 4) / 2;
-            const float2 dv = reinterpret_cast<const float2*>(a.dist)[idx];
-            const float2 sv = reinterpret_cast<const float2*>(a.err)[idx];
-            df[0] = dv.x; df[1] = dv.y; sf[0] = sv.x; sf[1] = sv.y;
-        } else {
-            static_assert(APL == 1 || APL == 2 || APL % 4 == 0, "anchors per lane");
-            const long long idx = (((long long)k * a.M4 + m0 / 4) * B + inst) * 4 + (m0 % 4);
-            df[0] = a.dist[idx]; sf[0] = a.err[idx];
+    for (int j = 0; j < APL; ++j) { dn[j] = 0; wn[j] = 0; dfr[j] = 0; sfr[j] = 0; }
+    if (live) { px = a.pos[0 * B + inst]; py = a.pos[1 * B + inst]; pz = a.pos[2 * B + inst]; }
+    {
+        float df0[APL], sf0[APL];
+        load_epoch<APL>(a, 0, m0, ld_inst, df0, sf0);
+        ingest<APL>(df0, sf0, d, w);
+        if (K > 1) {
+            load_epoch<APL>(a, 1, m0, ld_inst, df0, sf0);
+            ingest<APL>(df0, sf0, dn, wn);
         }
-        // ---- cost definition: information 1/err^2, outlier gate on the prior estimate -----------------
-        double d[APL], w[APL];
-        double wsum = 0.0;
-        const bool gate_on = (a.gate > 0.0) && (k >= a.gate_from_epoch);
-#pragma unroll
-        for (int j = 0; j < APL; ++j) {
-            const double dd = (double)df[j], ss = (double)sf[j];
-            const bool valid = (ss > 0.0) && (ss < DBL_MAX) && (fabs(dd) < DBL_MAX);
-            double wj = valid ? 1.0 / (ss * ss) : 0.0;
-            const double dx = px - ax[j], dy = py - ay[j], dz = pz - az[j];
-            const double dhat = sqrt(dx * dx + dy * dy + dz * dz);
-            if (gate_on && fabs(dhat - dd) > a.gate) wj = 0.0;
-            d[j] = valid ? dd : 0.0;
-            w[j] = wj;
-            wsum += wj;
-        }
-        wsum = group_sum<LPI>(wsum);
+        if (K > 2) load_epoch<APL>(a, 2, m0, ld_inst, dfr, sfr);
+    }
 
-        // ---- g2o LM, flattened ---------------------------------------------------------------------------
-        System cur = evaluate<LPI, APL, JAC>(px, py, pz, ax, ay, az, d, w);
-        double cur_chi = cur.rchi;
-        double last_chi = cur.chi;
-        double lambda = tau * fmax(fabs(cur.h00), fmax(fabs(cur.h11), fabs(cur.h22)));  // computeLambdaInit
-        double ni = 2.0;
-        int it = 0, q = 0, trials = 0;
-        bool done = (a.iterations <= 0) || !(wsum > 0.0);  // no active edge: "0 vertices to optimize"
+    System cur = {1, 0, 0, 1, 0, 1, 0, 0, 0, 0, 0};
+    double cur_chi = 0, last_chi = 0, lambda = 1.0, ni = 2.0;
+    int c = 0;          // wave-uniform window base
+    int k = 0;          // this lane's epoch: c or c+1
+    int it = 0, q = 0, trials = 0;
+    bool init = true;   // next pass is the first evaluation of this epoch's update
+    bool waiting = false;
 
-        while (__any(!done)) {
-            double x0, x1, x2;
-            const bool ok2 = solve3(cur, lambda, x0, x1, x2);
-            if (!ok2) { x0 = 0.0; x1 = 0.0; x2 = 0.0; }
-            const double tx = px + x0, ty = py + x1, tz = pz + x2;  // oplus: t += R dt with R = I
-            const System tr = evaluate<LPI, APL, JAC>(tx, ty, tz, ax, ay, az, d, w);
-            const double temp_chi = ok2 ? tr.rchi : DBL_MAX;
-            double scale = x0 * (lambda * x0 + cur.b0) + x1 * (lambda * x1 + cur.b1) + x2 * (lambda * x2 + cur.b2);
-            scale += 1e-3;
-            const double rho = (cur_chi - temp_chi) / scale;
-            const bool accept = (rho > 0.0) && (fabs(temp_chi) < DBL_MAX) && ok2;
-            if (!done) {
+    while (__any(!exhausted)) {
+        const bool active = !exhausted && !waiting;
+        // ---- step: (H + lambda I) x = b; first pass of an update evaluates the prior itself -------------------
+        double x0, x1, x2;
+        const bool ok2 = solve3(cur, lambda, x0, x1, x2) && !init;
+        if (!ok2) { x0 = 0.0; x1 = 0.0; x2 = 0.0; }
+        const double tx = px + x0, ty = py + x1, tz = pz + x2;  // oplus: t += R dt with R = I
+        const bool gate_now = active && init && (a.gate > 0.0) && (k >= a.gate_from_epoch);
+        const System tr = evaluate<LPI, APL, JAC>(tx, ty, tz, ax, ay, az, d, w, gate_now, a.gate);
+
+        // ---- per-lane LM bookkeeping (g2o OptimizationAlgorithmLevenberg::solve + SparseOptimizer::optimize) ---
+        bool finished = false;
+        if (active) {
+            if (init) {
+                init = false;
+                cur = tr;
+                cur_chi = tr.rchi;
+                last_chi = tr.chi;
+                lambda = tau * fmax(fabs(tr.h00), fmax(fabs(tr.h11), fabs(tr.h22)));  // computeLambdaInit
+                ni = 2.0;
+                it = 0; q = 0; trials = 0;
+                // no active edge ("0 vertices to optimize") or nothing to iterate
+                finished = (a.iterations <= 0) || !((tr.h00 + tr.h11 + tr.h22) > 0.0);
+            } else {
+                const double temp_chi = ok2 ? tr.rchi : DBL_MAX;
+                double scale = x0 * __builtin_fma(lambda, x0, cur.b0) + x1 * __builtin_fma(lambda, x1, cur.b1) +
+                               x2 * __builtin_fma(lambda, x2, cur.b2);
+                scale += 1e-3;
+                const double rho = (cur_chi - temp_chi) / scale;
+                const bool accept = (rho > 0.0) && (fabs(temp_chi) < DBL_MAX) && ok2;
                 ++trials;
                 last_chi = tr.chi;
                 if (accept) {
@@ -251,22 +333,48 @@ __global__ void __launch_bounds__(256) snapshot_lm_kernel(const SnapshotArgs a) 
                 const bool again = (rho < 0.0) && (q < max_trials);
                 if (!again) {
                     ++it;
-                    if (q == max_trials || rho == 0.0 || it >= a.iterations) done = true;
+                    finished = (q == max_trials) || (rho == 0.0) || (it >= a.iterations);
                     q = 0;
                 }
             }
         }
 
-        if (live && g == 0) {
-            a.out_pos[((long long)k * 3 + 0) * B + inst] = px;
-            a.out_pos[((long long)k * 3 + 1) * B + inst] = py;
-            a.out_pos[((long long)k * 3 + 2) * B + inst] = pz;
-            a.out_chi2[(long long)k * B + inst] = last_chi;
-            if (a.out_trials) a.out_trials[(long long)k * B + inst] = (uint8_t)(trials > 255 ? 255 : trials);
+        // ---- lanes that just finished an update: emit, then step into the next epoch or wait for the window ------
+        if (__any(finished)) {
+            if (finished) {
+                if (g == 0) {
+                    a.out_pos[((long long)k * 3 + 0) * B + inst] = px;
+                    a.out_pos[((long long)k * 3 + 1) * B + inst] = py;
+                    a.out_pos[((long long)k * 3 + 2) * B + inst] = pz;
+                    a.out_chi2[(long long)k * B + inst] = last_chi;
+                    if (a.out_trials) a.out_trials[(long long)k * B + inst] = (uint8_t)(trials > 255 ? 255 : trials);
+                }
+                if (k + 1 >= K) {
+                    exhausted = true;
+                    if (g == 0) { a.pos[0 * B + inst] = px; a.pos[1 * B + inst] = py; a.pos[2 * B + inst] = pz; }
+                } else if (k == c) {
+#pragma unroll
+                    for (int j = 0; j < APL; ++j) { d[j] = dn[j]; w[j] = wn[j]; }
+                    k = c + 1;
+                    init = true;
+                } else {
+                    waiting = true;  // a full epoch ahead of the slowest lane of this wave
+                }
+            }
         }
-    }
-    if (live && g == 0) {
-        a.pos[0 * B + inst] = px; a.pos[1 * B + inst] = py; a.pos[2 * B + inst] = pz;
+        // ---- window advance: nobody is left in epoch c -> convert epoch c+2 for all lanes, prefetch c+3 --------------
+        if (!__any(!exhausted && k == c)) {
+            ++c;
+            ingest<APL>(dfr, sfr, dn, wn);  // epoch c+1 (garbage-but-unused once c+1 >= K)
+            if (c + 2 < K) load_epoch<APL>(a, c + 2, m0, ld_inst, dfr, sfr);
+            if (waiting) {  // k == c now: release into epoch c+1
+#pragma unroll
+                for (int j = 0; j < APL; ++j) { d[j] = dn[j]; w[j] = wn[j]; }
+                k = c + 1;
+                init = true;
+                waiting = false;
+            }
+        }
     }
 }
 
