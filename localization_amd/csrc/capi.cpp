@@ -90,7 +90,7 @@ int loc_snapshot_create(loc_snapshot** out, int32_t device, int64_t batch, int32
     const int M_PAD = 4 * M4;
     if (M_PAD > 16) return fail(LOC_ERR_UNSUPPORTED, "more than 16 anchors per tag");
     int lpi = prm.lanes_per_instance;
-    if (lpi == 0) lpi = locamd::snapshot_supported(M_PAD, 2) ? 2 : 1;
+    if (lpi == 0) lpi = (M_PAD == 16) ? 2 : 1;  // measured on MI355X: one lane per tag is fastest up to 12 anchors
     if (!locamd::snapshot_supported(M_PAD, lpi)) return fail(LOC_ERR_UNSUPPORTED, "lanes_per_instance for this anchor count");
     if (prm.block_threads == 0) prm.block_threads = 256;
     if (prm.gate_warmup_epochs < 0) return fail(LOC_ERR_INVALID, "gate_warmup_epochs");

@@ -28,8 +28,8 @@
 //     flight from HBM as raw floats; float->(measurement, information) conversion runs once per epoch for the whole
 //     wave in lockstep, when the slowest lane leaves the window's first epoch.
 //   * sum_m log(1 + chi_m) is evaluated as log(prod_m (1 + chi_m)): one f64 log per pass instead of M.
-//     1/x and (sqrt x, 1/sqrt x) come from v_rcp_f64 / v_rsq_f64 + FMA refinement (~1 ulp) instead of the IEEE
-//     division/sqrt expansions (operands are ranges and 1 + chi: always normal, positive).
+//     1/x and (sqrt x, 1/sqrt x) come from v_rcp_f64 / v_rsq_f64 + FMA refinement instead of the IEEE division/sqrt
+//     expansions (operands are ranges, 1 + chi, pivots: always normal); ranges keep the builtin sqrt's 1.1e-16 bound.
 //   * HBM layout: ranges as float4 tiles [K][M4][B] (16 B per lane, unit stride over tags); position state double
 //     [3][B] stays in registers across the K epochs of a launch; outputs are SoA doubles.
 //   * Every workgroup does identical, independent work on a private slice of B, and the only shared data is the
@@ -71,7 +71,9 @@ __device__ __forceinline__ double group_prod(double v) {
 }
 
 // ---- f64 reciprocal / sqrt from the hardware seeds + FMA refinement ------------------------------------
-// v_rcp_f64 seed, two Newton steps: ~1 ulp for normal, non-zero d (no div_scale / div_fixup range handling).
+// Accuracies measured on MI355X with tools/math_probe.hip (profiles/r01_math_probe.txt); operands here are ranges,
+// 1 + chi and pivots: normal, positive, so no div_scale / div_fixup range handling is needed.
+// v_rcp_f64 seed (4.6e-8) + two Newton steps: 1.1e-16 relative (as good as an IEEE divide).
 __device__ __forceinline__ double fast_rcp(double d) {
     double r = __builtin_amdgcn_rcp(d);
     double e = __builtin_fma(-d, r, 1.0);
@@ -80,8 +82,15 @@ __device__ __forceinline__ double fast_rcp(double d) {
     r = __builtin_fma(r, e, r);
     return r;
 }
-// n = sqrt(x), inv = 1/sqrt(x) for normal x > 0: v_rsq_f64 seed, one Goldschmidt step, two residual corrections of
-// the root (what the compiler's own sqrt lowering does), one Newton step on the reciprocal.
+// one Newton step: 2.2e-15 relative — used for the robust weight rho' = 1/(1 + chi), which scales H and b alike.
+__device__ __forceinline__ double fast_rcp_1nr(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    const double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return r;
+}
+// n = sqrt(x) to 1.1e-16 relative (identical error bound to the builtin sqrt: v_rsq_f64 seed, one Goldschmidt step, one
+// residual correction) and inv = 1/sqrt(x) to 4.2e-15 (only scales the unit vector of the Jacobian).
 __device__ __forceinline__ void sqrt_and_rsqrt(double x, double& n, double& inv) {
     const double y = __builtin_amdgcn_rsq(x);
     double g = x * y;
@@ -89,15 +98,9 @@ __device__ __forceinline__ void sqrt_and_rsqrt(double x, double& n, double& inv)
     const double r = __builtin_fma(-h, g, 0.5);
     g = __builtin_fma(g, r, g);
     h = __builtin_fma(h, r, h);
-    double dd = __builtin_fma(-g, g, x);
-    g = __builtin_fma(dd, h, g);
-    dd = __builtin_fma(-g, g, x);
-    g = __builtin_fma(dd, h, g);
-    double i = h + h;
-    const double e = __builtin_fma(-g, i, 1.0);
-    i = __builtin_fma(i, e, i);
-    n = g;
-    inv = i;
+    const double dd = __builtin_fma(-g, g, x);
+    n = __builtin_fma(dd, h, g);
+    inv = h + h;
 }
 
 struct System {
@@ -151,7 +154,7 @@ __device__ __forceinline__ System evaluate(const double px, const double py, con
         const double we = w[j] * e;
         const double chi = e * we;
         const double aux = 1.0 + chi;
-        const double rho1 = fast_rcp(aux);
+        const double rho1 = fast_rcp_1nr(aux);
         const double wr = rho1 * w[j];
         const double wjx = wr * jx, wjy = wr * jy, wjz = wr * jz;
         s.h00 = __builtin_fma(wjx, jx, s.h00); s.h01 = __builtin_fma(wjx, jy, s.h01); s.h02 = __builtin_fma(wjx, jz, s.h02);
@@ -312,7 +315,7 @@ __global__ void __launch_bounds__(256) snapshot_lm_kernel(const SnapshotArgs a) 
                 double scale = x0 * __builtin_fma(lambda, x0, cur.b0) + x1 * __builtin_fma(lambda, x1, cur.b1) +
                                x2 * __builtin_fma(lambda, x2, cur.b2);
                 scale += 1e-3;
-                const double rho = (cur_chi - temp_chi) / scale;
+                const double rho = (cur_chi - temp_chi) * fast_rcp(scale);
                 const bool accept = (rho > 0.0) && (fabs(temp_chi) < DBL_MAX) && ok2;
                 ++trials;
                 last_chi = tr.chi;
