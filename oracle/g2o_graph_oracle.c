@@ -457,6 +457,22 @@ static void edge_linearize(og_graph* g, edge_t* e, int jac_mode) {
     }
 }
 
+int og_debug_linearize(og_graph* g, int edge_index, int jac_mode, double* err6, double* J0, double* J1) {
+    int n = 0;
+    for (int i = 0; i < g->nE; ++i) {
+        edge_t* e = &g->E[i];
+        if (!e->alive) continue;
+        if (n++ != edge_index) continue;
+        edge_compute_error(g, e);
+        edge_linearize(g, e, jac_mode);
+        if (err6) memcpy(err6, e->err, sizeof(double) * 6);
+        if (J0) memcpy(J0, e->J[0], sizeof(double) * 36);
+        if (J1) memcpy(J1, e->J[1], sizeof(double) * 36);
+        return e->dim;
+    }
+    return -1;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * A.5 initializeOptimization
  * ---------------------------------------------------------------------------------------------- */

@@ -67,6 +67,8 @@ int og_optimize(og_graph* g, int iterations, int jac_mode, og_stats* stats);
 double og_chi2(og_graph* g);
 
 /* helpers exposed for known-answer tests */
+/* error (dim 1 or 6) and Jacobians (dim x 6 row-major per endpoint) of the edge_index-th live edge (creation order) */
+int og_debug_linearize(og_graph* g, int edge_index, int jac_mode, double* err6, double* J0_36, double* J1_36);
 void og_quat_to_R(const double* q_wxyz, double* R);          /* Eigen toRotationMatrix, no normalisation */
 void og_R_to_quat(const double* R, double* q_wxyz);          /* Eigen Quaternion(R) */
 void og_from_vector_mqt(const double* v6, double* R, double* t);

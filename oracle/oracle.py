@@ -67,6 +67,7 @@ def lib():
         L.og_R_to_quat.argtypes = [dp, dp]
         L.og_from_vector_mqt.argtypes = [dp, dp, dp]
         L.og_to_vector_mqt.argtypes = [dp, dp, dp]
+        L.og_debug_linearize.argtypes = [C.c_void_p, C.c_int, C.c_int, dp, dp, dp]
         L.og_cauchy_rho.argtypes = [C.c_double, dp]
         L.og_cauchy_rho.restype = C.c_double
         L.og_snapshot_batch.argtypes = [C.c_int, C.c_int, C.c_int, dp, C.POINTER(C.c_float), C.POINTER(C.c_float),
@@ -146,6 +147,12 @@ class Graph:
 
     def chi2(self):
         return self.L.og_chi2(self.h)
+
+    def linearize(self, edge_index, jac_mode=JAC_NUMERIC_G2O):
+        err = np.zeros(6); J0 = np.zeros((6, 6)); J1 = np.zeros((6, 6))
+        dim = self.L.og_debug_linearize(self.h, edge_index, jac_mode, _dp(err), _dp(J0), _dp(J1))
+        assert dim > 0
+        return err[:dim].copy(), J0[:dim].copy(), J1[:dim].copy()
 
 
 def snapshot_batch(anchors, dist, err, pos, iterations=10, gate=1.0, jac_mode=JAC_NUMERIC_G2O, gate_from_epoch=1):

@@ -1,0 +1,178 @@
+"""Pin the oracle against committed golden vectors.
+
+tests/golden/scipy_minima.npz  — minima of the same robust objective found by an independent optimiser
+                                 (tools/make_golden_scipy.py; scipy, not the reference).
+tests/golden/bag_example.npz   — numeric content of the reference's own recording bag/data_example.bag
+                                 (tools/decode_bag.py): UWB ranges, IMU orientations, Vicon ground truth.
+The reference holds no golden outputs for this path, so parity against the reference itself stays "unpinned".
+"""
+import os
+
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation
+
+from oracle import oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(GOLD, "scipy_minima.npz"))
+
+
+@pytest.fixture(scope="module")
+def bag():
+    return np.load(os.path.join(GOLD, "bag_example.npz"))
+
+
+def _cost_3dof(p, anchors, d, s):
+    e = (d.astype(float) - np.linalg.norm(p[None] - anchors, axis=1)) / s.astype(float)
+    return np.log1p(e * e).sum()
+
+
+@pytest.mark.parametrize("mode", [O.JAC_NUMERIC_G2O, O.JAC_ANALYTIC])
+def test_snapshot_minima_match_scipy(gold, mode):
+    A = gold["a_anchors"]
+    N = gold["a_dist"].shape[0]
+    dist = np.ascontiguousarray(gold["a_dist"].T[None])          # [1, M, B]
+    err = np.ascontiguousarray(gold["a_err"].T[None])
+    pos, chi2, trials, _ = O.snapshot_batch(A, dist, err, gold["a_init"].T.copy(), iterations=400, gate=0.0,
+                                            jac_mode=mode)
+    got = pos[0].T
+    same_basin = 0
+    for i in range(N):
+        if np.abs(got[i] - gold["a_min"][i]).max() < 1e-6:
+            same_basin += 1
+            continue
+        # 8 % NLOS ranges make the robust cost multi-modal: LM and scipy's trust region may settle in different
+        # basins from the same start.  Then the oracle's answer must itself be a minimiser: scipy restarted from it
+        # stays put, and the stored golden is not a better minimum by more than the basin difference allows.
+        from scipy.optimize import least_squares
+        f = lambda p: np.sign(r := (gold["a_dist"][i].astype(float) - np.linalg.norm(p[None] - A, axis=1))
+                              / gold["a_err"][i].astype(float)) * np.sqrt(np.log1p(r * r))
+        pol = least_squares(f, got[i], xtol=1e-15, ftol=1e-15, gtol=1e-15)
+        assert np.abs(pol.x - got[i]).max() < 1e-6, (i, got[i], pol.x)
+    assert same_basin >= int(0.9 * N), same_basin
+
+
+def test_fusion_6dof_minima_match_scipy(gold):
+    """6-DoF vertex, antenna lever arm on endpoint 0 (localization.cpp:333-334), rotation-only EdgeSE3Prior with the
+    bag's IMU covariance (localization.cpp:515-525)."""
+    A = gold["b_anchors"]; off = gold["b_offset"]; cov = float(gold["b_cov"])
+    info = np.zeros((6, 6)); info[3, 3] = info[4, 4] = info[5, 5] = 1.0 / cov
+    for i in range(gold["b_dist"].shape[0]):
+        Rm = Rotation.from_quat(gold["b_imu_q_xyzw"][i]).as_matrix()
+        g = O.Graph()
+        for m, a in enumerate(A): g.add_vertex(m, a, fixed=True)
+        g.add_vertex(100, gold["b_init_t"][i], Rm)                       # addImuEdge overwrites R with the IMU's
+        for m in range(8):
+            s = float(gold["b_err"][i, m])
+            g.add_range_edge(100, m, float(gold["b_dist"][i, m]), 1.0 / (s * s), off0=off)
+        g.add_prior_edge(100, gold["b_init_t"][i], Rm, info)
+        g.optimize(300, O.JAC_NUMERIC_G2O)
+        R, t = g.estimate(100)
+        assert np.abs(t - gold["b_min_t"][i]).max() < 2e-6
+        dq = (Rotation.from_matrix(R).inv() * Rotation.from_quat(gold["b_min_q_xyzw"][i])).magnitude()
+        assert dq < 2e-6
+
+
+def test_window_minima_match_scipy(gold):
+    """5-pose window in the reference's topology: one Cauchy range per pose + Cauchy zero-range smoothness edges
+    (localization.cpp:331-340)."""
+    A = gold["c_anchors"]; sig_v = float(gold["c_sigma_v"])
+    for i in range(gold["c_dist"].shape[0]):
+        g = O.Graph()
+        for m, a in enumerate(A): g.add_vertex(m, a, fixed=True)
+        g.add_vertex(50, gold["c_prev"][i], fixed=True)
+        T = gold["c_dist"].shape[1]
+        for k in range(T):
+            g.add_vertex(100 + k, gold["c_init"][i, k])
+        for k in range(T):
+            g.add_range_edge(100 + k, int(gold["c_anchor_idx"][i, k]), float(gold["c_dist"][i, k]), 1.0 / 0.055 ** 2)
+            g.add_range_edge(50 if k == 0 else 100 + k - 1, 100 + k, 0.0, 1.0 / sig_v ** 2)
+        for j, m in enumerate((1, 2)):
+            g.add_range_edge(100 + T - 1, m, float(gold["c_extra"][i, j]), 1.0 / 0.055 ** 2)
+        g.optimize(500, O.JAC_ANALYTIC)
+        got = np.array([g.estimate(100 + k)[1] for k in range(T)])
+        assert np.abs(got - gold["c_min"][i]).max() < 5e-5, (i, np.abs(got - gold["c_min"][i]).max())
+
+
+# ---- the reference's own recording ---------------------------------------------------------------------------
+def test_bag_fixture_matches_what_the_survey_decoded(bag):
+    assert bag["uwb_stamp"].shape == (1444,) and bag["imu_stamp"].shape == (4514,) and bag["vicon_stamp"].shape == (1965,)
+    assert list(bag["anchor_ids"]) == [100, 101, 102, 103]
+    assert np.allclose(bag["anchor_pos"], [[3, -3, 0.58], [3, 3, 1.97], [-3, 3, 0.54], [-3, -3, 1.76]])
+    assert set(bag["uwb_requester"]) == {200} and set(bag["uwb_antenna"]) == {1}
+    assert set(np.round(bag["uwb_distance_err"].astype(np.float64), 3)) == {0.024, 0.055}
+    assert str(bag["frame_uwb"]) == "uwb" and str(bag["frame_imu"]) == "imu_link"
+    assert np.allclose(bag["imu_orientation_cov_diag"], 4.592449e-06)
+    assert 2.1 < bag["uwb_distance"].min() and bag["uwb_distance"].max() < 6.7
+
+
+def _replay(bag, cfg, with_imu=False, jac=O.JAC_NUMERIC_G2O, antenna_offsets=None):
+    ids = list(bag["anchor_ids"]) + [200]
+    pos = np.concatenate([bag["anchor_pos"], [[0.0, 0.0, 1.0]]])
+    lo = O.LocalizationOracle(ids, pos, jac_mode=jac, antenna_offsets=antenna_offsets, **cfg)
+    ev = [(t, 0, i) for i, t in enumerate(bag["uwb_rectime"])]
+    if with_imu:
+        ev += [(t, 1, i) for i, t in enumerate(bag["imu_rectime"])]
+    ev.sort()
+    rt, op, chi = [], [], []
+    for _, kind, i in ev:
+        if kind == 0:
+            o = lo.add_range(200, int(bag["uwb_responder"][i]), float(bag["uwb_stamp"][i]), bag["uwb_distance"][i],
+                             bag["uwb_distance_err"][i], int(bag["uwb_antenna"][i]), "uwb")
+            assert o["rc"] >= 0
+            if o["solved"] and o["published"]:
+                rt.append(o["realtime"]); op.append(o["optimized"]); chi.append(o["chi2"])
+        else:
+            lo.add_imu(float(bag["imu_stamp"][i]), bag["imu_q_xyzw"][i],
+                       np.diag(bag["imu_orientation_cov_diag"][i]).ravel(), "imu_link")
+    return np.array(rt), np.array(op), np.array(chi)
+
+
+def _rmse_vs_vicon(bag, traj):
+    v = np.stack([np.interp(traj[:, 0], bag["vicon_stamp"], bag["vicon_pos"][:, c]) for c in range(3)], 1)
+    e = traj[:, 1:4] - v
+    return np.sqrt((e ** 2).mean(axis=0))
+
+
+def test_bag_uwb_only_config1(bag):
+    """BASELINE config 1: cfg/uwb_only.yaml solver parameters (T=10, vmax 5, outlier 1 m, 10 iterations, gate 2000)
+    on the example bag; the range topic is mapped to the bag's /uwb_endorange_info (SURVEY §8(c) caveat)."""
+    cfg = dict(trajectory_length=10, maximum_velocity=5.0, distance_outlier=1.0, maximum_iteration=10,
+               minimum_optimize_error=2000.0, publish_range=True)
+    rt, op, chi = _replay(bag, cfg)
+    assert len(rt) > 1400                      # warm-up (10) + a few gated ranges are not published
+    r = _rmse_vs_vicon(bag, rt)
+    # sanity band from SURVEY §4 (naive per-epoch trilateration: 0.050 / 0.052 / 0.197 m); z is weakly observable
+    assert r[0] < 0.08 and r[1] < 0.08 and r[2] < 0.25, r
+    ro = _rmse_vs_vicon(bag, op)
+    assert ro[0] < 0.08 and ro[1] < 0.08 and ro[2] < 0.25, ro
+    assert np.isfinite(chi).all() and (chi < 2000).all()
+    # analytic-Jacobian mode: same ATE within 1 mm (SURVEY §8(c) bag-level tolerance).  Pointwise the two differ more
+    # where the 10-pose window is weakly constrained (one range per pose, z barely observable) and 10 iterations
+    # have not converged (differences then carry forward through the window state): median ~2e-4 m, worst ~1 cm.
+    rt2, _, _ = _replay(bag, cfg, jac=O.JAC_ANALYTIC)
+    assert len(rt2) == len(rt)
+    assert np.abs(_rmse_vs_vicon(bag, rt2) - r).max() < 1e-3
+    dd = np.abs(rt2[:, 1:4] - rt[:, 1:4]).max(axis=1)
+    assert np.median(dd) < 1e-3 and dd.max() < 0.05
+
+
+def test_bag_uwb_imu_config(bag):
+    """cfg/uwb_imu.yaml (T=12, vmax 3, outlier 3 m, 10 iterations, gate 1000) with IMU orientation priors interleaved
+    in recorded order; a lever arm couples the rotation into the ranges."""
+    cfg = dict(trajectory_length=12, maximum_velocity=3.0, distance_outlier=3.0, maximum_iteration=10,
+               minimum_optimize_error=1000.0, publish_range=True, publish_imu=False)
+    rt, op, chi = _replay(bag, cfg, with_imu=True, antenna_offsets=[[0.05, 0.0, -0.02]] * 3)
+    assert len(rt) > 1380
+    r = _rmse_vs_vicon(bag, rt)
+    assert r[0] < 0.1 and r[1] < 0.1 and r[2] < 0.3, r
+    # published orientation is the IMU's (prior weight 1/4.6e-6 >> anything the ranges say about rotation)
+    k = len(rt) // 2
+    j = np.searchsorted(bag["imu_stamp"], rt[k, 0])
+    q_pub = Rotation.from_quat(rt[k, 4:8]); q_imu = Rotation.from_quat(bag["imu_q_xyzw"][max(j - 1, 0)])
+    assert (q_pub.inv() * q_imu).magnitude() < 0.05
