@@ -114,6 +114,43 @@ int loc_snapshot_solve_host(loc_snapshot* s, int32_t epochs, const float* dist_t
 int loc_snapshot_timing_begin(loc_snapshot* s, int32_t max_launches);
 int loc_snapshot_timing_end(loc_snapshot* s, int32_t* n_launches, double* total_ms, double* avg_ms);
 
+
+/* ================================================================================================
+ * Batched sliding-window graph solver — the reference's general case (BASELINE configs 1, 3, 5 shapes):
+ * B independent instances, each the graph one Localization object holds when it calls solve()
+ * (localization.cpp:164-170): moving VertexSE3 poses (robot.cpp:75-110), fixed anchors, EdgeSE3Range factors
+ * with an antenna lever arm on endpoint 0 (localization.cpp:331-340, types_edge_se3range.cpp:105-114),
+ * EdgeSE3Prior with diagonal information (IMU / lidar, localization.cpp:476-486, 513-525) and EdgeSE3
+ * (pose / twist, localization.cpp:263-281, 588-602).  Range and SE3 edges carry RobustKernelCauchy(1) as in the
+ * reference (range always; SE3 per the `robust` flag); priors do not.  Jacobians are analytic.
+ *
+ * Host layouts (arrays of B instances, fixed capacities per instance):
+ *   counts int32 [B][4]           nv, nr, np, ns  (poses, range edges, priors, SE3 edges actually used)
+ *   poses  double[B][nv_max][12]  R row-major (9), t (3); in: estimates, out: optimised estimates
+ *   r_idx  int32 [B][nr_max][2]   v0 = pose slot; v1 = pose slot, or -1 - anchor_index for a fixed anchor
+ *   r_val  double[B][nr_max][5]   measurement, information (1/cov), lever arm xyz of endpoint 0
+ *   p_idx  int32 [B][np_max]      pose slot
+ *   p_val  double[B][np_max][18]  INVERSE measurement Z^-1 as R(9), t(3); information diagonal (6)
+ *   s_idx  int32 [B][ns_max][4]   vi, vj, robust (0/1), 0
+ *   s_val  double[B][ns_max][48]  INVERSE measurement Z^-1 as R(9), t(3); information 6x6 row-major
+ *   result double[B][8]           chi2() over all edges at the last evaluated state, robust chi2 of the accepted
+ *                                 state, final lambda, outer iterations run, LM trials, terminated flag, 0, 0
+ * Limits: nv_max <= 16, nr_max <= 64, np_max <= 32, ns_max <= 32 and the per-instance LDS footprint <= 160 KiB.
+ * ============================================================================================== */
+typedef struct loc_window loc_window;
+typedef struct loc_window_caps { int32_t nv_max, nr_max, np_max, ns_max; } loc_window_caps;
+
+int loc_window_create(loc_window** out, int32_t device, int64_t batch, const loc_window_caps* caps,
+                      int32_t n_anchors, const double* anchors_xyz_host, int32_t maximum_iteration);
+int loc_window_destroy(loc_window* w);
+size_t loc_window_lds_bytes(const loc_window_caps* caps);
+/* Synchronous: stages the B instances over PCIe, runs one launch, copies poses and results back. */
+int loc_window_solve_host(loc_window* w, int64_t n_instances, const int32_t* counts, double* poses,
+                          const int32_t* r_idx, const double* r_val, const int32_t* p_idx, const double* p_val,
+                          const int32_t* s_idx, const double* s_val, double* result);
+/* kernel time of the last loc_window_solve_host launch (HIP events on its stream), milliseconds */
+int loc_window_last_kernel_ms(loc_window* w, double* ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,8 +9,9 @@ solver constructors raise.
 from ._lib import LocalizationAmdError, abi_version, device_count, lib, library_path
 from .config import LocalizationConfig, load_config
 from .snapshot import SnapshotSolver, pack_ranges, unpack_ranges
+from .window import WindowBatch, WindowSolver
 
 __all__ = [
     "LocalizationAmdError", "abi_version", "device_count", "lib", "library_path",
-    "LocalizationConfig", "load_config", "SnapshotSolver", "pack_ranges", "unpack_ranges",
+    "LocalizationConfig", "load_config", "SnapshotSolver", "pack_ranges", "unpack_ranges", "WindowBatch", "WindowSolver",
 ]

@@ -36,6 +36,8 @@ EXPORTED_SYMBOLS = [
     "loc_snapshot_epochs_done", "loc_snapshot_set_epochs_done",
     "loc_snapshot_pack_ranges_host", "loc_snapshot_solve_device", "loc_snapshot_solve_host",
     "loc_snapshot_timing_begin", "loc_snapshot_timing_end",
+    "loc_window_create", "loc_window_destroy", "loc_window_lds_bytes", "loc_window_solve_host",
+    "loc_window_last_kernel_ms",
 ]
 
 
@@ -70,6 +72,12 @@ def lib():
     L.loc_snapshot_solve_host.argtypes = [vp, C.c_int32, fp, fp, dp, dp, C.POINTER(C.c_uint8)]
     L.loc_snapshot_timing_begin.argtypes = [vp, C.c_int32]
     L.loc_snapshot_timing_end.argtypes = [vp, C.POINTER(C.c_int32), dp, dp]
+    ip = C.POINTER(C.c_int32)
+    L.loc_window_create.argtypes = [C.POINTER(vp), C.c_int32, C.c_int64, vp, C.c_int32, dp, C.c_int32]
+    L.loc_window_destroy.argtypes = [vp]
+    L.loc_window_lds_bytes.argtypes = [vp]; L.loc_window_lds_bytes.restype = C.c_size_t
+    L.loc_window_solve_host.argtypes = [vp, C.c_int64, ip, dp, ip, dp, ip, dp, ip, dp, dp]
+    L.loc_window_last_kernel_ms.argtypes = [vp, dp]
     _LIB = L
     return L
 

@@ -32,6 +32,10 @@ int fail_hip(hipError_t e, const char* where) {
 
 }  // namespace
 
+// shared with the other capi_*.cpp files
+int locamd_fail(int code, const char* what) { return fail(code, what); }
+int locamd_fail_hip(hipError_t e, const char* where) { return fail_hip(e, where); }
+
 struct loc_snapshot {
     int device = 0;
     long long B = 0;

@@ -1,0 +1,164 @@
+// C ABI of the batched sliding-window solver (see include/localization_amd.h). Host side only.
+#include "../../include/localization_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+#include "window_kernel.h"
+
+extern int locamd_fail(int code, const char* what);
+extern int locamd_fail_hip(hipError_t e, const char* where);
+#define LOC_HIP(expr)                                              \
+    do {                                                           \
+        hipError_t _e = (expr);                                    \
+        if (_e != hipSuccess) return locamd_fail_hip(_e, #expr);   \
+    } while (0)
+
+struct loc_window {
+    int device = 0;
+    long long B = 0;
+    locamd::WindowCaps caps{};
+    int n_anchors = 0;
+    int iterations = 10;
+    double* d_anchors = nullptr;
+    int32_t *d_counts = nullptr, *d_ridx = nullptr, *d_pidx = nullptr, *d_sidx = nullptr;
+    double *d_poses = nullptr, *d_rval = nullptr, *d_pval = nullptr, *d_sval = nullptr, *d_result = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double last_ms = 0.0;
+};
+
+extern "C" {
+
+size_t loc_window_lds_bytes(const loc_window_caps* caps) {
+    if (!caps) return 0;
+    locamd::WindowCaps c{caps->nv_max, caps->nr_max, caps->np_max, caps->ns_max};
+    return locamd::window_lds_bytes(c);
+}
+
+int loc_window_destroy(loc_window* w) {
+    if (!w) return LOC_OK;
+    (void)hipSetDevice(w->device);
+    void* ptrs[] = {w->d_anchors, w->d_counts, w->d_ridx, w->d_pidx, w->d_sidx, w->d_poses, w->d_rval, w->d_pval, w->d_sval, w->d_result};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (w->ev0) (void)hipEventDestroy(w->ev0);
+    if (w->ev1) (void)hipEventDestroy(w->ev1);
+    if (w->stream) (void)hipStreamDestroy(w->stream);
+    delete w;
+    return LOC_OK;
+}
+
+int loc_window_create(loc_window** out, int32_t device, int64_t batch, const loc_window_caps* caps,
+                      int32_t n_anchors, const double* anchors, int32_t maximum_iteration) {
+    if (!out) return locamd_fail(LOC_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (batch <= 0 || !caps || n_anchors < 0 || (n_anchors > 0 && !anchors)) return locamd_fail(LOC_ERR_INVALID, "window arguments");
+    if (caps->nv_max <= 0 || caps->nv_max > 16 || caps->nr_max < 0 || caps->nr_max > 64 || caps->np_max < 0 ||
+        caps->np_max > 32 || caps->ns_max < 0 || caps->ns_max > 32)
+        return locamd_fail(LOC_ERR_UNSUPPORTED, "window capacities (nv<=16, nr<=64, np<=32, ns<=32)");
+    if (loc_window_lds_bytes(caps) > 160 * 1024) return locamd_fail(LOC_ERR_UNSUPPORTED, "window does not fit 160 KiB of LDS");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return locamd_fail(LOC_ERR_NO_DEVICE, "no HIP device visible: localization_amd has no CPU fallback");
+    if (device < 0 || device >= ndev) return locamd_fail(LOC_ERR_INVALID, "device index out of range");
+    LOC_HIP(hipSetDevice(device));
+    loc_window* w = new (std::nothrow) loc_window();
+    if (!w) return locamd_fail(LOC_ERR_INVALID, "out of host memory");
+    w->device = device; w->B = batch; w->n_anchors = n_anchors; w->iterations = maximum_iteration;
+    w->caps = locamd::WindowCaps{caps->nv_max, caps->nr_max, caps->np_max, caps->ns_max};
+    const size_t B = (size_t)batch;
+    const size_t na = (size_t)(n_anchors > 0 ? n_anchors : 1);
+    hipError_t e;
+    auto alloc = [&](void** p, size_t bytes) { return hipMalloc(p, bytes ? bytes : 8); };
+    if ((e = alloc((void**)&w->d_anchors, na * 3 * sizeof(double))) != hipSuccess ||
+        (e = alloc((void**)&w->d_counts, B * 4 * sizeof(int32_t))) != hipSuccess ||
+        (e = alloc((void**)&w->d_poses, B * caps->nv_max * 12 * sizeof(double))) != hipSuccess ||
+        (e = alloc((void**)&w->d_ridx, B * caps->nr_max * 2 * sizeof(int32_t))) != hipSuccess ||
+        (e = alloc((void**)&w->d_rval, B * caps->nr_max * 5 * sizeof(double))) != hipSuccess ||
+        (e = alloc((void**)&w->d_pidx, B * caps->np_max * sizeof(int32_t))) != hipSuccess ||
+        (e = alloc((void**)&w->d_pval, B * caps->np_max * 18 * sizeof(double))) != hipSuccess ||
+        (e = alloc((void**)&w->d_sidx, B * caps->ns_max * 4 * sizeof(int32_t))) != hipSuccess ||
+        (e = alloc((void**)&w->d_sval, B * caps->ns_max * 48 * sizeof(double))) != hipSuccess ||
+        (e = alloc((void**)&w->d_result, B * 8 * sizeof(double))) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&w->ev0)) != hipSuccess || (e = hipEventCreate(&w->ev1)) != hipSuccess ||
+        (n_anchors > 0 && (e = hipMemcpy(w->d_anchors, anchors, (size_t)n_anchors * 3 * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess)) {
+        loc_window_destroy(w);
+        return locamd_fail_hip(e, "loc_window_create");
+    }
+    *out = w;
+    return LOC_OK;
+}
+
+int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, double* poses, const int32_t* r_idx,
+                          const double* r_val, const int32_t* p_idx, const double* p_val, const int32_t* s_idx,
+                          const double* s_val, double* result) {
+    if (!w || !counts || !poses || !result) return locamd_fail(LOC_ERR_INVALID, "window solve arguments");
+    if (n <= 0 || n > w->B) return locamd_fail(LOC_ERR_INVALID, "n_instances");
+    const locamd::WindowCaps& c = w->caps;
+    if ((c.nr_max && (!r_idx || !r_val)) || (c.np_max && (!p_idx || !p_val)) || (c.ns_max && (!s_idx || !s_val)))
+        return locamd_fail(LOC_ERR_INVALID, "missing edge arrays");
+    // host-side shape check: a bad index would fault the GPU
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t* cn = counts + i * 4;
+        if (cn[0] < 0 || cn[0] > c.nv_max || cn[1] < 0 || cn[1] > c.nr_max || cn[2] < 0 || cn[2] > c.np_max || cn[3] < 0 || cn[3] > c.ns_max)
+            return locamd_fail(LOC_ERR_INVALID, "counts exceed capacities");
+        for (int e = 0; e < cn[1]; ++e) {
+            const int32_t* ix = r_idx + ((size_t)i * c.nr_max + e) * 2;
+            if (ix[0] < 0 || ix[0] >= cn[0] || ix[1] >= cn[0] || ix[1] < -w->n_anchors || ix[0] == ix[1])
+                return locamd_fail(LOC_ERR_INVALID, "range edge vertex index");
+        }
+        for (int e = 0; e < cn[2]; ++e) {
+            const int32_t v = p_idx[(size_t)i * c.np_max + e];
+            if (v < 0 || v >= cn[0]) return locamd_fail(LOC_ERR_INVALID, "prior edge vertex index");
+        }
+        for (int e = 0; e < cn[3]; ++e) {
+            const int32_t* ix = s_idx + ((size_t)i * c.ns_max + e) * 4;
+            if (ix[0] < 0 || ix[0] >= cn[0] || ix[1] < 0 || ix[1] >= cn[0] || ix[0] == ix[1])
+                return locamd_fail(LOC_ERR_INVALID, "SE3 edge vertex index");
+        }
+    }
+    LOC_HIP(hipSetDevice(w->device));
+    const size_t N = (size_t)n;
+    hipStream_t st = w->stream;
+    LOC_HIP(hipMemcpyAsync(w->d_counts, counts, N * 4 * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    LOC_HIP(hipMemcpyAsync(w->d_poses, poses, N * c.nv_max * 12 * sizeof(double), hipMemcpyHostToDevice, st));
+    if (c.nr_max) {
+        LOC_HIP(hipMemcpyAsync(w->d_ridx, r_idx, N * c.nr_max * 2 * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        LOC_HIP(hipMemcpyAsync(w->d_rval, r_val, N * c.nr_max * 5 * sizeof(double), hipMemcpyHostToDevice, st));
+    }
+    if (c.np_max) {
+        LOC_HIP(hipMemcpyAsync(w->d_pidx, p_idx, N * c.np_max * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        LOC_HIP(hipMemcpyAsync(w->d_pval, p_val, N * c.np_max * 18 * sizeof(double), hipMemcpyHostToDevice, st));
+    }
+    if (c.ns_max) {
+        LOC_HIP(hipMemcpyAsync(w->d_sidx, s_idx, N * c.ns_max * 4 * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        LOC_HIP(hipMemcpyAsync(w->d_sval, s_val, N * c.ns_max * 48 * sizeof(double), hipMemcpyHostToDevice, st));
+    }
+    locamd::WindowArgs a;
+    a.counts = w->d_counts; a.poses = w->d_poses; a.r_idx = w->d_ridx; a.r_val = w->d_rval; a.p_idx = w->d_pidx;
+    a.p_val = w->d_pval; a.s_idx = w->d_sidx; a.s_val = w->d_sval; a.anchors = w->d_anchors; a.result = w->d_result;
+    a.n_anchors = w->n_anchors; a.B = (int)n; a.iterations = w->iterations; a.caps = c;
+    LOC_HIP(hipEventRecord(w->ev0, st));
+    hipError_t e = locamd::launch_window(a, st);
+    if (e != hipSuccess) return locamd_fail_hip(e, "launch_window");
+    LOC_HIP(hipEventRecord(w->ev1, st));
+    LOC_HIP(hipMemcpyAsync(poses, w->d_poses, N * c.nv_max * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
+    LOC_HIP(hipMemcpyAsync(result, w->d_result, N * 8 * sizeof(double), hipMemcpyDeviceToHost, st));
+    LOC_HIP(hipStreamSynchronize(st));
+    float ms = 0;
+    LOC_HIP(hipEventElapsedTime(&ms, w->ev0, w->ev1));
+    w->last_ms = ms;
+    return LOC_OK;
+}
+
+int loc_window_last_kernel_ms(loc_window* w, double* ms) {
+    if (!w || !ms) return locamd_fail(LOC_ERR_INVALID, "null");
+    *ms = w->last_ms;
+    return LOC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,44 @@
+// Internal interface of the sliding-window graph solver kernel (window_kernel.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace locamd {
+
+// Per-batch capacities; every instance owns fixed-size slices of the arrays below.
+struct WindowCaps {
+    int nv_max;  // moving poses per instance (<= 16)
+    int nr_max;  // range edges (<= 64)
+    int np_max;  // unary SE3 priors (<= 32)
+    int ns_max;  // binary SE3 edges (<= 32)
+};
+
+// Layout of one instance (all arrays are [B][...]):
+//   counts  int32 [B][4]            nv, nr, np, ns
+//   poses   double[B][nv_max][12]   R row-major (9), t (3)            in: estimate, out: optimised
+//   r_idx   int32 [B][nr_max][2]    v0 (moving slot), v1 (moving slot, or -1 - anchor index)
+//   r_val   double[B][nr_max][5]    measurement, information, lever arm of endpoint 0 (xyz)
+//   p_idx   int32 [B][np_max]       v
+//   p_val   double[B][np_max][18]   Z^-1 as R(9), t(3); information diagonal (6)
+//   s_idx   int32 [B][ns_max][4]    vi, vj, robust, pad
+//   s_val   double[B][ns_max][48]   Z^-1 as R(9), t(3); information 6x6 row-major (36)
+//   result  double[B][8]            chi2 (all edges, last evaluated), robust chi2, lambda, outer iterations,
+//                                   LM trials, terminated, 0, 0
+struct WindowArgs {
+    const int32_t* counts;
+    double* poses;
+    const int32_t* r_idx; const double* r_val;
+    const int32_t* p_idx; const double* p_val;
+    const int32_t* s_idx; const double* s_val;
+    const double* anchors;  // [n_anchors][3] fixed vertices (identity rotation), shared by all instances
+    double* result;
+    int n_anchors;
+    int B;
+    int iterations;
+    WindowCaps caps;
+};
+
+size_t window_lds_bytes(const WindowCaps& c);
+hipError_t launch_window(const WindowArgs& a, hipStream_t stream);
+
+}  // namespace locamd

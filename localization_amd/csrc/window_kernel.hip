@@ -1,0 +1,536 @@
+// gfx950 (MI355X / CDNA4) sliding-window graph solver: the reference's general case.
+//
+// One instance = one trajectory's window as Localization/Robot build it (reference file:line in brackets):
+//   vertices  g2o::VertexSE3 poses of the moving node(s), ring window              [robot.cpp:31-58, 75-110]
+//             fixed anchors (identity rotation)                                    [localization.cpp:100-106]
+//   edges     EdgeSE3Range  e = d - ||(X0*O0).t - X1.t||, Cauchy                    [types_edge_se3range.cpp:105-114,
+//                 range to an anchor (lever arm O0 = antenna offset), and the         localization.cpp:331-340, 608-627]
+//                 zero-range smoothness edge between consecutive poses
+//             EdgeSE3Prior  e = toVectorMQT(Z^-1 X), diagonal information           [localization.cpp:476-486, 513-525]
+//                 (IMU: rotation only; lidar: z only), not robust
+//             EdgeSE3       e = toVectorMQT(Z^-1 Xi^-1 Xj), 6x6 information, Cauchy  [localization.cpp:263-281, 588-602]
+//   solve     initializeOptimization + optimize(maximum_iteration), g2o LM          [localization.cpp:164-170]
+//             then optimizer.chi2()                                                 [localization.cpp:197]
+// (g2o semantics: SURVEY.md Appendix A.  Jacobians are analytic here; the reference's numeric range Jacobian is the
+//  same derivative up to 1e-7 relative noise.)
+//
+// MI355X mapping: ONE WAVE PER INSTANCE, everything in LDS.
+//   * edge evaluation: lane e evaluates edge e (error, Jacobian blocks, robust weight) into an LDS record;
+//   * normal equations: edges are folded into H one after the other (fixed order => bit-reproducible, no atomics),
+//     the 64 lanes covering the 6x6 block entries;  H (n = 6 * poses <= 96) lives in the UPPER triangle of one
+//     n x ld LDS matrix (ld odd: conflict-free column walks), its Cholesky factor goes into the strict LOWER triangle,
+//     so a rejected LM trial needs no copy of H;
+//   * left-looking Cholesky with lanes over rows, column-oriented triangular solves, lane-per-pose oplus;
+//   * all LM control flow is wave-uniform (sums are xor-butterflies: every lane holds the same bits).
+// This is the latency-oriented first version of the window path (one 64-lane wave per 60..96-unknown system);
+// DESIGN.md lists what the throughput version changes.
+#include "window_kernel.h"
+
+#include <float.h>
+#include <math.h>
+
+namespace locamd {
+
+namespace {
+
+constexpr int RREC = 16;   // J0[6] J1[6] wr omega_r chi rho0
+constexpr int PREC = 56;   // J[36] W[6] omega_r[6] (+pad)
+constexpr int SREC = 152;  // J0[36] J1[36] WJ0[36] WJ1[36] omega_r[6] (+pad)
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = fmax(v, __shfl_xor(v, m));
+    return v;
+}
+
+// ---- small SE3 algebra (row-major 3x3) -------------------------------------------------------------------------
+__device__ __forceinline__ void mat_mul(const double* A, const double* B, double* C) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i * 3 + 0] * B[0 * 3 + j] + A[i * 3 + 1] * B[1 * 3 + j] + A[i * 3 + 2] * B[2 * 3 + j];
+}
+__device__ __forceinline__ void mat_tmul(const double* A, const double* B, double* C) {  // A^T B
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[0 * 3 + i] * B[0 * 3 + j] + A[1 * 3 + i] * B[1 * 3 + j] + A[2 * 3 + i] * B[2 * 3 + j];
+}
+__device__ __forceinline__ void mat_vec(const double* A, const double* v, double* o) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[i] = A[i * 3 + 0] * v[0] + A[i * 3 + 1] * v[1] + A[i * 3 + 2] * v[2];
+}
+__device__ __forceinline__ void mat_tvec(const double* A, const double* v, double* o) {  // A^T v
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[i] = A[0 * 3 + i] * v[0] + A[1 * 3 + i] * v[1] + A[2 * 3 + i] * v[2];
+}
+// Eigen::Quaternion(Matrix3) — q = (w, x, y, z)
+__device__ void mat_to_quat(const double* R, double* q) {
+    double t = R[0] + R[4] + R[8];
+    if (t > 0) {
+        t = sqrt(t + 1.0);
+        q[0] = 0.5 * t;
+        t = 0.5 / t;
+        q[1] = (R[7] - R[5]) * t; q[2] = (R[2] - R[6]) * t; q[3] = (R[3] - R[1]) * t;
+    } else if (R[0] >= R[4] && R[0] >= R[8]) {  // i = 0, j = 1, k = 2
+        t = sqrt(R[0] - R[4] - R[8] + 1.0);
+        q[1] = 0.5 * t; t = 0.5 / t;
+        q[0] = (R[7] - R[5]) * t; q[2] = (R[3] + R[1]) * t; q[3] = (R[6] + R[2]) * t;
+    } else if (R[4] > R[0] && R[4] >= R[8]) {   // i = 1, j = 2, k = 0
+        t = sqrt(R[4] - R[8] - R[0] + 1.0);
+        q[2] = 0.5 * t; t = 0.5 / t;
+        q[0] = (R[2] - R[6]) * t; q[3] = (R[7] + R[5]) * t; q[1] = (R[1] + R[3]) * t;
+    } else {                                      // i = 2, j = 0, k = 1
+        t = sqrt(R[8] - R[0] - R[4] + 1.0);
+        q[3] = 0.5 * t; t = 0.5 / t;
+        q[0] = (R[3] - R[1]) * t; q[1] = (R[2] + R[6]) * t; q[2] = (R[5] + R[7]) * t;
+    }
+}
+__device__ __forceinline__ void quat_mul(const double* a, const double* b, double* o) {
+    o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+    o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+    o[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+    o[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+}
+// g2o internal::normalize: unit norm, w >= 0; returns the sign applied
+__device__ __forceinline__ double quat_normalize_sign(double* q) {
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    double s = 1.0 / n, sg = 1.0;
+    if (q[0] < 0) { s = -s; sg = -1.0; }
+    q[0] *= s; q[1] *= s; q[2] *= s; q[3] *= s;
+    return sg;
+}
+// Eigen toRotationMatrix (no normalisation)
+__device__ __forceinline__ void quat_to_mat(const double* q, double* R) {
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+    R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+// rows 3..5 x cols 3..5 of a Jacobian: d vec(q (x) (sqrt(1-|v|^2), v)) / dv at 0 = w I + [q_xyz]x
+__device__ __forceinline__ void quat_right_jac(const double* q, double sgn, double* J, int ldj) {
+    const double w = q[0] * sgn, x = q[1] * sgn, y = q[2] * sgn, z = q[3] * sgn;
+    J[3 * ldj + 3] = w;  J[3 * ldj + 4] = -z; J[3 * ldj + 5] = y;
+    J[4 * ldj + 3] = z;  J[4 * ldj + 4] = w;  J[4 * ldj + 5] = -x;
+    J[5 * ldj + 3] = -y; J[5 * ldj + 4] = x;  J[5 * ldj + 5] = w;
+}
+
+struct Lds {
+    double* A; int ld;
+    double *diagL, *b, *x, *pose, *bak, *rrec, *prec, *srec;
+};
+
+// Evaluate every edge at the current poses: errors + chi sums always, Jacobian/weight records when FULL.
+template <bool FULL>
+__device__ void evaluate_edges(const WindowArgs& a, const Lds& L, int inst, int lane, int nr, int np, int ns,
+                               double& robust_chi, double& plain_chi) {
+    const WindowCaps& c = a.caps;
+    double rsum = 0.0, csum = 0.0;
+    // ---- range edges ------------------------------------------------------------------------------------------
+    for (int e = lane; e < nr; e += 64) {
+        const int32_t* idx = a.r_idx + ((size_t)inst * c.nr_max + e) * 2;
+        const double* val = a.r_val + ((size_t)inst * c.nr_max + e) * 5;
+        const int v0 = idx[0], v1 = idx[1];
+        const double meas = val[0], info = val[1];
+        const double off[3] = {val[2], val[3], val[4]};
+        const double* X0 = L.pose + v0 * 12;
+        double p0[3], p1[3];
+        mat_vec(X0, off, p0);
+        p0[0] += X0[9]; p0[1] += X0[10]; p0[2] += X0[11];
+        if (v1 >= 0) { p1[0] = L.pose[v1 * 12 + 9]; p1[1] = L.pose[v1 * 12 + 10]; p1[2] = L.pose[v1 * 12 + 11]; }
+        else { const double* an = a.anchors + (size_t)(-1 - v1) * 3; p1[0] = an[0]; p1[1] = an[1]; p1[2] = an[2]; }
+        double u[3] = {p0[0] - p1[0], p0[1] - p1[1], p0[2] - p1[2]};
+        const double n = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+        const double err = meas - n;
+        const double chi = err * (info * err);
+        const double aux = 1.0 + chi;
+        rsum += log(aux);
+        csum += chi;
+        if (FULL) {
+            double* rec = L.rrec + e * RREC;
+            const double inv = n > 0.0 ? 1.0 / n : 0.0;  // coincident endpoints: J = 0
+            u[0] *= inv; u[1] *= inv; u[2] *= inv;
+            double uR[3];
+            mat_tvec(X0, u, uR);  // (u^T R0)^T
+            rec[0] = -uR[0]; rec[1] = -uR[1]; rec[2] = -uR[2];
+            // dp0/dv = -2 R0 [o]x  =>  de/dv0 = 2 (uR x o)
+            rec[3] = 2.0 * (uR[1] * off[2] - uR[2] * off[1]);
+            rec[4] = 2.0 * (uR[2] * off[0] - uR[0] * off[2]);
+            rec[5] = 2.0 * (uR[0] * off[1] - uR[1] * off[0]);
+            if (v1 >= 0) {
+                double uR1[3];
+                mat_tvec(L.pose + v1 * 12, u, uR1);
+                rec[6] = uR1[0]; rec[7] = uR1[1]; rec[8] = uR1[2];
+            } else { rec[6] = 0; rec[7] = 0; rec[8] = 0; }
+            rec[9] = 0; rec[10] = 0; rec[11] = 0;
+            const double wr = info / aux;  // rho' * Omega
+            rec[12] = wr;
+            rec[13] = -wr * err;           // omega_r
+        }
+    }
+    // ---- unary priors -------------------------------------------------------------------------------------------
+    for (int e = lane; e < np; e += 64) {
+        const int v = a.p_idx[(size_t)inst * c.np_max + e];
+        const double* val = a.p_val + ((size_t)inst * c.np_max + e) * 18;
+        const double* X = L.pose + v * 12;
+        double RE[9], tE[3], q[4];
+        mat_mul(val, X, RE);
+        mat_vec(val, X + 9, tE);
+        tE[0] += val[9]; tE[1] += val[10]; tE[2] += val[11];
+        mat_to_quat(RE, q);
+        quat_normalize_sign(q);
+        const double err[6] = {tE[0], tE[1], tE[2], q[1], q[2], q[3]};
+        double chi = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) chi += err[i] * (val[12 + i] * err[i]);
+        rsum += chi;  // not robust
+        csum += chi;
+        if (FULL) {
+            double* rec = L.prec + e * PREC;
+#pragma unroll
+            for (int i = 0; i < 36; ++i) rec[i] = 0.0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) rec[i * 6 + j] = RE[i * 3 + j];
+            quat_right_jac(q, 1.0, rec, 6);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { rec[36 + i] = val[12 + i]; rec[42 + i] = -val[12 + i] * err[i]; }
+        }
+    }
+    // ---- binary SE3 edges ---------------------------------------------------------------------------------------
+    for (int e = lane; e < ns; e += 64) {
+        const int32_t* idx = a.s_idx + ((size_t)inst * c.ns_max + e) * 4;
+        const double* val = a.s_val + ((size_t)inst * c.ns_max + e) * 48;
+        const int vi = idx[0], vj = idx[1], robust = idx[2];
+        const double* Xi = L.pose + vi * 12;
+        const double* Xj = L.pose + vj * 12;
+        double RB[9], tB[3], dt[3] = {Xj[9] - Xi[9], Xj[10] - Xi[10], Xj[11] - Xi[11]};
+        mat_tmul(Xi, Xj, RB);   // Ri^T Rj
+        mat_tvec(Xi, dt, tB);   // Ri^T (tj - ti)
+        double RE[9], tE[3];
+        mat_mul(val, RB, RE);
+        mat_vec(val, tB, tE);
+        tE[0] += val[9]; tE[1] += val[10]; tE[2] += val[11];
+        double qE[4];
+        mat_to_quat(RE, qE);
+        quat_normalize_sign(qE);
+        const double err[6] = {tE[0], tE[1], tE[2], qE[1], qE[2], qE[3]};
+        const double* Om = val + 12;
+        double Oe[6];
+        double chi = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            double r = 0.0;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) r += Om[i * 6 + j] * err[j];
+            Oe[i] = r;
+            chi += err[i] * r;
+        }
+        const double aux = 1.0 + chi;
+        rsum += robust ? log(aux) : chi;
+        csum += chi;
+        if (FULL) {
+            double* rec = L.srec + e * SREC;
+            const double w = robust ? 1.0 / aux : 1.0;
+            double* J0 = rec; double* J1 = rec + 36;
+#pragma unroll
+            for (int i = 0; i < 72; ++i) rec[i] = 0.0;
+            // Jj : E' = E * Delta
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) J1[i * 6 + j] = RE[i * 3 + j];
+            quat_right_jac(qE, 1.0, J1, 6);
+            // Ji : E' = A * Delta^-1 * B
+            const double S[9] = {0, -tB[2], tB[1], tB[2], 0, -tB[0], -tB[1], tB[0], 0};
+            double RAS[9];
+            mat_mul(val, S, RAS);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { J0[i * 6 + j] = -val[i * 3 + j]; J0[i * 6 + 3 + j] = 2.0 * RAS[i * 3 + j]; }
+            double qA[4], qB[4], qAB[4];
+            mat_to_quat(val, qA);
+            mat_to_quat(RB, qB);
+            quat_mul(qA, qB, qAB);
+            const double s = qAB[0] < 0 ? -1.0 : 1.0;
+            const double nrm = 1.0 / sqrt(qAB[0] * qAB[0] + qAB[1] * qAB[1] + qAB[2] * qAB[2] + qAB[3] * qAB[3]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                double ek[4] = {0, 0, 0, 0}, r1[4], r2[4];
+                ek[1 + k] = 1.0;
+                quat_mul(qA, ek, r1);
+                quat_mul(r1, qB, r2);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) J0[(3 + i) * 6 + 3 + k] = -s * nrm * r2[1 + i];
+            }
+            // WJ = w * Omega * J, omega_r = -w * Omega * e
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+#pragma unroll
+                for (int cc = 0; cc < 6; ++cc) {
+                    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) { s0 += Om[i * 6 + j] * J0[j * 6 + cc]; s1 += Om[i * 6 + j] * J1[j * 6 + cc]; }
+                    rec[72 + i * 6 + cc] = w * s0;
+                    rec[108 + i * 6 + cc] = w * s1;
+                }
+                rec[144 + i] = -w * Oe[i];
+            }
+        }
+    }
+    robust_chi = wave_sum(rsum);
+    plain_chi = wave_sum(csum);
+}
+
+// Fold the edge records into H (upper triangle of A, diagonal included) and b, one edge after the other.
+__device__ void build_system(const WindowArgs& a, const Lds& L, int inst, int lane, int n, int nr, int np, int ns) {
+    const WindowCaps& c = a.caps;
+    const int ld = L.ld;
+    for (int i = lane; i < n * ld; i += 64) L.A[i] = 0.0;
+    for (int i = lane; i < n; i += 64) L.b[i] = 0.0;
+    __syncthreads();
+    const int r = lane / 6, cc = lane % 6;  // lanes 0..35: one entry of a 6x6 block
+    for (int e = 0; e < nr; ++e) {
+        const int32_t* idx = a.r_idx + ((size_t)inst * c.nr_max + e) * 2;
+        const int v0 = idx[0], v1 = idx[1];
+        const double* rec = L.rrec + e * RREC;
+        const double wr = rec[12], om = rec[13];
+        if (lane < 36) {
+            if (r <= cc) L.A[(v0 * 6 + r) * ld + v0 * 6 + cc] += wr * rec[r] * rec[cc];
+            if (v1 >= 0) {
+                if (r <= cc) L.A[(v1 * 6 + r) * ld + v1 * 6 + cc] += wr * rec[6 + r] * rec[6 + cc];
+                if (v0 < v1) L.A[(v0 * 6 + r) * ld + v1 * 6 + cc] += wr * rec[r] * rec[6 + cc];
+                else         L.A[(v1 * 6 + r) * ld + v0 * 6 + cc] += wr * rec[6 + r] * rec[cc];
+            }
+        } else if (lane < 42) {
+            L.b[v0 * 6 + lane - 36] += rec[lane - 36] * om;
+        } else if (lane < 48 && v1 >= 0) {
+            L.b[v1 * 6 + lane - 42] += rec[6 + lane - 42] * om;
+        }
+    }
+    for (int e = 0; e < np; ++e) {
+        const int v = a.p_idx[(size_t)inst * c.np_max + e];
+        const double* rec = L.prec + e * PREC;
+        if (lane < 36) {
+            if (r <= cc) {
+                double s = 0.0;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) s += rec[i * 6 + r] * rec[36 + i] * rec[i * 6 + cc];
+                L.A[(v * 6 + r) * ld + v * 6 + cc] += s;
+            }
+        } else if (lane < 42) {
+            const int rr = lane - 36;
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) s += rec[i * 6 + rr] * rec[42 + i];
+            L.b[v * 6 + rr] += s;
+        }
+    }
+    for (int e = 0; e < ns; ++e) {
+        const int32_t* idx = a.s_idx + ((size_t)inst * c.ns_max + e) * 4;
+        const int vi = idx[0], vj = idx[1];
+        const double* rec = L.srec + e * SREC;
+        const double *J0 = rec, *J1 = rec + 36, *WJ0 = rec + 72, *WJ1 = rec + 108, *om = rec + 144;
+        if (lane < 36) {
+            double sii = 0.0, sjj = 0.0, sij = 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                sii += J0[i * 6 + r] * WJ0[i * 6 + cc];
+                sjj += J1[i * 6 + r] * WJ1[i * 6 + cc];
+                sij += (vi < vj) ? J0[i * 6 + r] * WJ1[i * 6 + cc] : J1[i * 6 + r] * WJ0[i * 6 + cc];
+            }
+            if (r <= cc) { L.A[(vi * 6 + r) * ld + vi * 6 + cc] += sii; L.A[(vj * 6 + r) * ld + vj * 6 + cc] += sjj; }
+            if (vi < vj) L.A[(vi * 6 + r) * ld + vj * 6 + cc] += sij;
+            else         L.A[(vj * 6 + r) * ld + vi * 6 + cc] += sij;
+        } else if (lane < 48) {
+            const bool second = lane >= 42;
+            const int rr = second ? lane - 42 : lane - 36;
+            const double* J = second ? J1 : J0;
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) s += J[i * 6 + rr] * om[i];
+            L.b[(second ? vj : vi) * 6 + rr] += s;
+        }
+    }
+    __syncthreads();
+}
+
+// (H + lambda I) = L L^T, L into the strict lower triangle of A + diagL; false if not positive definite.
+__device__ bool cholesky(const Lds& L, int lane, int n, double lambda) {
+    const int ld = L.ld;
+    bool ok = true;
+    for (int j = 0; j < n; ++j) {
+        double s = L.A[j * ld + j] + lambda;
+        for (int k = 0; k < j; ++k) { const double l = L.A[j * ld + k]; s -= l * l; }
+        if (!(s > 0.0) || !(s < DBL_MAX)) { ok = false; break; }
+        const double ljj = sqrt(s), inv = 1.0 / ljj;
+        for (int i = j + 1 + lane; i < n; i += 64) {
+            double v = L.A[j * ld + i];
+            for (int k = 0; k < j; ++k) v -= L.A[i * ld + k] * L.A[j * ld + k];
+            L.A[i * ld + j] = v * inv;
+        }
+        if (lane == 0) L.diagL[j] = ljj;
+        __syncthreads();
+    }
+    return ok;
+}
+// L L^T x = b (column oriented, lanes over the trailing rows)
+__device__ void chol_solve(const Lds& L, int lane, int n) {
+    const int ld = L.ld;
+    for (int i = lane; i < n; i += 64) L.x[i] = L.b[i];
+    __syncthreads();
+    for (int j = 0; j < n; ++j) {
+        const double yj = L.x[j] / L.diagL[j];
+        __syncthreads();
+        if (lane == 0) L.x[j] = yj;
+        for (int i = j + 1 + lane; i < n; i += 64) L.x[i] -= L.A[i * ld + j] * yj;
+        __syncthreads();
+    }
+    for (int j = n - 1; j >= 0; --j) {
+        const double xj = L.x[j] / L.diagL[j];
+        __syncthreads();
+        if (lane == 0) L.x[j] = xj;
+        for (int k = lane; k < j; k += 64) L.x[k] -= L.A[j * ld + k] * xj;
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int inst = blockIdx.x;
+    const int lane = threadIdx.x;
+    const WindowCaps& c = a.caps;
+    const int nv = a.counts[inst * 4 + 0], nr = a.counts[inst * 4 + 1], np = a.counts[inst * 4 + 2], ns = a.counts[inst * 4 + 3];
+    const int n = 6 * nv;
+    const int n_max = 6 * c.nv_max;
+    Lds L;
+    L.ld = n_max | 1;
+    double* p = lds;
+    L.A = p; p += (size_t)n_max * L.ld;
+    L.diagL = p; p += n_max;
+    L.b = p; p += n_max;
+    L.x = p; p += n_max;
+    L.pose = p; p += c.nv_max * 12;
+    L.bak = p; p += c.nv_max * 12;
+    L.rrec = p; p += c.nr_max * RREC;
+    L.prec = p; p += c.np_max * PREC;
+    L.srec = p;
+
+    double* gpose = a.poses + (size_t)inst * c.nv_max * 12;
+    for (int i = lane; i < nv * 12; i += 64) L.pose[i] = gpose[i];
+    __syncthreads();
+
+    constexpr double tau = 1e-5, good_lo = 1.0 / 3.0, good_hi = 2.0 / 3.0;
+    constexpr int max_trials = 10;
+    double lambda = 0.0, ni = 2.0, cur_chi = 0.0, last_plain = 0.0;
+    int it = 0, trials = 0, terminated = 0;
+    const bool empty = (nv <= 0) || (nr + np + ns <= 0);
+
+    bool ok = !empty;
+    for (it = 0; it < a.iterations && ok; ++it) {
+        double plain;
+        evaluate_edges<true>(a, L, inst, lane, nr, np, ns, cur_chi, plain);  // computeActiveErrors + linearize
+        last_plain = plain;
+        __syncthreads();
+        build_system(a, L, inst, lane, n, nr, np, ns);
+        if (it == 0) {  // computeLambdaInit
+            double md = 0.0;
+            for (int j = lane; j < n; j += 64) md = fmax(md, fabs(L.A[j * L.ld + j]));
+            lambda = tau * wave_max(md);
+            ni = 2.0;
+        }
+        double rho = 0.0;
+        int q = 0;
+        do {
+            for (int i = lane; i < nv * 12; i += 64) L.bak[i] = L.pose[i];  // push
+            const bool ok2 = cholesky(L, lane, n, lambda);
+            __syncthreads();
+            if (ok2) chol_solve(L, lane, n);
+            else { for (int i = lane; i < n; i += 64) L.x[i] = 0.0; __syncthreads(); }
+            // update: X <- X * fromVectorMQT(dx), one pose per lane
+            for (int v = lane; v < nv; v += 64) {
+                const double* dx = L.x + v * 6;
+                double* X = L.pose + v * 12;
+                double Rd[9];
+                const double ww = 1.0 - (dx[3] * dx[3] + dx[4] * dx[4] + dx[5] * dx[5]);
+                if (ww < 0) { Rd[0] = 1; Rd[1] = 0; Rd[2] = 0; Rd[3] = 0; Rd[4] = 1; Rd[5] = 0; Rd[6] = 0; Rd[7] = 0; Rd[8] = 1; }
+                else { const double qd[4] = {sqrt(ww), dx[3], dx[4], dx[5]}; quat_to_mat(qd, Rd); }
+                double Rn[9], tn[3];
+                mat_mul(X, Rd, Rn);
+                mat_vec(X, dx, tn);
+                X[9] += tn[0]; X[10] += tn[1]; X[11] += tn[2];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) X[i] = Rn[i];
+            }
+            __syncthreads();
+            ++trials;
+            double temp_chi, plain2;
+            evaluate_edges<false>(a, L, inst, lane, nr, np, ns, temp_chi, plain2);
+            last_plain = plain2;
+            if (!ok2) temp_chi = DBL_MAX;
+            double sc = 0.0;
+            for (int j = lane; j < n; j += 64) sc += L.x[j] * (lambda * L.x[j] + L.b[j]);  // computeScale
+            const double scale = wave_sum(sc) + 1e-3;
+            rho = (cur_chi - temp_chi) / scale;
+            if (rho > 0.0 && fabs(temp_chi) < DBL_MAX && ok2) {
+                const double r21 = 2.0 * rho - 1.0;
+                double alpha = 1.0 - r21 * r21 * r21;
+                alpha = fmin(alpha, good_hi);
+                lambda *= fmax(good_lo, alpha);
+                ni = 2.0;
+                cur_chi = temp_chi;
+            } else {
+                lambda *= ni;
+                ni *= 2.0;
+                __syncthreads();
+                for (int i = lane; i < nv * 12; i += 64) L.pose[i] = L.bak[i];  // pop
+            }
+            __syncthreads();
+            ++q;
+        } while (rho < 0.0 && q < max_trials);
+        if (q == max_trials || rho == 0.0) { ok = false; terminated = 1; }
+    }
+
+    for (int i = lane; i < nv * 12; i += 64) gpose[i] = L.pose[i];
+    if (lane == 0) {
+        double* res = a.result + (size_t)inst * 8;
+        res[0] = last_plain; res[1] = cur_chi; res[2] = lambda; res[3] = (double)it; res[4] = (double)trials;
+        res[5] = (double)terminated; res[6] = 0.0; res[7] = 0.0;
+    }
+}
+
+}  // namespace
+
+size_t window_lds_bytes(const WindowCaps& c) {
+    const size_t n_max = 6 * (size_t)c.nv_max;
+    const size_t ld = n_max | 1;
+    size_t d = n_max * ld + 3 * n_max + 2 * (size_t)c.nv_max * 12 + (size_t)c.nr_max * RREC + (size_t)c.np_max * PREC +
+               (size_t)c.ns_max * SREC;
+    return d * sizeof(double);
+}
+
+hipError_t launch_window(const WindowArgs& a, hipStream_t stream) {
+    if (a.B <= 0) return hipErrorInvalidValue;
+    const size_t lds = window_lds_bytes(a.caps);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&window_lm_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(window_lm_kernel, dim3((unsigned)a.B), dim3(64), lds, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace locamd

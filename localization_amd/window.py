@@ -1,0 +1,112 @@
+"""Batched sliding-window graph solver: Python harness over loc_window_* (include/localization_amd.h)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
+
+
+class WindowCaps(C.Structure):
+    _fields_ = [("nv_max", C.c_int32), ("nr_max", C.c_int32), ("np_max", C.c_int32), ("ns_max", C.c_int32)]
+
+
+def _inv_iso(R, t):
+    Ri = R.T
+    return Ri, -Ri @ t
+
+
+class WindowBatch:
+    """Host-side arrays of B instances in the ABI's layout; fill with add_* then hand to WindowSolver.solve."""
+
+    def __init__(self, batch, nv_max, nr_max, np_max, ns_max):
+        self.B = int(batch)
+        self.caps = (int(nv_max), int(nr_max), int(np_max), int(ns_max))
+        self.counts = np.zeros((self.B, 4), dtype=np.int32)
+        self.poses = np.zeros((self.B, nv_max, 12))
+        self.poses[:, :, 0] = self.poses[:, :, 4] = self.poses[:, :, 8] = 1.0
+        self.r_idx = np.zeros((self.B, max(nr_max, 1), 2), dtype=np.int32)
+        self.r_val = np.zeros((self.B, max(nr_max, 1), 5))
+        self.p_idx = np.zeros((self.B, max(np_max, 1)), dtype=np.int32)
+        self.p_val = np.zeros((self.B, max(np_max, 1), 18))
+        self.s_idx = np.zeros((self.B, max(ns_max, 1), 4), dtype=np.int32)
+        self.s_val = np.zeros((self.B, max(ns_max, 1), 48))
+        self.result = np.zeros((self.B, 8))
+
+    def add_pose(self, i, t, R=None):
+        v = int(self.counts[i, 0])
+        assert v < self.caps[0]
+        self.poses[i, v, :9] = (np.eye(3) if R is None else np.asarray(R)).reshape(9)
+        self.poses[i, v, 9:] = t
+        self.counts[i, 0] = v + 1
+        return v
+
+    def add_range(self, i, v0, v1, meas, info, off=(0.0, 0.0, 0.0), anchor=False):
+        e = int(self.counts[i, 1])
+        assert e < self.caps[1]
+        self.r_idx[i, e] = (v0, -1 - v1 if anchor else v1)
+        self.r_val[i, e] = (meas, info, off[0], off[1], off[2])
+        self.counts[i, 1] = e + 1
+
+    def add_prior(self, i, v, t, R, info_diag):
+        e = int(self.counts[i, 2])
+        assert e < self.caps[2]
+        Ri, ti = _inv_iso(np.asarray(R, dtype=float), np.asarray(t, dtype=float))
+        self.p_idx[i, e] = v
+        self.p_val[i, e, :9] = Ri.reshape(9); self.p_val[i, e, 9:12] = ti; self.p_val[i, e, 12:] = info_diag
+        self.counts[i, 2] = e + 1
+
+    def add_se3(self, i, vi, vj, t, R, info, robust=True):
+        e = int(self.counts[i, 3])
+        assert e < self.caps[3]
+        Ri, ti = _inv_iso(np.asarray(R, dtype=float), np.asarray(t, dtype=float))
+        self.s_idx[i, e] = (vi, vj, int(robust), 0)
+        self.s_val[i, e, :9] = Ri.reshape(9); self.s_val[i, e, 9:12] = ti
+        self.s_val[i, e, 12:] = np.asarray(info, dtype=float).reshape(36)
+        self.counts[i, 3] = e + 1
+
+    def pose(self, i, v):
+        return self.poses[i, v, :9].reshape(3, 3).copy(), self.poses[i, v, 9:].copy()
+
+
+class WindowSolver:
+    def __init__(self, anchors, batch, nv_max, nr_max, np_max=0, ns_max=0, maximum_iteration=10, device=0):
+        L = lib()
+        if L.loc_device_count() <= 0:
+            raise _lib.LocalizationAmdError(_lib.LOC_ERR_NO_DEVICE, "no HIP device visible: localization_amd has no CPU fallback")
+        anchors = np.ascontiguousarray(anchors, dtype=np.float64).reshape(-1, 3)
+        caps = WindowCaps(nv_max, nr_max, np_max, ns_max)
+        h = C.c_void_p()
+        check(L.loc_window_create(C.byref(h), device, int(batch), C.byref(caps), anchors.shape[0],
+                                  anchors.ctypes.data_as(C.POINTER(C.c_double)), int(maximum_iteration)))
+        self.h, self.L, self.B = h, L, int(batch)
+        self.caps = (nv_max, nr_max, np_max, ns_max)
+        self.lds_bytes = L.loc_window_lds_bytes(C.byref(caps))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.loc_window_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def solve(self, wb: WindowBatch):
+        assert wb.caps == self.caps and wb.B <= self.B
+        ip, dp = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+        for a in (wb.counts, wb.poses, wb.r_idx, wb.r_val, wb.p_idx, wb.p_val, wb.s_idx, wb.s_val, wb.result):
+            assert a.flags["C_CONTIGUOUS"]
+        check(self.L.loc_window_solve_host(self.h, wb.B, wb.counts.ctypes.data_as(ip), wb.poses.ctypes.data_as(dp),
+                                           wb.r_idx.ctypes.data_as(ip), wb.r_val.ctypes.data_as(dp),
+                                           wb.p_idx.ctypes.data_as(ip), wb.p_val.ctypes.data_as(dp),
+                                           wb.s_idx.ctypes.data_as(ip), wb.s_val.ctypes.data_as(dp),
+                                           wb.result.ctypes.data_as(dp)))
+        return wb.result
+
+    def last_kernel_ms(self):
+        ms = C.c_double()
+        check(self.L.loc_window_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value
