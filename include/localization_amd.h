@@ -151,6 +151,65 @@ int loc_window_solve_host(loc_window* w, int64_t n_instances, const int32_t* cou
 /* kernel time of the last loc_window_solve_host launch (HIP events on its stream), milliseconds */
 int loc_window_last_kernel_ms(loc_window* w, double* ms);
 
+/* ================================================================================================
+ * Node front-end — `class Localization` behind the ABI (one moving tag, its ring window, its anchors).
+ * Same callbacks, same parameters, same gating as the reference; every solve() is one window-kernel launch.
+ *   loc_node_create        Localization::Localization          localization.cpp:32-161 (+ Robot::init, robot.cpp:31-58)
+ *   loc_node_add_range     Localization::addRangeEdge          localization.cpp:297-376
+ *   loc_node_add_imu       Localization::addImuEdge            localization.cpp:499-535
+ *   loc_node_add_pose      Localization::addPoseEdge           localization.cpp:254-290
+ *   loc_node_add_twist     Localization::addTwistEdge          localization.cpp:438-459, 560-605
+ *   loc_node_add_lidar     Localization::addLidarEdge          localization.cpp:462-496
+ *   loc_node_solve         Localization::solve + publish       localization.cpp:164-251
+ *   loc_node_get_path      Robot::vertices2path                robot.cpp:61-72
+ * add_* return 1 when the call ran a solve (out is filled), 0 when it did not, < 0 on error.
+ * Poses are 8 doubles: stamp, x, y, z, qx, qy, qz, qw (the TUM order the reference logs, localization.cpp:630-642).
+ * Limits of this kernel version: trajectory_length <= 16 moving poses in the window.
+ * ============================================================================================== */
+typedef struct loc_node loc_node;
+
+typedef struct loc_node_config {
+    int32_t trajectory_length;        /* robot/trajectory_length           localization.cpp:72 (no default) */
+    double maximum_velocity;          /* robot/maximum_velocity (1.0)       :75 */
+    double distance_outlier;          /* robot/distance_outlier (1.0)       :78 */
+    int32_t maximum_iteration;        /* optimizer/maximum_iteration (20)   :65 */
+    double minimum_optimize_error;    /* optimizer/minimum_optimize_error (1000)  :68 */
+    int32_t publish_range, publish_pose, publish_twist, publish_lidar, publish_imu; /* publish_flag/...  :146-158 */
+    int32_t has_relative_range;       /* topic/relative_range present: every node moves  :94 */
+} loc_node_config;
+
+typedef struct loc_node_output {
+    int32_t solved;                   /* a solve ran */
+    int32_t published;                /* chi2 < minimum_optimize_error (localization.cpp:199-205) */
+    double chi2;                      /* optimizer.chi2() */
+    double realtime[8];               /* robots[self].current_pose()            :208 */
+    double optimized[8];              /* path->poses[trajectory_length / 2]     :220 */
+    int32_t outer_iterations, lm_trials;
+} loc_node_output;
+
+void loc_node_default_config(loc_node_config* c);
+/* ids[n-1] is the moving tag (nodesId.back(), :89); pos_xyz = /uwb/nodesPos; antenna_xyz = /uwb/antennaOffset or NULL */
+int loc_node_create(loc_node** out, int32_t device, const loc_node_config* cfg, int32_t n_nodes, const int32_t* ids,
+                    const double* pos_xyz, int32_t n_antenna, const double* antenna_xyz);
+int loc_node_destroy(loc_node* n);
+int loc_node_add_range(loc_node* n, int32_t requester_id, int32_t responder_id, double stamp, float distance,
+                       float distance_err, int32_t antenna, const char* frame_id, loc_node_output* out);
+int loc_node_add_imu(loc_node* n, double stamp, const double* q_xyzw, const double* orientation_cov9,
+                     const char* frame_id, loc_node_output* out);
+int loc_node_add_pose(loc_node* n, double stamp, const double* pose_xyz_qxyzw, const double* cov36,
+                      const char* frame_id, loc_node_output* out);
+int loc_node_add_twist(loc_node* n, double stamp, const double* twist_lin_ang6, const double* cov36,
+                       const char* frame_id, loc_node_output* out);
+int loc_node_add_lidar(loc_node* n, double stamp, double z, const char* frame_id, loc_node_output* out);
+int loc_node_solve(loc_node* n, loc_node_output* out);
+int loc_node_get_path(loc_node* n, int32_t node_id, double* out_T_by_8, int32_t capacity_poses);
+int32_t loc_node_number_measurements(const loc_node* n);
+/* Fleet mode: with deferred on, add_* only mark the node "solve pending"; loc_nodes_solve_batch then solves every
+ * pending node of the array in ONE launch (returns how many were solved). */
+int loc_node_set_deferred(loc_node* n, int32_t on);
+int32_t loc_node_solve_pending(const loc_node* n);
+int loc_nodes_solve_batch(loc_node** nodes, int32_t n_nodes, loc_node_output* outs);
+
 #ifdef __cplusplus
 }
 #endif

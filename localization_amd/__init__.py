@@ -10,8 +10,9 @@ from ._lib import LocalizationAmdError, abi_version, device_count, lib, library_
 from .config import LocalizationConfig, load_config
 from .snapshot import SnapshotSolver, pack_ranges, unpack_ranges
 from .window import WindowBatch, WindowSolver
+from .node import LocalizationNode, solve_batch
 
 __all__ = [
     "LocalizationAmdError", "abi_version", "device_count", "lib", "library_path",
-    "LocalizationConfig", "load_config", "SnapshotSolver", "pack_ranges", "unpack_ranges", "WindowBatch", "WindowSolver",
+    "LocalizationConfig", "load_config", "SnapshotSolver", "pack_ranges", "unpack_ranges", "WindowBatch", "WindowSolver", "LocalizationNode", "solve_batch",
 ]

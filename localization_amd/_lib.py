@@ -38,6 +38,9 @@ EXPORTED_SYMBOLS = [
     "loc_snapshot_timing_begin", "loc_snapshot_timing_end",
     "loc_window_create", "loc_window_destroy", "loc_window_lds_bytes", "loc_window_solve_host",
     "loc_window_last_kernel_ms",
+    "loc_node_default_config", "loc_node_create", "loc_node_destroy", "loc_node_add_range", "loc_node_add_imu",
+    "loc_node_add_pose", "loc_node_add_twist", "loc_node_add_lidar", "loc_node_solve", "loc_node_get_path",
+    "loc_node_number_measurements", "loc_node_set_deferred", "loc_node_solve_pending", "loc_nodes_solve_batch",
 ]
 
 

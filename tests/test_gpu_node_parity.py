@@ -1,0 +1,200 @@
+"""Drop-in front-end on the GPU (loc_node_*: Localization/Robot semantics + window kernel) vs the oracle's front-end
+restatement, message for message, on the reference's own recording and on synthetic streams.
+
+Per-solve parity is 1e-7 m (tests/test_gpu_window_parity.py).  Over a 45 s stream the window state is carried from
+solve to solve and the weakly observable directions (z; one range per pose) let last-bit differences grow — the
+oracle's own analytic/numeric modes drift apart by ~2e-4 m median on the same bag — so stream-level tolerances are:
+identical publish decisions, ATE RMSE difference <= 1 mm, median pointwise difference <= 1e-4 m.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def bag():
+    return np.load(os.path.join(GOLD, "bag_example.npz"))
+
+
+def _events(bag, with_imu, n_ranges=None):
+    n = len(bag["uwb_rectime"]) if n_ranges is None else n_ranges
+    ev = [(t, 0, i) for i, t in enumerate(bag["uwb_rectime"][:n])]
+    if with_imu:
+        tmax = bag["uwb_rectime"][n - 1]
+        ev += [(t, 1, i) for i, t in enumerate(bag["imu_rectime"]) if t <= tmax]
+    ev.sort()
+    return ev
+
+
+def _replay(bag, obj, ev):
+    rt, pub, chi = [], [], []
+    for _, kind, i in ev:
+        if kind == 0:
+            o = obj.add_range(200, int(bag["uwb_responder"][i]), float(bag["uwb_stamp"][i]), bag["uwb_distance"][i],
+                              bag["uwb_distance_err"][i], int(bag["uwb_antenna"][i]), "uwb")
+            if o["solved"]:
+                rt.append(o["realtime"]); pub.append(o["published"]); chi.append(o["chi2"])
+        else:
+            obj.add_imu(float(bag["imu_stamp"][i]), bag["imu_q_xyzw"][i], np.diag(bag["imu_orientation_cov_diag"][i]).ravel(), "imu_link")
+    return np.array(rt), np.array(pub), np.array(chi)
+
+
+def _rmse(bag, traj):
+    v = np.stack([np.interp(traj[:, 0], bag["vicon_stamp"], bag["vicon_pos"][:, c]) for c in range(3)], 1)
+    return np.sqrt(((traj[:, 1:4] - v) ** 2).mean(axis=0))
+
+
+def _pair(bag, cfg, antenna=None):
+    import localization_amd as la
+    from oracle import oracle as O
+    ids = list(bag["anchor_ids"]) + [200]
+    pos = np.concatenate([bag["anchor_pos"], [[0.0, 0.0, 1.0]]])
+    node = la.LocalizationNode(ids, pos, antenna_offsets=antenna, **cfg)
+    ora = O.LocalizationOracle(ids, pos, antenna_offsets=antenna, jac_mode=O.JAC_ANALYTIC, **cfg)
+    return node, ora
+
+
+def test_bag_uwb_only_first_solves_match_tightly(gpu, bag):
+    """The first 60 solves (before any drift can build up): every published pose within 1e-6 m of the oracle."""
+    cfg = dict(trajectory_length=10, maximum_velocity=5.0, distance_outlier=1.0, maximum_iteration=10,
+               minimum_optimize_error=2000.0, publish_range=True)
+    node, ora = _pair(bag, cfg)
+    ev = _events(bag, False, 70)
+    g, gp, gc = _replay(bag, node, ev)
+    o, op, oc = _replay(bag, ora, ev)
+    assert len(g) == len(o) == 60 and np.array_equal(gp, op)
+    assert np.abs(g[:, 1:4] - o[:, 1:4]).max() < 1e-6
+    assert np.abs(gc - oc).max() <= 1e-6 * max(1.0, np.abs(oc).max())
+    assert np.array_equal(node.path(200)[:, 0], ora.path(200)[:, 0])           # same window, same stamps
+    assert np.abs(node.path(200)[:, 1:4] - ora.path(200)[:, 1:4]).max() < 1e-6
+    node.close()
+
+
+def test_bag_uwb_only_full_replay_config1(gpu, bag):
+    """BASELINE config 1 on the GPU front-end: cfg/uwb_only.yaml parameters over the whole bag."""
+    cfg = dict(trajectory_length=10, maximum_velocity=5.0, distance_outlier=1.0, maximum_iteration=10,
+               minimum_optimize_error=2000.0, publish_range=True)
+    node, ora = _pair(bag, cfg)
+    ev = _events(bag, False)
+    g, gp, gc = _replay(bag, node, ev)
+    o, op, oc = _replay(bag, ora, ev)
+    assert len(g) == len(o) and np.array_equal(gp, op)
+    rg, ro = _rmse(bag, g[gp]), _rmse(bag, o[op])
+    assert np.abs(rg - ro).max() < 1e-3, (rg, ro)
+    assert rg[0] < 0.08 and rg[1] < 0.08 and rg[2] < 0.25
+    d = np.abs(g[:, 1:4] - o[:, 1:4]).max(axis=1)
+    assert np.median(d) < 1e-4, (np.median(d), d.max())
+    node.close()
+
+
+def test_bag_uwb_imu_replay(gpu, bag):
+    """cfg/uwb_imu.yaml: IMU rotation priors interleaved in recorded order + an antenna lever arm."""
+    cfg = dict(trajectory_length=12, maximum_velocity=3.0, distance_outlier=3.0, maximum_iteration=10,
+               minimum_optimize_error=1000.0, publish_range=True, publish_imu=False)
+    ant = [[0.05, 0.0, -0.02]] * 3
+    node, ora = _pair(bag, cfg, ant)
+    ev = _events(bag, True, 400)
+    g, gp, gc = _replay(bag, node, ev)
+    o, op, oc = _replay(bag, ora, ev)
+    assert len(g) == len(o) and np.array_equal(gp, op)
+    d = np.abs(g[:, 1:8] - o[:, 1:8]).max(axis=1)
+    assert np.median(d) < 1e-5 and d[:40].max() < 1e-6, (np.median(d), d.max())
+    assert np.abs(_rmse(bag, g[gp]) - _rmse(bag, o[op])).max() < 1e-3
+    node.close()
+
+
+def test_pose_twist_lidar_factors_match_oracle(gpu):
+    """addPoseEdge (key-frame star), addTwistEdge (chain) and addLidarEdge against the oracle, one solve at a time."""
+    import localization_amd as la
+    from oracle import oracle as O
+    anch = np.array([[3, -3, 0.58], [3, 3, 1.97], [-3, 3, 0.54], [-3, -3, 1.76]], dtype=float)
+    ids = [100, 101, 102, 103, 200]
+    pos = np.concatenate([anch, [[0.0, 0.0, 1.0]]])
+    cfg = dict(trajectory_length=8, maximum_velocity=2.0, distance_outlier=5.0, maximum_iteration=10,
+               minimum_optimize_error=1e9, publish_range=True, publish_pose=True, publish_twist=True, publish_lidar=True)
+    node = la.LocalizationNode(ids, pos, **cfg)
+    ora = O.LocalizationOracle(ids, pos, jac_mode=O.JAC_ANALYTIC, **cfg)
+    rng = np.random.default_rng(3)
+    truth = np.array([0.4, -0.3, 1.1])
+    t = 10.0
+    worst = 0.0
+    for step in range(40):
+        t += 0.1
+        kind = step % 4
+        outs = []
+        for obj in (node, ora):
+            if kind in (0, 1):
+                a = step % 4
+                outs.append(obj.add_range(200, ids[a], t, np.linalg.norm(truth - anch[a]) + 0.01 * np.sin(step), 0.055, 0, "uwb"))
+            elif kind == 2:
+                tw = np.array([0.1, -0.05, 0.0, 0.0, 0.0, 0.2])
+                outs.append(obj.add_twist(t, tw, (np.eye(6) * 1e-2).ravel(), "uwb"))
+            else:
+                outs.append(obj.add_lidar(t, 1.1, "lidar"))
+        g, o = outs
+        assert g["solved"] == o["solved"]
+        if g["solved"]:
+            worst = max(worst, np.abs(g["realtime"][1:] - o["realtime"][1:]).max())
+        truth = truth + np.array([0.01, -0.005, 0.0])
+    assert worst < 1e-6, worst
+    # key-frame pose factors: frame_id changes every 3 messages
+    for step in range(12):
+        t += 0.1
+        pose = np.array([0.02 * (step % 3 + 1), 0.0, 0.0, 0.0, 0.0, np.sin(0.01), np.cos(0.01)])
+        cov = (np.eye(6) * 1e-3).ravel()
+        g = node.add_pose(t, pose, cov, f"key_{step // 3}")
+        o = ora.add_pose(t, pose, cov, f"key_{step // 3}")
+        assert g["solved"] and o["solved"]
+        assert np.abs(g["realtime"][1:] - o["realtime"][1:]).max() < 1e-6
+    node.close()
+
+
+def test_fleet_batch_equals_one_by_one(gpu, bag):
+    """Deferred mode: N nodes fed different streams, every pending solve done by ONE window launch — bit-identical to
+    solving each node on its own (instances are independent)."""
+    import localization_amd as la
+    ids = list(bag["anchor_ids"]) + [200]
+    pos = np.concatenate([bag["anchor_pos"], [[0.0, 0.0, 1.0]]])
+    cfg = dict(trajectory_length=6, maximum_velocity=5.0, distance_outlier=1.0, maximum_iteration=10,
+               minimum_optimize_error=2000.0, publish_range=True)
+    N = 24
+    rng = np.random.default_rng(0)
+    solo = [la.LocalizationNode(ids, pos, **cfg) for _ in range(N)]
+    fleet = [la.LocalizationNode(ids, pos, **cfg) for _ in range(N)]
+    for n in fleet:
+        n.set_deferred(True)
+    noise = rng.normal(0, 0.02, (N, 40))
+    for i in range(40):
+        outs_solo = []
+        for k in range(N):
+            args = (200, int(bag["uwb_responder"][i]), float(bag["uwb_stamp"][i]), float(bag["uwb_distance"][i] + noise[k, i]),
+                    float(bag["uwb_distance_err"][i]), 1, "uwb")
+            outs_solo.append(solo[k].add_range(*args))
+            o = fleet[k].add_range(*args)
+            assert not o["solved"]
+        n_solved, outs = la.solve_batch(fleet)
+        assert n_solved == sum(o["solved"] for o in outs_solo)
+        for k in range(N):
+            if outs_solo[k]["solved"]:
+                assert outs[k]["solved"] and np.array_equal(outs[k]["realtime"], outs_solo[k]["realtime"])
+                assert outs[k]["chi2"] == outs_solo[k]["chi2"]
+    for n in solo + fleet:
+        n.close()
+
+
+def test_node_errors(gpu, bag):
+    import localization_amd as la
+    ids = list(bag["anchor_ids"]) + [200]
+    pos = np.concatenate([bag["anchor_pos"], [[0.0, 0.0, 1.0]]])
+    node = la.LocalizationNode(ids, pos, trajectory_length=4, publish_range=True)
+    with pytest.raises(la.LocalizationAmdError) as e:
+        node.add_range(200, 177, 1.0, 3.0, 0.055)         # reference: std::map::at throws (localization.cpp:306)
+    assert e.value.code == -4
+    with pytest.raises(la.LocalizationAmdError):
+        la.LocalizationNode(ids, pos, trajectory_length=20)  # uwb_st.yaml's T = 20: beyond this kernel version
+    node.close()
