@@ -125,18 +125,22 @@ __device__ __forceinline__ void quat_right_jac(const double* q, double sgn, doub
 struct Lds {
     double* A; int ld;
     double *diagL, *b, *x, *pose, *bak, *rrec, *prec, *srec;
+    int* first;  // skyline: leftmost column of each row of H
+    // this instance's edge tables, staged from HBM once per launch
+    const int32_t *r_idx, *p_idx, *s_idx;
+    const double *r_val, *p_val, *s_val;
 };
 
 // Evaluate every edge at the current poses: errors + chi sums always, Jacobian/weight records when FULL.
 template <bool FULL>
 __device__ void evaluate_edges(const WindowArgs& a, const Lds& L, int inst, int lane, int nr, int np, int ns,
                                double& robust_chi, double& plain_chi) {
-    const WindowCaps& c = a.caps;
+    (void)inst;
     double rsum = 0.0, csum = 0.0;
     // ---- range edges ------------------------------------------------------------------------------------------
     for (int e = lane; e < nr; e += 64) {
-        const int32_t* idx = a.r_idx + ((size_t)inst * c.nr_max + e) * 2;
-        const double* val = a.r_val + ((size_t)inst * c.nr_max + e) * 5;
+        const int32_t* idx = L.r_idx + e * 2;
+        const double* val = L.r_val + e * 5;
         const int v0 = idx[0], v1 = idx[1];
         const double meas = val[0], info = val[1];
         const double off[3] = {val[2], val[3], val[4]};
@@ -177,8 +181,8 @@ __device__ void evaluate_edges(const WindowArgs& a, const Lds& L, int inst, int 
     }
     // ---- unary priors -------------------------------------------------------------------------------------------
     for (int e = lane; e < np; e += 64) {
-        const int v = a.p_idx[(size_t)inst * c.np_max + e];
-        const double* val = a.p_val + ((size_t)inst * c.np_max + e) * 18;
+        const int v = L.p_idx[e];
+        const double* val = L.p_val + e * 18;
         const double* X = L.pose + v * 12;
         double RE[9], tE[3], q[4];
         mat_mul(val, X, RE);
@@ -207,8 +211,8 @@ __device__ void evaluate_edges(const WindowArgs& a, const Lds& L, int inst, int 
     }
     // ---- binary SE3 edges ---------------------------------------------------------------------------------------
     for (int e = lane; e < ns; e += 64) {
-        const int32_t* idx = a.s_idx + ((size_t)inst * c.ns_max + e) * 4;
-        const double* val = a.s_val + ((size_t)inst * c.ns_max + e) * 48;
+        const int32_t* idx = L.s_idx + e * 4;
+        const double* val = L.s_val + e * 48;
         const int vi = idx[0], vj = idx[1], robust = idx[2];
         const double* Xi = L.pose + vi * 12;
         const double* Xj = L.pose + vj * 12;
@@ -291,16 +295,36 @@ __device__ void evaluate_edges(const WindowArgs& a, const Lds& L, int inst, int 
     plain_chi = wave_sum(csum);
 }
 
+// Skyline of H, once per solve (the topology does not change between iterations).
+__device__ void compute_skyline(const Lds& L, int lane, int n, int nr, int ns) {
+    // skyline of H: a pose's rows start at its leftmost neighbour's block (binary edges only couple two poses)
+    if (lane == 0) {
+        const int nv = n / 6;
+        for (int v = 0; v < nv; ++v) L.first[v * 6] = v;
+        for (int e = 0; e < nr; ++e) {
+            const int32_t* idx = L.r_idx + e * 2;
+            if (idx[1] >= 0) { const int lo = min(idx[0], idx[1]), hi = max(idx[0], idx[1]); L.first[hi * 6] = min(L.first[hi * 6], lo); }
+        }
+        for (int e = 0; e < ns; ++e) {
+            const int32_t* idx = L.s_idx + e * 4;
+            const int lo = min(idx[0], idx[1]), hi = max(idx[0], idx[1]);
+            L.first[hi * 6] = min(L.first[hi * 6], lo);
+        }
+        for (int v = 0; v < nv; ++v) { const int f = L.first[v * 6] * 6; for (int r = 0; r < 6; ++r) L.first[v * 6 + r] = f; }
+    }
+    __syncthreads();
+}
+
 // Fold the edge records into H (upper triangle of A, diagonal included) and b, one edge after the other.
 __device__ void build_system(const WindowArgs& a, const Lds& L, int inst, int lane, int n, int nr, int np, int ns) {
-    const WindowCaps& c = a.caps;
+    (void)a; (void)inst;
     const int ld = L.ld;
-    for (int i = lane; i < n * ld; i += 64) L.A[i] = 0.0;
+    for (int i = lane; i < (n + 1) * ld; i += 64) L.A[i] = 0.0;
     for (int i = lane; i < n; i += 64) L.b[i] = 0.0;
     __syncthreads();
     const int r = lane / 6, cc = lane % 6;  // lanes 0..35: one entry of a 6x6 block
     for (int e = 0; e < nr; ++e) {
-        const int32_t* idx = a.r_idx + ((size_t)inst * c.nr_max + e) * 2;
+        const int32_t* idx = L.r_idx + e * 2;
         const int v0 = idx[0], v1 = idx[1];
         const double* rec = L.rrec + e * RREC;
         const double wr = rec[12], om = rec[13];
@@ -318,7 +342,7 @@ __device__ void build_system(const WindowArgs& a, const Lds& L, int inst, int la
         }
     }
     for (int e = 0; e < np; ++e) {
-        const int v = a.p_idx[(size_t)inst * c.np_max + e];
+        const int v = L.p_idx[e];
         const double* rec = L.prec + e * PREC;
         if (lane < 36) {
             if (r <= cc) {
@@ -336,7 +360,7 @@ __device__ void build_system(const WindowArgs& a, const Lds& L, int inst, int la
         }
     }
     for (int e = 0; e < ns; ++e) {
-        const int32_t* idx = a.s_idx + ((size_t)inst * c.ns_max + e) * 4;
+        const int32_t* idx = L.s_idx + e * 4;
         const int vi = idx[0], vj = idx[1];
         const double* rec = L.srec + e * SREC;
         const double *J0 = rec, *J1 = rec + 36, *WJ0 = rec + 72, *WJ1 = rec + 108, *om = rec + 144;
@@ -364,44 +388,73 @@ __device__ void build_system(const WindowArgs& a, const Lds& L, int inst, int la
     __syncthreads();
 }
 
-// (H + lambda I) = L L^T, L into the strict lower triangle of A + diagL; false if not positive definite.
-__device__ bool cholesky(const Lds& L, int lane, int n, double lambda) {
+// (H + lambda I) x = b in one sweep.
+//   * Left-looking Cholesky, one matrix row per lane (two for n > 64): at column j every lane forms
+//     v_i = H[j][i] - sum_k L[i][k] L[j][k] for its rows i >= j; the pivot is lane j's own v, fetched with one
+//     cross-lane read, so there is no serial diagonal loop.
+//   * The right-hand side rides along as row n of the factor (forward substitution IS one more Cholesky row):
+//     after the sweep L[n][k] = y_k.
+//   * Skyline: row i has no entry left of first[i] (its leftmost graph neighbour's block), and Cholesky keeps that
+//     envelope, so the k-loops run over the band only (<= 12 entries for the reference's chain topology).
+//   * Back substitution keeps y in registers and walks the rows of L: no LDS writes, no barriers.
+// L goes to the strict lower triangle of A (H stays in the upper one), pivots to diagL, x to L.x.
+__device__ bool factor_and_solve(const Lds& L, int lane, int n, double lambda) {
     const int ld = L.ld;
+    const int i0 = lane, i1 = lane + 64;
+    const bool has1 = i1 <= n;
+    const int f0 = (i0 < n) ? L.first[i0] : 0, f1 = (has1 && i1 < n) ? L.first[i1] : 0;
     bool ok = true;
     for (int j = 0; j < n; ++j) {
-        double s = L.A[j * ld + j] + lambda;
-        for (int k = 0; k < j; ++k) { const double l = L.A[j * ld + k]; s -= l * l; }
-        if (!(s > 0.0) || !(s < DBL_MAX)) { ok = false; break; }
-        const double ljj = sqrt(s), inv = 1.0 / ljj;
-        for (int i = j + 1 + lane; i < n; i += 64) {
-            double v = L.A[j * ld + i];
-            for (int k = 0; k < j; ++k) v -= L.A[i * ld + k] * L.A[j * ld + k];
-            L.A[i * ld + j] = v * inv;
+        const int fj = L.first[j];
+        double v0 = 0.0, v1 = 0.0;
+        if (i0 >= j && i0 <= n) {
+            v0 = (i0 == n) ? L.b[j] : L.A[j * ld + i0];
+            if (i0 == j) v0 += lambda;
+            const double* ri = L.A + i0 * ld;
+            const double* rj = L.A + j * ld;
+            int k = fj > f0 ? fj : f0;
+            double s0 = 0.0, s1 = 0.0;
+            for (; k + 1 < j; k += 2) { s0 += ri[k] * rj[k]; s1 += ri[k + 1] * rj[k + 1]; }
+            if (k < j) s0 += ri[k] * rj[k];
+            v0 -= s0 + s1;
         }
+        if (has1 && i1 >= j) {
+            v1 = (i1 == n) ? L.b[j] : L.A[j * ld + i1];
+            if (i1 == j) v1 += lambda;
+            const double* ri = L.A + i1 * ld;
+            const double* rj = L.A + j * ld;
+            int k = fj > f1 ? fj : f1;
+            double s0 = 0.0, s1 = 0.0;
+            for (; k + 1 < j; k += 2) { s0 += ri[k] * rj[k]; s1 += ri[k + 1] * rj[k + 1]; }
+            if (k < j) s0 += ri[k] * rj[k];
+            v1 -= s0 + s1;
+        }
+        const double piv = (j < 64) ? __shfl(v0, j) : __shfl(v1, j - 64);
+        if (!(piv > 0.0) || !(piv < DBL_MAX)) { ok = false; break; }
+        const double ljj = sqrt(piv), inv = 1.0 / ljj;
+        if (i0 > j && i0 <= n) L.A[i0 * ld + j] = v0 * inv;
+        if (has1 && i1 > j) L.A[i1 * ld + j] = v1 * inv;
         if (lane == 0) L.diagL[j] = ljj;
         __syncthreads();
     }
-    return ok;
-}
-// L L^T x = b (column oriented, lanes over the trailing rows)
-__device__ void chol_solve(const Lds& L, int lane, int n) {
-    const int ld = L.ld;
-    for (int i = lane; i < n; i += 64) L.x[i] = L.b[i];
-    __syncthreads();
-    for (int j = 0; j < n; ++j) {
-        const double yj = L.x[j] / L.diagL[j];
-        __syncthreads();
-        if (lane == 0) L.x[j] = yj;
-        for (int i = j + 1 + lane; i < n; i += 64) L.x[i] -= L.A[i * ld + j] * yj;
-        __syncthreads();
-    }
+    if (!ok) return false;
+    // y (= row n of the factor) into registers: lane k holds y_k and y_{k+64}
+    double y0 = (i0 < n) ? L.A[n * ld + i0] : 0.0;
+    double y1 = (i1 < n) ? L.A[n * ld + i1] : 0.0;
     for (int j = n - 1; j >= 0; --j) {
-        const double xj = L.x[j] / L.diagL[j];
-        __syncthreads();
-        if (lane == 0) L.x[j] = xj;
-        for (int k = lane; k < j; k += 64) L.x[k] -= L.A[j * ld + k] * xj;
-        __syncthreads();
+        const double yj = (j < 64) ? __shfl(y0, j) : __shfl(y1, j - 64);
+        const double xj = yj / L.diagL[j];
+        const int fj = L.first[j];
+        const double* rj = L.A + j * ld;
+        if (i0 == j) y0 = xj;
+        else if (i0 < j && i0 >= fj) y0 -= rj[i0] * xj;
+        if (i1 == j) y1 = xj;
+        else if (i1 < j && i1 >= fj) y1 -= rj[i1] * xj;
     }
+    if (i0 < n) L.x[i0] = y0;
+    if (i1 < n) L.x[i1] = y1;
+    __syncthreads();
+    return true;
 }
 
 __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
@@ -415,7 +468,7 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
     Lds L;
     L.ld = n_max | 1;
     double* p = lds;
-    L.A = p; p += (size_t)n_max * L.ld;
+    L.A = p; p += (size_t)(n_max + 1) * L.ld;  // +1 row: the right-hand side rides along as row n
     L.diagL = p; p += n_max;
     L.b = p; p += n_max;
     L.x = p; p += n_max;
@@ -423,11 +476,26 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
     L.bak = p; p += c.nv_max * 12;
     L.rrec = p; p += c.nr_max * RREC;
     L.prec = p; p += c.np_max * PREC;
-    L.srec = p;
+    L.srec = p; p += c.ns_max * SREC;
+    L.first = reinterpret_cast<int*>(p); p += (n_max + 2) / 2;
+    double* st_rval = p; p += c.nr_max * 5;
+    double* st_pval = p; p += c.np_max * 18;
+    double* st_sval = p; p += c.ns_max * 48;
+    int32_t* st_ridx = reinterpret_cast<int32_t*>(p); p += c.nr_max;        // nr_max * 2 ints
+    int32_t* st_pidx = reinterpret_cast<int32_t*>(p); p += (c.np_max + 1) / 2;
+    int32_t* st_sidx = reinterpret_cast<int32_t*>(p);                        // ns_max * 4 ints
+    L.r_idx = st_ridx; L.p_idx = st_pidx; L.s_idx = st_sidx; L.r_val = st_rval; L.p_val = st_pval; L.s_val = st_sval;
 
     double* gpose = a.poses + (size_t)inst * c.nv_max * 12;
     for (int i = lane; i < nv * 12; i += 64) L.pose[i] = gpose[i];
+    for (int i = lane; i < nr * 2; i += 64) st_ridx[i] = a.r_idx[(size_t)inst * c.nr_max * 2 + i];
+    for (int i = lane; i < nr * 5; i += 64) st_rval[i] = a.r_val[(size_t)inst * c.nr_max * 5 + i];
+    for (int i = lane; i < np; i += 64) st_pidx[i] = a.p_idx[(size_t)inst * c.np_max + i];
+    for (int i = lane; i < np * 18; i += 64) st_pval[i] = a.p_val[(size_t)inst * c.np_max * 18 + i];
+    for (int i = lane; i < ns * 4; i += 64) st_sidx[i] = a.s_idx[(size_t)inst * c.ns_max * 4 + i];
+    for (int i = lane; i < ns * 48; i += 64) st_sval[i] = a.s_val[(size_t)inst * c.ns_max * 48 + i];
     __syncthreads();
+    compute_skyline(L, lane, n, nr, ns);
 
     constexpr double tau = 1e-5, good_lo = 1.0 / 3.0, good_hi = 2.0 / 3.0;
     constexpr int max_trials = 10;
@@ -452,10 +520,8 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
         int q = 0;
         do {
             for (int i = lane; i < nv * 12; i += 64) L.bak[i] = L.pose[i];  // push
-            const bool ok2 = cholesky(L, lane, n, lambda);
-            __syncthreads();
-            if (ok2) chol_solve(L, lane, n);
-            else { for (int i = lane; i < n; i += 64) L.x[i] = 0.0; __syncthreads(); }
+            const bool ok2 = factor_and_solve(L, lane, n, lambda);
+            if (!ok2) { for (int i = lane; i < n; i += 64) L.x[i] = 0.0; __syncthreads(); }
             // update: X <- X * fromVectorMQT(dx), one pose per lane
             for (int v = lane; v < nv; v += 64) {
                 const double* dx = L.x + v * 6;
@@ -513,7 +579,8 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
 size_t window_lds_bytes(const WindowCaps& c) {
     const size_t n_max = 6 * (size_t)c.nv_max;
     const size_t ld = n_max | 1;
-    size_t d = n_max * ld + 3 * n_max + 2 * (size_t)c.nv_max * 12 + (size_t)c.nr_max * RREC + (size_t)c.np_max * PREC +
+    size_t d = (n_max + 1) * ld + 3 * n_max + (n_max + 2) / 2 + (size_t)c.nr_max * 6 + (size_t)c.np_max * 18 + (c.np_max + 1) / 2 +
+               (size_t)c.ns_max * 50 + 2 * (size_t)c.nv_max * 12 + (size_t)c.nr_max * RREC + (size_t)c.np_max * PREC +
                (size_t)c.ns_max * SREC;
     return d * sizeof(double);
 }

@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Secondary measurements of the sliding-window path (not the headline bench): windows/s of the general graph kernel
+on synthetic instances in the reference's topology, next to the oracle on one host core.
+
+    python tools/bench_window.py --shape uwb_only   # T = 10, ranges + smoothness        (cfg/uwb_only.yaml shape)
+    python tools/bench_window.py --shape uwb_imu    # T = 12, + IMU priors + lever arm   (cfg/uwb_imu.yaml shape)
+    python tools/bench_window.py --shape fusion1    # 1 pose, 8 ranges + IMU prior       (BASELINE config 3 shape)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+from scipy.spatial.transform import Rotation
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+ANCH4 = np.array([[3, -3, 0.58], [3, 3, 1.97], [-3, 3, 0.54], [-3, -3, 1.76]], dtype=float)
+
+
+def build(B, shape, seed=0):
+    import localization_amd as la
+    from localization_amd.synthetic import ANCHORS_8
+    rng = np.random.default_rng(seed)
+    if shape == "fusion1":
+        T, anchors, imu, lever, per_pose = 1, ANCHORS_8, True, True, 8
+    elif shape == "uwb_imu":
+        T, anchors, imu, lever, per_pose = 12, ANCH4, True, True, 1
+    else:
+        T, anchors, imu, lever, per_pose = 10, ANCH4, False, False, 1
+    off = np.array([0.1, 0.0, -0.05]) if lever else np.zeros(3)
+    wb = la.WindowBatch(B, T, max(2 * T, per_pose), T if imu else 0, 0)
+    graphs = []
+    for i in range(B):
+        tt = np.cumsum(rng.normal(0, 0.05, (T, 3)), axis=0) + np.array([rng.uniform(-1.5, 1.5), rng.uniform(-1.5, 1.5), 1.1])
+        tR = Rotation.from_rotvec(np.cumsum(rng.normal(0, 0.03, (T, 3)), axis=0) + rng.normal(0, 0.3, 3))
+        et = tt + rng.normal(0, 0.05, (T, 3)); eR = (tR * Rotation.from_rotvec(rng.normal(0, 0.02, (T, 3)))).as_matrix()
+        g = dict(et=et, eR=eR, off=off, ranges=[], smooth=[], priors=[])
+        for k in range(T):
+            wb.add_pose(i, et[k], eR[k])
+            for a in (range(per_pose) if per_pose > 1 else [int(rng.integers(0, len(anchors)))]):
+                d = float(np.float32(np.linalg.norm(tt[k] + tR[k].apply(off) - anchors[a]) + rng.normal(0, 0.03)))
+                wb.add_range(i, k, a, d, 1 / 0.055 ** 2, off, anchor=True); g["ranges"].append((k, a, d))
+            if k:
+                wb.add_range(i, k - 1, k, 0.0, 1 / (5.0 / 32 / 3) ** 2); g["smooth"].append((k - 1, k))
+            if imu:
+                R = (tR[k] * Rotation.from_rotvec(rng.normal(0, 2e-3, 3))).as_matrix()
+                dg = np.array([0, 0, 0, 1, 1, 1.0]) / 4.592449e-06
+                wb.add_prior(i, k, et[k], R, dg); g["priors"].append((k, et[k].copy(), R, dg))
+        graphs.append(g)
+    return wb, graphs, anchors, T
+
+
+def oracle_time(graphs, anchors, T, n, iters=10):
+    from oracle import oracle as O
+    t0 = time.perf_counter()
+    out = []
+    for g in graphs[:n]:
+        G = O.Graph()
+        for m, a in enumerate(anchors): G.add_vertex(m, a, fixed=True)
+        for k in range(T): G.add_vertex(100 + k, g["et"][k], g["eR"][k])
+        for (k, a, d) in g["ranges"]: G.add_range_edge(100 + k, a, d, 1 / 0.055 ** 2, off0=g["off"])
+        for (k0, k1) in g["smooth"]: G.add_range_edge(100 + k0, 100 + k1, 0.0, 1 / (5.0 / 32 / 3) ** 2)
+        for (k, t, R, dg) in g["priors"]: G.add_prior_edge(100 + k, t, R, np.diag(dg))
+        G.optimize(iters, O.JAC_NUMERIC_G2O)
+        out.append(np.array([G.estimate(100 + k)[1] for k in range(T)]))
+    return time.perf_counter() - t0, np.array(out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", default="uwb_only", choices=["uwb_only", "uwb_imu", "fusion1"])
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--cpu-n", type=int, default=256)
+    a = ap.parse_args()
+    import localization_amd as la
+    wb, graphs, anchors, T = build(a.batch, a.shape)
+    solver = la.WindowSolver(anchors, a.batch, *wb.caps, maximum_iteration=10)
+    poses0 = wb.poses.copy()
+    ms = []
+    for r in range(a.reps + 1):
+        wb.poses[:] = poses0
+        t0 = time.perf_counter(); solver.solve(wb); wall = time.perf_counter() - t0
+        if r: ms.append((solver.last_kernel_ms(), wall * 1e3))
+    k_ms = float(np.median([m[0] for m in ms])); w_ms = float(np.median([m[1] for m in ms]))
+    one = la.WindowBatch(1, *wb.caps)
+    for name in ("counts", "poses", "r_idx", "r_val", "p_idx", "p_val", "s_idx", "s_val"):
+        getattr(one, name)[:] = getattr(wb, name)[:1] if name != "poses" else poses0[:1]
+    s1 = la.WindowSolver(anchors, 1, *wb.caps, maximum_iteration=10)
+    lat = []
+    for r in range(20):
+        one.poses[:] = poses0[:1]
+        t0 = time.perf_counter(); s1.solve(one); lat.append((time.perf_counter() - t0) * 1e3)
+    cpu_s, cpu_t = oracle_time(graphs, anchors, T, min(a.cpu_n, a.batch))
+    diff = float(np.abs(wb.poses[: len(cpu_t), :, 9:] - cpu_t).max())
+    print(json.dumps({
+        "shape": a.shape, "poses_per_window": T, "unknowns": 6 * T, "batch": a.batch, "lds_bytes_per_instance": solver.lds_bytes,
+        "gpu_kernel_ms_per_batch": k_ms, "gpu_windows_per_s_kernel": a.batch / (k_ms * 1e-3),
+        "gpu_windows_per_s_incl_pcie": a.batch / (w_ms * 1e-3),
+        "gpu_single_window_latency_ms_incl_pcie": float(np.median(lat)), "gpu_single_window_kernel_ms": s1.last_kernel_ms(),
+        "cpu_oracle_windows_per_s_1core": len(cpu_t) / cpu_s, "cpu_ms_per_window": cpu_s / len(cpu_t) * 1e3,
+        "mean_lm_trials": float(wb.result[:, 4].mean()),
+        "max_abs_diff_vs_oracle_numeric_m": diff}))
+
+
+if __name__ == "__main__":
+    main()
