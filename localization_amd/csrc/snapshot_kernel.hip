@@ -231,9 +231,26 @@ __device__ __forceinline__ void ingest(const float (&df)[APL], const float (&sf)
     }
 }
 
+// LDS holds what a lane touches once per epoch, so the per-pass registers stay under the 256 architectural VGPRs:
+//   s_next [APL][256] double2 : (measurement, information) of the window's second epoch, per lane
+//   s_raw  [2*APL/4][256] float4 : raw float tiles of the epoch after that, landed by LDS-DMA (global_load_lds_dwordx4:
+//            no VGPR destination, so an in-flight prefetch costs no registers and no loop-carried copies)
+template <int APL> struct SnapshotLds {
+    static constexpr int NEXT_BYTES = APL * 256 * 16;
+    static constexpr int RAW_BYTES = (APL % 4 == 0) ? (2 * (APL / 4) * 256 * 16) : 0;
+    static constexpr int BYTES = NEXT_BYTES + RAW_BYTES;
+};
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* glb_void_ptr;
+
 template <int LPI, int APL, int JAC>
 __global__ void __launch_bounds__(256) snapshot_lm_kernel(const SnapshotArgs a) {
-    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ __attribute__((aligned(16))) char lds_bytes[SnapshotLds<APL>::BYTES];
+    double2* const s_next = reinterpret_cast<double2*>(lds_bytes);
+    float4* const s_raw = reinterpret_cast<float4*>(lds_bytes + SnapshotLds<APL>::NEXT_BYTES);
+    const int tib = threadIdx.x;
+    const long long tid = (long long)blockIdx.x * blockDim.x + tib;
     const long long inst = tid / LPI;
     const int g = (int)(tid % LPI);
     const long long B = a.B;
@@ -257,27 +274,81 @@ __global__ void __launch_bounds__(256) snapshot_lm_kernel(const SnapshotArgs a) 
     constexpr int max_trials = 10;
 
     // Epoch window [c, c+1]: every live lane of the wave works on epoch c or c+1.
-    //   d, w   : this lane's current epoch (k)
-    //   dn, wn : epoch c+1, already converted to (measurement, information) for ALL lanes
-    //   dfr,sfr: raw float ranges of epoch c+2, in flight from HBM
-    // A lane that finishes epoch c takes (dn, wn) with register moves; one that finishes c+1 early waits until the
-    // slowest lane has left epoch c, at which point the whole wave converts c+2 in lockstep and prefetches c+3.
-    double px = 0, py = 0, pz = 0;
-    double d[APL], w[APL], dn[APL], wn[APL];
-    float dfr[APL], sfr[APL];
+    //   d, w   (registers): this lane's current epoch (k)
+    //   s_next (LDS)      : epoch c+1, already converted to (measurement, information) for ALL lanes
+    //   s_raw  (LDS)      : raw float ranges of epoch c+2, in flight from HBM
+    // A lane that finishes epoch c takes its s_next entry; one that finishes c+1 early waits until the slowest lane
+    // has left epoch c, at which point the whole wave converts c+2 in lockstep and prefetches c+3.
+    auto put_next = [&](const double (&dd)[APL], const double (&ww)[APL]) {
 #pragma unroll
-    for (int j = 0; j < APL; ++j) { dn[j] = 0; wn[j] = 0; dfr[j] = 0; sfr[j] = 0; }
+        for (int j = 0; j < APL; ++j) s_next[j * 256 + tib] = make_double2(dd[j], ww[j]);
+    };
+    // Hand-issued ds_read_b128: hipcc cannot tell s_next from s_raw and would put an s_waitcnt vmcnt(0) (the LDS-DMA
+    // and every store in flight) in front of compiler-generated LDS reads here, on every pass; s_next is only ever
+    // written by this lane's own ds_write, so lgkmcnt is the only counter that matters.
+    auto take_next = [&](double (&dd)[APL], double (&ww)[APL]) {
+        typedef double v2f64 __attribute__((ext_vector_type(2)));
+        const unsigned addr = (unsigned)(unsigned long long)(s_next + tib);
+        v2f64 v[APL];
+#pragma unroll
+        for (int j = 0; j < APL; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[j]) : "v"(addr), "n"(j * 4096));
+        if constexpr (APL == 8) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) :: "memory");
+        } else {
+#pragma unroll
+            for (int j = 0; j < APL; ++j) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[j]) :: "memory");
+        }
+#pragma unroll
+        for (int j = 0; j < APL; ++j) { dd[j] = v[j].x; ww[j] = v[j].y; }
+    };
+    // start the fetch of epoch `ke` (no-op for lane mappings that cannot use 16-byte LDS-DMA: they load at consume time)
+    auto prefetch = [&](int ke) {
+        if constexpr (APL % 4 == 0) {
+            const int wave_base = (tib / 64) * 64;
+#pragma unroll
+            for (int q4 = 0; q4 < APL / 4; ++q4) {
+                const long long idx = ((long long)ke * a.M4 + (m0 / 4 + q4)) * B + ld_inst;
+                __builtin_amdgcn_global_load_lds((glb_void_ptr)(reinterpret_cast<const float4*>(a.dist) + idx),
+                                                 (lds_void_ptr)(s_raw + q4 * 256 + wave_base), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_void_ptr)(reinterpret_cast<const float4*>(a.err) + idx),
+                                                 (lds_void_ptr)(s_raw + (APL / 4 + q4) * 256 + wave_base), 16, 0, 0);
+            }
+        }
+    };
+    auto consume = [&](int ke, double (&dd)[APL], double (&ww)[APL]) {
+        float df[APL], sf[APL];
+        if constexpr (APL % 4 == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA of epoch ke has landed (issued ~10 passes ago)
+#pragma unroll
+            for (int q4 = 0; q4 < APL / 4; ++q4) {
+                const float4 dv = s_raw[q4 * 256 + tib];
+                const float4 sv = s_raw[(APL / 4 + q4) * 256 + tib];
+                df[4 * q4 + 0] = dv.x; df[4 * q4 + 1] = dv.y; df[4 * q4 + 2] = dv.z; df[4 * q4 + 3] = dv.w;
+                sf[4 * q4 + 0] = sv.x; sf[4 * q4 + 1] = sv.y; sf[4 * q4 + 2] = sv.z; sf[4 * q4 + 3] = sv.w;
+            }
+        } else {
+            load_epoch<APL>(a, ke, m0, ld_inst, df, sf);
+        }
+        ingest<APL>(df, sf, dd, ww);
+    };
+
+    double px = 0, py = 0, pz = 0;
+    double d[APL], w[APL];
     if (live) { px = a.pos[0 * B + inst]; py = a.pos[1 * B + inst]; pz = a.pos[2 * B + inst]; }
     {
         float df0[APL], sf0[APL];
         load_epoch<APL>(a, 0, m0, ld_inst, df0, sf0);
         ingest<APL>(df0, sf0, d, w);
         if (K > 1) {
+            double dn[APL], wn[APL];
             load_epoch<APL>(a, 1, m0, ld_inst, df0, sf0);
             ingest<APL>(df0, sf0, dn, wn);
+            put_next(dn, wn);
         }
-        if (K > 2) load_epoch<APL>(a, 2, m0, ld_inst, dfr, sfr);
+        if (K > 2) prefetch(2);
     }
+    // the prior's loads retire here, not at their first use inside the loop (where the wait would sit on every pass)
+    asm volatile("" : "+v"(px), "+v"(py), "+v"(pz));
 
     System cur = {1, 0, 0, 1, 0, 1, 0, 0, 0, 0, 0};
     double cur_chi = 0, last_chi = 0, lambda = 1.0, ni = 2.0;
@@ -356,8 +427,7 @@ __global__ void __launch_bounds__(256) snapshot_lm_kernel(const SnapshotArgs a) 
                     exhausted = true;
                     if (g == 0) { a.pos[0 * B + inst] = px; a.pos[1 * B + inst] = py; a.pos[2 * B + inst] = pz; }
                 } else if (k == c) {
-#pragma unroll
-                    for (int j = 0; j < APL; ++j) { d[j] = dn[j]; w[j] = wn[j]; }
+                    take_next(d, w);
                     k = c + 1;
                     init = true;
                 } else {
@@ -368,14 +438,19 @@ __global__ void __launch_bounds__(256) snapshot_lm_kernel(const SnapshotArgs a) 
         // ---- window advance: nobody is left in epoch c -> convert epoch c+2 for all lanes, prefetch c+3 --------------
         if (!__any(!exhausted && k == c)) {
             ++c;
-            ingest<APL>(dfr, sfr, dn, wn);  // epoch c+1 (garbage-but-unused once c+1 >= K)
-            if (c + 2 < K) load_epoch<APL>(a, c + 2, m0, ld_inst, dfr, sfr);
-            if (waiting) {  // k == c now: release into epoch c+1
+            if (c + 1 < K) {
+                double dn[APL], wn[APL];
+                consume(c + 1, dn, wn);
+                put_next(dn, wn);
+                asm volatile("" ::: "memory");  // the LDS reads of s_raw above stay ahead of the DMA that refills it
+                if (c + 2 < K) prefetch(c + 2);
+                if (waiting) {  // k == c now: release into epoch c+1
 #pragma unroll
-                for (int j = 0; j < APL; ++j) { d[j] = dn[j]; w[j] = wn[j]; }
-                k = c + 1;
-                init = true;
-                waiting = false;
+                    for (int j = 0; j < APL; ++j) { d[j] = dn[j]; w[j] = wn[j]; }
+                    k = c + 1;
+                    init = true;
+                    waiting = false;
+                }
             }
         }
     }
