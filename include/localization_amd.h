@@ -135,7 +135,9 @@ int loc_snapshot_timing_end(loc_snapshot* s, int32_t* n_launches, double* total_
  *   s_val  double[B][ns_max][48]  INVERSE measurement Z^-1 as R(9), t(3); information 6x6 row-major
  *   result double[B][8]           chi2() over all edges at the last evaluated state, robust chi2 of the accepted
  *                                 state, final lambda, outer iterations run, LM trials, terminated flag, 0, 0
- * Limits: nv_max <= 16, nr_max <= 64, np_max <= 32, ns_max <= 32 and the per-instance LDS footprint <= 160 KiB.
+ * Limits: nv_max <= 64.  Up to 16 poses the (6 nv_max + 1)^2 matrix lives in LDS next to the edge tables; larger
+ * windows keep it in a per-instance HBM workspace ((6 nv_max + 1)^2 doubles each).  In both cases the edge tables and
+ * records must fit 160 KiB of LDS (loc_window_lds_bytes tells).
  * ============================================================================================== */
 typedef struct loc_window loc_window;
 typedef struct loc_window_caps { int32_t nv_max, nr_max, np_max, ns_max; } loc_window_caps;

@@ -26,6 +26,7 @@ struct loc_window {
     double* d_anchors = nullptr;
     int32_t *d_counts = nullptr, *d_ridx = nullptr, *d_pidx = nullptr, *d_sidx = nullptr;
     double *d_poses = nullptr, *d_rval = nullptr, *d_pval = nullptr, *d_sval = nullptr, *d_result = nullptr;
+    double* d_workspace = nullptr;  // HBM copy of the (H, L) matrices when they do not fit LDS
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_ms = 0.0;
@@ -36,13 +37,14 @@ extern "C" {
 size_t loc_window_lds_bytes(const loc_window_caps* caps) {
     if (!caps) return 0;
     locamd::WindowCaps c{caps->nv_max, caps->nr_max, caps->np_max, caps->ns_max};
-    return locamd::window_lds_bytes(c);
+    const size_t in_lds = locamd::window_lds_bytes(c, false);
+    return in_lds <= 160 * 1024 ? in_lds : locamd::window_lds_bytes(c, true);
 }
 
 int loc_window_destroy(loc_window* w) {
     if (!w) return LOC_OK;
     (void)hipSetDevice(w->device);
-    void* ptrs[] = {w->d_anchors, w->d_counts, w->d_ridx, w->d_pidx, w->d_sidx, w->d_poses, w->d_rval, w->d_pval, w->d_sval, w->d_result};
+    void* ptrs[] = {w->d_anchors, w->d_counts, w->d_ridx, w->d_pidx, w->d_sidx, w->d_poses, w->d_rval, w->d_pval, w->d_sval, w->d_result, w->d_workspace};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (w->ev0) (void)hipEventDestroy(w->ev0);
     if (w->ev1) (void)hipEventDestroy(w->ev1);
@@ -56,10 +58,10 @@ int loc_window_create(loc_window** out, int32_t device, int64_t batch, const loc
     if (!out) return locamd_fail(LOC_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (batch <= 0 || !caps || n_anchors < 0 || (n_anchors > 0 && !anchors)) return locamd_fail(LOC_ERR_INVALID, "window arguments");
-    if (caps->nv_max <= 0 || caps->nv_max > 16 || caps->nr_max < 0 || caps->nr_max > 64 || caps->np_max < 0 ||
-        caps->np_max > 32 || caps->ns_max < 0 || caps->ns_max > 32)
-        return locamd_fail(LOC_ERR_UNSUPPORTED, "window capacities (nv<=16, nr<=64, np<=32, ns<=32)");
-    if (loc_window_lds_bytes(caps) > 160 * 1024) return locamd_fail(LOC_ERR_UNSUPPORTED, "window does not fit 160 KiB of LDS");
+    if (caps->nv_max <= 0 || caps->nv_max > 64 || caps->nr_max < 0 || caps->np_max < 0 || caps->ns_max < 0)
+        return locamd_fail(LOC_ERR_UNSUPPORTED, "window capacities (1 <= nv_max <= 64)");
+    if (loc_window_lds_bytes(caps) > 160 * 1024)
+        return locamd_fail(LOC_ERR_UNSUPPORTED, "edge tables and records of this window do not fit 160 KiB of LDS");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return locamd_fail(LOC_ERR_NO_DEVICE, "no HIP device visible: localization_amd has no CPU fallback");
@@ -69,6 +71,7 @@ int loc_window_create(loc_window** out, int32_t device, int64_t batch, const loc
     if (!w) return locamd_fail(LOC_ERR_INVALID, "out of host memory");
     w->device = device; w->B = batch; w->n_anchors = n_anchors; w->iterations = maximum_iteration;
     w->caps = locamd::WindowCaps{caps->nv_max, caps->nr_max, caps->np_max, caps->ns_max};
+    const bool global_a = locamd::window_lds_bytes(w->caps, false) > 160 * 1024;
     const size_t B = (size_t)batch;
     const size_t na = (size_t)(n_anchors > 0 ? n_anchors : 1);
     hipError_t e;
@@ -83,6 +86,7 @@ int loc_window_create(loc_window** out, int32_t device, int64_t batch, const loc
         (e = alloc((void**)&w->d_sidx, B * caps->ns_max * 4 * sizeof(int32_t))) != hipSuccess ||
         (e = alloc((void**)&w->d_sval, B * caps->ns_max * 48 * sizeof(double))) != hipSuccess ||
         (e = alloc((void**)&w->d_result, B * 8 * sizeof(double))) != hipSuccess ||
+        (global_a && (e = hipMalloc((void**)&w->d_workspace, B * locamd::window_workspace_doubles(w->caps) * sizeof(double))) != hipSuccess) ||
         (e = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&w->ev0)) != hipSuccess || (e = hipEventCreate(&w->ev1)) != hipSuccess ||
         (n_anchors > 0 && (e = hipMemcpy(w->d_anchors, anchors, (size_t)n_anchors * 3 * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess)) {
@@ -141,6 +145,7 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
     locamd::WindowArgs a;
     a.counts = w->d_counts; a.poses = w->d_poses; a.r_idx = w->d_ridx; a.r_val = w->d_rval; a.p_idx = w->d_pidx;
     a.p_val = w->d_pval; a.s_idx = w->d_sidx; a.s_val = w->d_sval; a.anchors = w->d_anchors; a.result = w->d_result;
+    a.workspace = w->d_workspace;
     a.n_anchors = w->n_anchors; a.B = (int)n; a.iterations = w->iterations; a.caps = c;
     LOC_HIP(hipEventRecord(w->ev0, st));
     hipError_t e = locamd::launch_window(a, st);

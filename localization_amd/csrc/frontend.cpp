@@ -120,7 +120,7 @@ struct loc_node {
     bool deferred = false, pending = false;
     loc_window* win = nullptr;            // cached single-instance solver (anchors are part of its device state)
     std::vector<double> win_anchors;
-    loc_window_caps caps{16, 64, 32, 32};
+    loc_window_caps caps{16, 64, 32, 32};  // grown to the window's size in loc_node_create
 
     RobotRing* robot(int id) { for (auto& r : robots) if (r.id == id) return &r; return nullptr; }
     void remove_vertex(int vid) {  // optimizer.removeVertex(v, false): the vertex and every edge touching it
@@ -183,7 +183,7 @@ int pack(const loc_node* n, Packed& P) {
     for (const auto& e : n->se3s) if (active2(e.vi, e.vj)) { touch(e.vi); touch(e.vj); }
     int k = 0;
     for (auto& kv : slot) kv.second = k++;
-    if ((int)slot.size() > c.nv_max) return locamd_fail(LOC_ERR_UNSUPPORTED, "window has more than 16 active poses");
+    if ((int)slot.size() > c.nv_max) return locamd_fail(LOC_ERR_UNSUPPORTED, "window has more active poses than the node was sized for");
     P.slot_vid.clear();
     for (auto& kv : slot) P.slot_vid.push_back(kv.first);
     P.counts.assign(4, 0);
@@ -201,7 +201,7 @@ int pack(const loc_node* n, Packed& P) {
     int nr = 0, np = 0, ns = 0;
     for (const auto& e : n->ranges) {
         if (!active2(e.v0, e.v1)) continue;
-        if (nr >= c.nr_max) return locamd_fail(LOC_ERR_UNSUPPORTED, "more than 64 range edges in the window");
+        if (nr >= c.nr_max) return locamd_fail(LOC_ERR_UNSUPPORTED, "more range edges in the window than the node was sized for");
         int a = e.v0, b = e.v1;
         double off[3] = {e.off[0], e.off[1], e.off[2]};
         if (n->vertices.at(a).fixed) {  // the kernel wants endpoint 0 moving; the residual is symmetric
@@ -216,7 +216,7 @@ int pack(const loc_node* n, Packed& P) {
     }
     for (const auto& e : n->priors) {
         if (n->vertices.at(e.v).fixed) continue;
-        if (np >= c.np_max) return locamd_fail(LOC_ERR_UNSUPPORTED, "more than 32 prior edges in the window");
+        if (np >= c.np_max) return locamd_fail(LOC_ERR_UNSUPPORTED, "more prior edges in the window than the node was sized for");
         P.p_idx[np] = slot.at(e.v);
         double* v = &P.p_val[(size_t)np * 18];
         std::memcpy(v, e.zinv.R, sizeof(double) * 9); std::memcpy(v + 9, e.zinv.t, sizeof(double) * 3);
@@ -226,7 +226,7 @@ int pack(const loc_node* n, Packed& P) {
     for (const auto& e : n->se3s) {
         if (!active2(e.vi, e.vj)) continue;
         if (n->vertices.at(e.vi).fixed || n->vertices.at(e.vj).fixed) return locamd_fail(LOC_ERR_UNSUPPORTED, "SE3 edge to a fixed vertex");
-        if (ns >= c.ns_max) return locamd_fail(LOC_ERR_UNSUPPORTED, "more than 32 SE3 edges in the window");
+        if (ns >= c.ns_max) return locamd_fail(LOC_ERR_UNSUPPORTED, "more SE3 edges in the window than the node was sized for");
         int32_t* ix = &P.s_idx[(size_t)ns * 4];
         ix[0] = slot.at(e.vi); ix[1] = slot.at(e.vj); ix[2] = e.robust ? 1 : 0; ix[3] = 0;
         double* v = &P.s_val[(size_t)ns * 48];
@@ -315,13 +315,22 @@ int loc_node_create(loc_node** out, int32_t device, const loc_node_config* cfg, 
     if (!cfg || n_nodes <= 0 || !ids || !pos_xyz) return locamd_fail(LOC_ERR_INVALID, "node arguments");
     if (cfg->trajectory_length <= 0) return locamd_fail(LOC_ERR_INVALID, "robot/trajectory_length must be set");
     if (loc_device_count() <= 0) return locamd_fail(LOC_ERR_NO_DEVICE, "no HIP device visible: localization_amd has no CPU fallback");
-    if (cfg->trajectory_length > 16 || (cfg->has_relative_range && cfg->trajectory_length * n_nodes > 16))
-        return locamd_fail(LOC_ERR_UNSUPPORTED, "windows of more than 16 moving poses are not supported by this kernel version");
+    if (cfg->trajectory_length > 64 || (cfg->has_relative_range && cfg->trajectory_length * n_nodes > 64))
+        return locamd_fail(LOC_ERR_UNSUPPORTED, "windows of more than 64 moving poses are not supported by this kernel version");
     loc_node* n = new (std::nothrow) loc_node();
     if (!n) return locamd_fail(LOC_ERR_INVALID, "out of host memory");
     n->cfg = *cfg;
     n->device = device;
     n->self_id = ids[n_nodes - 1];  // nodesId.back(), localization.cpp:89
+    {   // capacities for this window: every pose can carry a range + a smoothness edge, one prior, one SE3 edge
+        const int tv = cfg->has_relative_range ? cfg->trajectory_length * n_nodes : cfg->trajectory_length;
+        n->caps.nv_max = tv <= 16 ? 16 : tv;
+        n->caps.nr_max = tv <= 16 ? 64 : 2 * tv + 8;
+        n->caps.np_max = tv <= 16 ? 32 : tv;
+        n->caps.ns_max = tv <= 16 ? 32 : tv;
+        if (loc_window_lds_bytes(&n->caps) > 160 * 1024) { n->caps.np_max = tv / 2; }
+        if (loc_window_lds_bytes(&n->caps) > 160 * 1024) { delete n; return locamd_fail(LOC_ERR_UNSUPPORTED, "window too large for this kernel version"); }
+    }
     for (int i = 0; i < n_nodes; ++i) {  // :92-108 and Robot::init, robot.cpp:31-58
         RobotRing r;
         r.id = ids[i];

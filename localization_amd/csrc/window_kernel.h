@@ -7,10 +7,10 @@ namespace locamd {
 
 // Per-batch capacities; every instance owns fixed-size slices of the arrays below.
 struct WindowCaps {
-    int nv_max;  // moving poses per instance (<= 16)
-    int nr_max;  // range edges (<= 64)
-    int np_max;  // unary SE3 priors (<= 32)
-    int ns_max;  // binary SE3 edges (<= 32)
+    int nv_max;  // moving poses per instance (<= 64; <= 16 keeps the matrix in LDS)
+    int nr_max;  // range edges
+    int np_max;  // unary SE3 priors
+    int ns_max;  // binary SE3 edges   (edge tables and records must fit 160 KiB of LDS)
 };
 
 // Layout of one instance (all arrays are [B][...]):
@@ -32,13 +32,15 @@ struct WindowArgs {
     const int32_t* s_idx; const double* s_val;
     const double* anchors;  // [n_anchors][3] fixed vertices (identity rotation), shared by all instances
     double* result;
+    double* workspace;  // nullptr: H/L in LDS; else [B][(6 nv_max + 1) * ld] doubles in HBM (large windows)
     int n_anchors;
     int B;
     int iterations;
     WindowCaps caps;
 };
 
-size_t window_lds_bytes(const WindowCaps& c);
+size_t window_lds_bytes(const WindowCaps& c, bool global_a);
+size_t window_workspace_doubles(const WindowCaps& c);
 hipError_t launch_window(const WindowArgs& a, hipStream_t stream);
 
 }  // namespace locamd

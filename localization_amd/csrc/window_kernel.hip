@@ -319,7 +319,7 @@ __device__ void compute_skyline(const Lds& L, int lane, int n, int nr, int ns) {
 __device__ void build_system(const WindowArgs& a, const Lds& L, int inst, int lane, int n, int nr, int np, int ns) {
     (void)a; (void)inst;
     const int ld = L.ld;
-    for (int i = lane; i < (n + 1) * ld; i += 64) L.A[i] = 0.0;
+    for (size_t i = lane; i < (size_t)(n + 1) * ld; i += 64) L.A[i] = 0.0;
     for (int i = lane; i < n; i += 64) L.b[i] = 0.0;
     __syncthreads();
     const int r = lane / 6, cc = lane % 6;  // lanes 0..35: one entry of a 6x6 block
@@ -398,65 +398,70 @@ __device__ void build_system(const WindowArgs& a, const Lds& L, int inst, int la
 //     envelope, so the k-loops run over the band only (<= 12 entries for the reference's chain topology).
 //   * Back substitution keeps y in registers and walks the rows of L: no LDS writes, no barriers.
 // L goes to the strict lower triangle of A (H stays in the upper one), pivots to diagL, x to L.x.
+template <int RMAX>  // matrix rows per lane: row i = lane + 64 r, r < RMAX  (n + 1 <= 64 * RMAX)
 __device__ bool factor_and_solve(const Lds& L, int lane, int n, double lambda) {
     const int ld = L.ld;
-    const int i0 = lane, i1 = lane + 64;
-    const bool has1 = i1 <= n;
-    const int f0 = (i0 < n) ? L.first[i0] : 0, f1 = (has1 && i1 < n) ? L.first[i1] : 0;
+    int fi[RMAX];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) { const int i = lane + 64 * r; fi[r] = (i < n) ? L.first[i] : 0; }
     bool ok = true;
     for (int j = 0; j < n; ++j) {
         const int fj = L.first[j];
-        double v0 = 0.0, v1 = 0.0;
-        if (i0 >= j && i0 <= n) {
-            v0 = (i0 == n) ? L.b[j] : L.A[j * ld + i0];
-            if (i0 == j) v0 += lambda;
-            const double* ri = L.A + i0 * ld;
-            const double* rj = L.A + j * ld;
-            int k = fj > f0 ? fj : f0;
-            double s0 = 0.0, s1 = 0.0;
-            for (; k + 1 < j; k += 2) { s0 += ri[k] * rj[k]; s1 += ri[k + 1] * rj[k + 1]; }
-            if (k < j) s0 += ri[k] * rj[k];
-            v0 -= s0 + s1;
+        const double* rj = L.A + (size_t)j * ld;
+        double v[RMAX];
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            const int i = lane + 64 * r;
+            v[r] = 0.0;
+            if (i >= j && i <= n) {
+                double vv = (i == n) ? L.b[j] : rj[i];
+                if (i == j) vv += lambda;
+                const double* ri = L.A + (size_t)i * ld;
+                int k = fj > fi[r] ? fj : fi[r];
+                double s0 = 0.0, s1 = 0.0;
+                for (; k + 1 < j; k += 2) { s0 += ri[k] * rj[k]; s1 += ri[k + 1] * rj[k + 1]; }
+                if (k < j) s0 += ri[k] * rj[k];
+                v[r] = vv - (s0 + s1);
+            }
         }
-        if (has1 && i1 >= j) {
-            v1 = (i1 == n) ? L.b[j] : L.A[j * ld + i1];
-            if (i1 == j) v1 += lambda;
-            const double* ri = L.A + i1 * ld;
-            const double* rj = L.A + j * ld;
-            int k = fj > f1 ? fj : f1;
-            double s0 = 0.0, s1 = 0.0;
-            for (; k + 1 < j; k += 2) { s0 += ri[k] * rj[k]; s1 += ri[k + 1] * rj[k + 1]; }
-            if (k < j) s0 += ri[k] * rj[k];
-            v1 -= s0 + s1;
-        }
-        const double piv = (j < 64) ? __shfl(v0, j) : __shfl(v1, j - 64);
+        double piv = 0.0;
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) { const double c = __shfl(v[r], j & 63); if ((j >> 6) == r) piv = c; }
         if (!(piv > 0.0) || !(piv < DBL_MAX)) { ok = false; break; }
         const double ljj = sqrt(piv), inv = 1.0 / ljj;
-        if (i0 > j && i0 <= n) L.A[i0 * ld + j] = v0 * inv;
-        if (has1 && i1 > j) L.A[i1 * ld + j] = v1 * inv;
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) { const int i = lane + 64 * r; if (i > j && i <= n) L.A[(size_t)i * ld + j] = v[r] * inv; }
         if (lane == 0) L.diagL[j] = ljj;
         __syncthreads();
     }
     if (!ok) return false;
-    // y (= row n of the factor) into registers: lane k holds y_k and y_{k+64}
-    double y0 = (i0 < n) ? L.A[n * ld + i0] : 0.0;
-    double y1 = (i1 < n) ? L.A[n * ld + i1] : 0.0;
+    // y (= row n of the factor) into registers: lane k holds y_k, y_{k+64}, ...
+    double y[RMAX];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) { const int i = lane + 64 * r; y[r] = (i < n) ? L.A[(size_t)n * ld + i] : 0.0; }
     for (int j = n - 1; j >= 0; --j) {
-        const double yj = (j < 64) ? __shfl(y0, j) : __shfl(y1, j - 64);
+        double yj = 0.0;
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) { const double c = __shfl(y[r], j & 63); if ((j >> 6) == r) yj = c; }
         const double xj = yj / L.diagL[j];
         const int fj = L.first[j];
-        const double* rj = L.A + j * ld;
-        if (i0 == j) y0 = xj;
-        else if (i0 < j && i0 >= fj) y0 -= rj[i0] * xj;
-        if (i1 == j) y1 = xj;
-        else if (i1 < j && i1 >= fj) y1 -= rj[i1] * xj;
+        const double* rj = L.A + (size_t)j * ld;
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            const int i = lane + 64 * r;
+            if (i == j) y[r] = xj;
+            else if (i < j && i >= fj) y[r] -= rj[i] * xj;
+        }
     }
-    if (i0 < n) L.x[i0] = y0;
-    if (i1 < n) L.x[i1] = y1;
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) { const int i = lane + 64 * r; if (i < n) L.x[i] = y[r]; }
     __syncthreads();
     return true;
 }
 
+// GLOBAL_A: the (n+1) x ld matrix lives in an HBM workspace slice instead of LDS (windows of more than 16 poses);
+// a workgroup is one wave on one CU, whose L1 is coherent for its own stores after the workgroup barrier.
+template <int RMAX, bool GLOBAL_A>
 __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int inst = blockIdx.x;
@@ -468,7 +473,8 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
     Lds L;
     L.ld = n_max | 1;
     double* p = lds;
-    L.A = p; p += (size_t)(n_max + 1) * L.ld;  // +1 row: the right-hand side rides along as row n
+    if (GLOBAL_A) L.A = a.workspace + (size_t)inst * (size_t)(n_max + 1) * L.ld;
+    else { L.A = p; p += (size_t)(n_max + 1) * L.ld; }  // +1 row: the right-hand side rides along as row n
     L.diagL = p; p += n_max;
     L.b = p; p += n_max;
     L.x = p; p += n_max;
@@ -512,7 +518,7 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
         build_system(a, L, inst, lane, n, nr, np, ns);
         if (it == 0) {  // computeLambdaInit
             double md = 0.0;
-            for (int j = lane; j < n; j += 64) md = fmax(md, fabs(L.A[j * L.ld + j]));
+            for (int j = lane; j < n; j += 64) md = fmax(md, fabs(L.A[(size_t)j * L.ld + j]));
             lambda = tau * wave_max(md);
             ni = 2.0;
         }
@@ -520,7 +526,7 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
         int q = 0;
         do {
             for (int i = lane; i < nv * 12; i += 64) L.bak[i] = L.pose[i];  // push
-            const bool ok2 = factor_and_solve(L, lane, n, lambda);
+            const bool ok2 = factor_and_solve<RMAX>(L, lane, n, lambda);
             if (!ok2) { for (int i = lane; i < n; i += 64) L.x[i] = 0.0; __syncthreads(); }
             // update: X <- X * fromVectorMQT(dx), one pose per lane
             for (int v = lane; v < nv; v += 64) {
@@ -576,28 +582,45 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
 
 }  // namespace
 
-size_t window_lds_bytes(const WindowCaps& c) {
+size_t window_lds_bytes(const WindowCaps& c, bool global_a) {
     const size_t n_max = 6 * (size_t)c.nv_max;
     const size_t ld = n_max | 1;
-    size_t d = (n_max + 1) * ld + 3 * n_max + (n_max + 2) / 2 + (size_t)c.nr_max * 6 + (size_t)c.np_max * 18 + (c.np_max + 1) / 2 +
-               (size_t)c.ns_max * 50 + 2 * (size_t)c.nv_max * 12 + (size_t)c.nr_max * RREC + (size_t)c.np_max * PREC +
-               (size_t)c.ns_max * SREC;
+    size_t d = (global_a ? 0 : (n_max + 1) * ld) + 3 * n_max + (n_max + 2) / 2 + (size_t)c.nr_max * 6 + (size_t)c.np_max * 18 +
+               (c.np_max + 1) / 2 + (size_t)c.ns_max * 50 + 2 * (size_t)c.nv_max * 12 + (size_t)c.nr_max * RREC +
+               (size_t)c.np_max * PREC + (size_t)c.ns_max * SREC;
     return d * sizeof(double);
 }
+size_t window_workspace_doubles(const WindowCaps& c) {
+    const size_t n_max = 6 * (size_t)c.nv_max;
+    return (n_max + 1) * (n_max | 1);
+}
 
-hipError_t launch_window(const WindowArgs& a, hipStream_t stream) {
-    if (a.B <= 0) return hipErrorInvalidValue;
-    const size_t lds = window_lds_bytes(a.caps);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
+template <int RMAX, bool GLOBAL_A>
+static hipError_t launch_window_t(const WindowArgs& a, size_t lds, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&window_lm_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&window_lm_kernel<RMAX, GLOBAL_A>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(window_lm_kernel, dim3((unsigned)a.B), dim3(64), lds, stream, a);
+    hipLaunchKernelGGL((window_lm_kernel<RMAX, GLOBAL_A>), dim3((unsigned)a.B), dim3(64), lds, stream, a);
     return hipGetLastError();
+}
+
+hipError_t launch_window(const WindowArgs& a, hipStream_t stream) {
+    if (a.B <= 0) return hipErrorInvalidValue;
+    const bool global_a = a.workspace != nullptr;
+    const size_t lds = window_lds_bytes(a.caps, global_a);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const int rows = 6 * a.caps.nv_max + 1;
+    if (!global_a) {
+        if (rows > 128) return hipErrorInvalidValue;
+        return launch_window_t<2, false>(a, lds, stream);
+    }
+    if (rows <= 128) return launch_window_t<2, true>(a, lds, stream);
+    if (rows <= 448) return launch_window_t<7, true>(a, lds, stream);
+    return hipErrorInvalidValue;
 }
 
 }  // namespace locamd

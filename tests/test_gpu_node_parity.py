@@ -108,6 +108,24 @@ def test_bag_uwb_imu_replay(gpu, bag):
     node.close()
 
 
+def test_bag_uwb_st_large_window(gpu, bag):
+    """cfg/uwb_st.yaml — the profile launch/localization_bag_play.launch:16 actually pairs with this bag: T = 20
+    (120 unknowns: the matrix moves from LDS to the HBM workspace), 20 iterations, vmax 10, outlier 5 m."""
+    cfg = dict(trajectory_length=20, maximum_velocity=10.0, distance_outlier=5.0, maximum_iteration=20,
+               minimum_optimize_error=10000.0, publish_range=True)
+    node, ora = _pair(bag, cfg)
+    ev = _events(bag, False, 200)
+    g, gp, gc = _replay(bag, node, ev)
+    o, op, oc = _replay(bag, ora, ev)
+    assert len(g) == len(o) == 180 and np.array_equal(gp, op)
+    d = np.abs(g[:, 1:4] - o[:, 1:4]).max(axis=1)
+    # the first 30 solves (ring wrap included) agree to 1e-10; after that the loosely tied 20-pose window
+    # (sigma_v = 10 cm per step) lets last-bit differences grow from solve to solve, as between the oracle's own modes
+    assert d[:30].max() < 1e-6 and np.median(d) < 1e-3, (d[:30].max(), np.median(d))
+    assert np.abs(_rmse(bag, g[gp]) - _rmse(bag, o[op])).max() < 1e-3
+    node.close()
+
+
 def test_pose_twist_lidar_factors_match_oracle(gpu):
     """addPoseEdge (key-frame star), addTwistEdge (chain) and addLidarEdge against the oracle, one solve at a time."""
     import localization_amd as la
@@ -196,5 +214,5 @@ def test_node_errors(gpu, bag):
         node.add_range(200, 177, 1.0, 3.0, 0.055)         # reference: std::map::at throws (localization.cpp:306)
     assert e.value.code == -4
     with pytest.raises(la.LocalizationAmdError):
-        la.LocalizationNode(ids, pos, trajectory_length=20)  # uwb_st.yaml's T = 20: beyond this kernel version
+        la.LocalizationNode(ids, pos, trajectory_length=500)  # uwb_pose.yaml's T = 500: beyond this kernel version
     node.close()

@@ -85,9 +85,11 @@ def _solve_both(gpu, B, T, iters, seed, with_imu, with_pose_edges, lever):
     (8, False, True, False),     # pose factors around key frames (addPoseEdge)
     (16, True, True, True),      # everything at the capacity limit (96 unknowns)
     (1, True, False, True),      # one pose: BASELINE config 3's snapshot shape through the general kernel
+    (24, True, False, True),     # beyond 16 poses the matrix lives in the HBM workspace (two rows per lane)
+    (64, False, True, False),    # BASELINE config 5's shape: 64-pose window, key-frame pose factors (seven rows per lane)
 ])
 def test_window_matches_oracle(gpu, T, with_imu, with_pose_edges, lever):
-    B = 96
+    B = 96 if T <= 16 else 12
     got_t, got_R, res, want_t, want_R, want_chi, want_trials, ms = _solve_both(gpu, B, T, 10, 7 * T + 1, with_imu,
                                                                                with_pose_edges, lever)
     dt = np.abs(got_t - want_t)
