@@ -140,12 +140,15 @@ def main():
     if rank == 0:
         trials_mean = float(out_trials[args.warmup * E:].cpu().numpy().mean())
         err_last = torch.from_numpy(np.sqrt(((out_pos[-1].cpu().numpy() - stream["truth_last"].cpu().numpy()) ** 2).sum(axis=0)))
-        traffic = None
+        # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process); they apply
+        # to the default launch shape only
+        traffic, traffic_src, f64_flop = None, None, None
         prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(prof):
+        if os.path.exists(prof) and (B, E) == (65536, 128) and args.jacobian == "analytic":
             try:
                 with open(prof) as f:
-                    traffic = json.load(f)
+                    pj = json.load(f)
+                traffic, traffic_src, f64_flop = pj["hbm_bytes_per_launch"], pj["source"], pj.get("f64_flop_per_launch")
             except Exception:
                 traffic = None
         res = {
@@ -164,11 +167,17 @@ def main():
             "frac_err_gt_0p5m": float((err_last > 0.5).double().mean().item()),
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS,
-                         "traffic": traffic,
+                         "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_UPDATE * updates_per_launch,
                          "kernel": "snapshot_lm_kernel", "kernel_ms_avg": kern_ms_avg, "launches_timed": n_launch,
                          "algorithmic_bytes_per_update": ALGO_BYTES_PER_UPDATE,
                          "note": "fp64, 10 LM iterations: VALU-bound, see DESIGN.md"},
         }
+        if f64_flop:
+            tf = f64_flop / (kern_ms_avg * 1e-3) / 1e12
+            res["valu_f64"] = {"achieved_tflops": tf, "peak_tflops": 78.6, "frac": tf / 78.6,
+                               "note": "f64 add+mul+2*fma+trans lane-ops per launch (PMC, profiles/) / live kernel time; "
+                                       "the kernel is VALU-issue bound at one wave per SIMD, not HBM bound"}
         if not args.no_cpu_baseline and n_gpus == 1:
             res["cpu_baseline"] = cpu_baseline(ANCHORS_8, dist_t, err_t, stream["init"], min(args.cpu_tags, B),
                                                min(args.cpu_epochs, E * total_steps), out_pos, M)
