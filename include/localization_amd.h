@@ -212,6 +212,40 @@ int loc_node_set_deferred(loc_node* n, int32_t on);
 int32_t loc_node_solve_pending(const loc_node* n);
 int loc_nodes_solve_batch(loc_node** nodes, int32_t n_nodes, loc_node_output* outs);
 
+/* ================================================================================================
+ * Batched fusion snapshot solver — BASELINE config 3 (8 anchors + IMU orientation prior, 6-DoF state).
+ * Per tag and epoch, in the order the reference's callbacks produce it:
+ *   IMU quaternion overwrites the rotation, translation kept                    localization.cpp:505-513
+ *   EdgeSE3Prior on that pose, information diag(0,0,0,1/c0,1/c4,1/c8)            localization.cpp:515-525
+ *   M EdgeSE3Range factors with the antenna lever arm on the tag side            localization.cpp:331-336
+ *   outlier gate on the vertex origins, warm-up as in loc_snapshot_*             localization.cpp:306-313
+ *   Localization::solve() on the 6-DoF vertex, optimizer.chi2()                  localization.cpp:164-170, 197
+ * Device layouts:
+ *   dist, err : float  [K][2][B][4]   as loc_snapshot_* with M <= 8
+ *   imu       : double [K][B][8]      q x y z w, orientation_covariance[0], [4], [8], pad
+ *   pose      : double [7][B]         state t xyz, q xyzw (in: initial, out: last); outputs [K][7][B], chi2 [K][B]
+ * ============================================================================================== */
+typedef struct loc_fusion loc_fusion;
+typedef struct loc_fusion_params {
+    int32_t maximum_iteration;   /* optimizer/maximum_iteration */
+    double distance_outlier;     /* robot/distance_outlier; <= 0 disables */
+    int32_t gate_warmup_epochs;  /* default 1 */
+    double antenna_offset[3];    /* /uwb/antennaOffset of the antenna every range uses (localization.cpp:111-123, 333) */
+    int32_t block_threads;       /* 0 = 256 */
+} loc_fusion_params;
+
+void loc_fusion_default_params(loc_fusion_params* p);
+int loc_fusion_create(loc_fusion** out, int32_t device, int64_t batch, int32_t n_anchors, const double* anchors_xyz_host,
+                      const loc_fusion_params* params);
+int loc_fusion_destroy(loc_fusion* f);
+int loc_fusion_set_poses(loc_fusion* f, const double* pose_soa_host /* [7][B] */);
+int loc_fusion_get_poses(loc_fusion* f, double* pose_soa_host);
+int loc_fusion_solve_device(loc_fusion* f, int32_t epochs, const float* dist_dev, const float* err_dev, const double* imu_dev,
+                            double* out_pose_dev, double* out_chi2_dev, uint8_t* out_trials_dev, void* hip_stream);
+int loc_fusion_solve_host(loc_fusion* f, int32_t epochs, const float* dist_tiles_host, const float* err_tiles_host,
+                          const double* imu_host, double* out_pose_host, double* out_chi2_host, uint8_t* out_trials_host);
+int loc_fusion_last_kernel_ms(loc_fusion* f, double* ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,8 +11,9 @@ from .config import LocalizationConfig, load_config
 from .snapshot import SnapshotSolver, pack_ranges, unpack_ranges
 from .window import WindowBatch, WindowSolver
 from .node import LocalizationNode, solve_batch
+from .fusion import FusionSolver
 
 __all__ = [
     "LocalizationAmdError", "abi_version", "device_count", "lib", "library_path",
-    "LocalizationConfig", "load_config", "SnapshotSolver", "pack_ranges", "unpack_ranges", "WindowBatch", "WindowSolver", "LocalizationNode", "solve_batch",
+    "LocalizationConfig", "load_config", "SnapshotSolver", "pack_ranges", "unpack_ranges", "WindowBatch", "WindowSolver", "LocalizationNode", "solve_batch", "FusionSolver",
 ]

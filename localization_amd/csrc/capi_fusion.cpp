@@ -1,0 +1,180 @@
+// C ABI of the batched fusion snapshot solver (BASELINE config 3). Host side only.
+#include "../../include/localization_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "fusion_kernel.h"
+
+extern int locamd_fail(int code, const char* what);
+extern int locamd_fail_hip(hipError_t e, const char* where);
+#define LOC_HIP(expr)                                              \
+    do {                                                           \
+        hipError_t _e = (expr);                                    \
+        if (_e != hipSuccess) return locamd_fail_hip(_e, #expr);   \
+    } while (0)
+
+struct loc_fusion {
+    int device = 0;
+    long long B = 0;
+    int M = 0;
+    loc_fusion_params prm{};
+    double *d_anchors = nullptr, *d_offset = nullptr, *d_pose = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    long long epochs_done = 0;
+    // staging for the host path
+    float *d_dist = nullptr, *d_err = nullptr;
+    double *d_imu = nullptr, *d_out_pose = nullptr, *d_out_chi2 = nullptr;
+    uint8_t* d_out_trials = nullptr;
+    int staged = 0;
+};
+
+static void fusion_free_staging(loc_fusion* f) {
+    void* p[] = {f->d_dist, f->d_err, f->d_imu, f->d_out_pose, f->d_out_chi2, f->d_out_trials};
+    for (void* x : p) if (x) (void)hipFree(x);
+    f->d_dist = f->d_err = nullptr; f->d_imu = f->d_out_pose = f->d_out_chi2 = nullptr; f->d_out_trials = nullptr; f->staged = 0;
+}
+
+extern "C" {
+
+void loc_fusion_default_params(loc_fusion_params* p) {
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->maximum_iteration = 20; p->distance_outlier = 1.0; p->gate_warmup_epochs = 1;
+}
+
+int loc_fusion_destroy(loc_fusion* f) {
+    if (!f) return LOC_OK;
+    (void)hipSetDevice(f->device);
+    fusion_free_staging(f);
+    if (f->d_anchors) (void)hipFree(f->d_anchors);
+    if (f->d_offset) (void)hipFree(f->d_offset);
+    if (f->d_pose) (void)hipFree(f->d_pose);
+    if (f->ev0) (void)hipEventDestroy(f->ev0);
+    if (f->ev1) (void)hipEventDestroy(f->ev1);
+    if (f->stream) (void)hipStreamDestroy(f->stream);
+    delete f;
+    return LOC_OK;
+}
+
+int loc_fusion_create(loc_fusion** out, int32_t device, int64_t batch, int32_t n_anchors, const double* anchors,
+                      const loc_fusion_params* params) {
+    if (!out) return locamd_fail(LOC_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (batch <= 0 || n_anchors <= 0 || !anchors) return locamd_fail(LOC_ERR_INVALID, "batch/anchors");
+    if (n_anchors > 8) return locamd_fail(LOC_ERR_UNSUPPORTED, "more than 8 anchors per tag in the fusion kernel");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return locamd_fail(LOC_ERR_NO_DEVICE, "no HIP device visible: localization_amd has no CPU fallback");
+    if (device < 0 || device >= ndev) return locamd_fail(LOC_ERR_INVALID, "device index out of range");
+    loc_fusion_params prm;
+    if (params) prm = *params; else loc_fusion_default_params(&prm);
+    if (prm.block_threads == 0) prm.block_threads = 256;
+    if (prm.block_threads % 64 || prm.block_threads > 256 || prm.gate_warmup_epochs < 0) return locamd_fail(LOC_ERR_INVALID, "fusion params");
+    LOC_HIP(hipSetDevice(device));
+    loc_fusion* f = new (std::nothrow) loc_fusion();
+    if (!f) return locamd_fail(LOC_ERR_INVALID, "out of host memory");
+    f->device = device; f->B = batch; f->M = n_anchors; f->prm = prm;
+    double anch[24];
+    std::memset(anch, 0, sizeof(anch));
+    std::memcpy(anch, anchors, sizeof(double) * 3 * (size_t)n_anchors);
+    std::vector<double> pose0((size_t)7 * batch, 0.0);
+    for (long long b = 0; b < batch; ++b) pose0[(size_t)6 * batch + b] = 1.0;  // identity rotation
+    hipError_t e;
+    if ((e = hipMalloc((void**)&f->d_anchors, sizeof(anch))) != hipSuccess ||
+        (e = hipMalloc((void**)&f->d_offset, 3 * sizeof(double))) != hipSuccess ||
+        (e = hipMalloc((void**)&f->d_pose, sizeof(double) * 7 * (size_t)batch)) != hipSuccess ||
+        (e = hipMemcpy(f->d_anchors, anch, sizeof(anch), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(f->d_offset, prm.antenna_offset, 3 * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(f->d_pose, pose0.data(), sizeof(double) * 7 * (size_t)batch, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&f->ev0)) != hipSuccess || (e = hipEventCreate(&f->ev1)) != hipSuccess) {
+        loc_fusion_destroy(f);
+        return locamd_fail_hip(e, "loc_fusion_create");
+    }
+    *out = f;
+    return LOC_OK;
+}
+
+int loc_fusion_set_poses(loc_fusion* f, const double* pose) {
+    if (!f || !pose) return locamd_fail(LOC_ERR_INVALID, "null");
+    LOC_HIP(hipSetDevice(f->device));
+    LOC_HIP(hipMemcpy(f->d_pose, pose, sizeof(double) * 7 * (size_t)f->B, hipMemcpyHostToDevice));
+    f->epochs_done = 0;
+    return LOC_OK;
+}
+int loc_fusion_get_poses(loc_fusion* f, double* pose) {
+    if (!f || !pose) return locamd_fail(LOC_ERR_INVALID, "null");
+    LOC_HIP(hipSetDevice(f->device));
+    LOC_HIP(hipMemcpy(pose, f->d_pose, sizeof(double) * 7 * (size_t)f->B, hipMemcpyDeviceToHost));
+    return LOC_OK;
+}
+
+int loc_fusion_solve_device(loc_fusion* f, int32_t epochs, const float* dist, const float* err, const double* imu,
+                            double* out_pose, double* out_chi2, uint8_t* out_trials, void* hip_stream) {
+    if (!f) return locamd_fail(LOC_ERR_INVALID, "null handle");
+    if (epochs <= 0 || !dist || !err || !imu || !out_pose || !out_chi2) return locamd_fail(LOC_ERR_INVALID, "solve arguments");
+    if (((uintptr_t)dist | (uintptr_t)err | (uintptr_t)imu) & 15u) return locamd_fail(LOC_ERR_INVALID, "inputs must be 16-byte aligned");
+    LOC_HIP(hipSetDevice(f->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : f->stream;
+    locamd::FusionArgs a;
+    a.dist = dist; a.err = err; a.imu = imu; a.pose = f->d_pose; a.out_pose = out_pose; a.out_chi2 = out_chi2; a.out_trials = out_trials;
+    a.anchors = f->d_anchors; a.offset = f->d_offset; a.B = f->B; a.K = epochs; a.iterations = f->prm.maximum_iteration;
+    a.gate = f->prm.distance_outlier;
+    const long long left = (long long)f->prm.gate_warmup_epochs - f->epochs_done;
+    a.gate_from_epoch = left > 0 ? (int)(left > epochs ? epochs : left) : 0;
+    LOC_HIP(hipEventRecord(f->ev0, st));
+    hipError_t e = locamd::launch_fusion(a, f->prm.block_threads, st);
+    if (e != hipSuccess) return locamd_fail_hip(e, "launch_fusion");
+    LOC_HIP(hipEventRecord(f->ev1, st));
+    f->timed = true;
+    f->epochs_done += epochs;
+    return LOC_OK;
+}
+
+int loc_fusion_solve_host(loc_fusion* f, int32_t epochs, const float* dist_h, const float* err_h, const double* imu_h,
+                          double* out_pose_h, double* out_chi2_h, uint8_t* out_trials_h) {
+    if (!f) return locamd_fail(LOC_ERR_INVALID, "null handle");
+    if (epochs <= 0 || !dist_h || !err_h || !imu_h || !out_pose_h || !out_chi2_h) return locamd_fail(LOC_ERR_INVALID, "solve arguments");
+    LOC_HIP(hipSetDevice(f->device));
+    const size_t B = (size_t)f->B, K = (size_t)epochs;
+    const size_t nf = K * 2 * B * 4;
+    if (epochs > f->staged) {
+        fusion_free_staging(f);
+        LOC_HIP(hipMalloc((void**)&f->d_dist, nf * sizeof(float)));
+        LOC_HIP(hipMalloc((void**)&f->d_err, nf * sizeof(float)));
+        LOC_HIP(hipMalloc((void**)&f->d_imu, K * B * 8 * sizeof(double)));
+        LOC_HIP(hipMalloc((void**)&f->d_out_pose, K * 7 * B * sizeof(double)));
+        LOC_HIP(hipMalloc((void**)&f->d_out_chi2, K * B * sizeof(double)));
+        LOC_HIP(hipMalloc((void**)&f->d_out_trials, K * B));
+        f->staged = epochs;
+    }
+    LOC_HIP(hipMemcpyAsync(f->d_dist, dist_h, nf * sizeof(float), hipMemcpyHostToDevice, f->stream));
+    LOC_HIP(hipMemcpyAsync(f->d_err, err_h, nf * sizeof(float), hipMemcpyHostToDevice, f->stream));
+    LOC_HIP(hipMemcpyAsync(f->d_imu, imu_h, K * B * 8 * sizeof(double), hipMemcpyHostToDevice, f->stream));
+    int rc = loc_fusion_solve_device(f, epochs, f->d_dist, f->d_err, f->d_imu, f->d_out_pose, f->d_out_chi2, f->d_out_trials, f->stream);
+    if (rc != LOC_OK) return rc;
+    LOC_HIP(hipMemcpyAsync(out_pose_h, f->d_out_pose, K * 7 * B * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+    LOC_HIP(hipMemcpyAsync(out_chi2_h, f->d_out_chi2, K * B * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+    if (out_trials_h) LOC_HIP(hipMemcpyAsync(out_trials_h, f->d_out_trials, K * B, hipMemcpyDeviceToHost, f->stream));
+    LOC_HIP(hipStreamSynchronize(f->stream));
+    return LOC_OK;
+}
+
+int loc_fusion_last_kernel_ms(loc_fusion* f, double* ms) {
+    if (!f || !ms) return locamd_fail(LOC_ERR_INVALID, "null");
+    if (!f->timed) { *ms = 0; return LOC_OK; }
+    LOC_HIP(hipSetDevice(f->device));
+    LOC_HIP(hipEventSynchronize(f->ev1));
+    float t = 0;
+    LOC_HIP(hipEventElapsedTime(&t, f->ev0, f->ev1));
+    *ms = t;
+    return LOC_OK;
+}
+
+}  // extern "C"

@@ -35,6 +35,7 @@
 //   * Every workgroup does identical, independent work on a private slice of B, and the only shared data is the
 //     192-byte anchor table, so there is no L2 reuse to steer: blockIdx -> XCD mapping is left to the dispatcher.
 #include "snapshot_kernel.h"
+#include "device_math.h"
 
 #include <float.h>
 #include <math.h>
@@ -68,39 +69,6 @@ __device__ __forceinline__ double group_prod(double v) {
     if constexpr (LPI >= 4) v *= dpp_move<DPP_QUAD_XOR2>(v);
     if constexpr (LPI >= 8) v *= dpp_move<DPP_ROW_HALF_MIRROR>(v);
     return v;
-}
-
-// ---- f64 reciprocal / sqrt from the hardware seeds + FMA refinement ------------------------------------
-// Accuracies measured on MI355X with tools/math_probe.hip (profiles/r01_math_probe.txt); operands here are ranges,
-// 1 + chi and pivots: normal, positive, so no div_scale / div_fixup range handling is needed.
-// v_rcp_f64 seed (4.6e-8) + two Newton steps: 1.1e-16 relative (as good as an IEEE divide).
-__device__ __forceinline__ double fast_rcp(double d) {
-    double r = __builtin_amdgcn_rcp(d);
-    double e = __builtin_fma(-d, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-d, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    return r;
-}
-// one Newton step: 2.2e-15 relative — used for the robust weight rho' = 1/(1 + chi), which scales H and b alike.
-__device__ __forceinline__ double fast_rcp_1nr(double d) {
-    double r = __builtin_amdgcn_rcp(d);
-    const double e = __builtin_fma(-d, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    return r;
-}
-// n = sqrt(x) to 1.1e-16 relative (identical error bound to the builtin sqrt: v_rsq_f64 seed, one Goldschmidt step, one
-// residual correction) and inv = 1/sqrt(x) to 4.2e-15 (only scales the unit vector of the Jacobian).
-__device__ __forceinline__ void sqrt_and_rsqrt(double x, double& n, double& inv) {
-    const double y = __builtin_amdgcn_rsq(x);
-    double g = x * y;
-    double h = 0.5 * y;
-    const double r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);
-    h = __builtin_fma(h, r, h);
-    const double dd = __builtin_fma(-g, g, x);
-    n = __builtin_fma(dd, h, g);
-    inv = h + h;
 }
 
 struct System {

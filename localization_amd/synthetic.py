@@ -71,3 +71,35 @@ def make_snapshot_stream_torch(B, K, seed, device, anchors=ANCHORS_8, sigma=0.05
         err_tiles[k] = e.view(M4, 4, B).permute(0, 2, 1)
     init = np.repeat(np.asarray(anchors).mean(axis=0)[:, None], B, axis=1).astype(np.float64)
     return dict(dist_tiles=dist_tiles.contiguous(), err_tiles=err_tiles.contiguous(), init=init, truth_last=p)
+
+
+def make_fusion_stream(B, K, seed=0, anchors=ANCHORS_8, offset=(0.1, 0.0, -0.05), sigma=0.05, err=0.055, outlier_frac=0.01,
+                       vmax=3.0, dt=1.0 / 32.0, imu_cov=4.592449e-06):
+    """BASELINE config 3 stream: as make_snapshot_stream plus a true attitude random walk, the antenna
+    lever arm on the tag side, and IMU quaternions = truth x small-angle N(0, imu_cov) noise; cfg/uwb_imu.yaml values
+    (vmax = 3 m/s).  Returns dict(anchors, offset, dist[K,M,B] f32, err f32, imu[K,B,8] f64, init[7,B], truth_t[K,3,B],
+    truth_q[K,B,4] xyzw)."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(seed)
+    off = np.asarray(offset, dtype=np.float64)
+    p = rng.uniform(LO[:, None], HI[:, None], size=(3, B))
+    rv = rng.normal(0, 0.3, size=(B, 3))
+    truth_t = np.empty((K, 3, B)); truth_q = np.empty((K, B, 4)); imu = np.zeros((K, B, 8))
+    dist = np.empty((K, anchors.shape[0], B), dtype=np.float32)
+    for k in range(K):
+        step = rng.normal(size=(3, B))
+        step *= (rng.uniform(0, vmax * dt, size=(1, B)) / np.maximum(np.linalg.norm(step, axis=0, keepdims=True), 1e-12))
+        p = np.clip(p + step, LO[:, None], HI[:, None])
+        rv = rv + rng.normal(0, 0.02, size=(B, 3))
+        Rk = Rotation.from_rotvec(rv)
+        truth_t[k] = p; truth_q[k] = Rk.as_quat()
+        ant = p.T + Rk.apply(off)                                           # [B,3]
+        d = np.sqrt(((ant[None, :, :] - anchors[:, None, :]) ** 2).sum(axis=2))  # [M,B]
+        d = d + rng.normal(0, sigma, size=d.shape)
+        d = d + (rng.random(d.shape) < outlier_frac) * rng.uniform(1.0, 3.0, size=d.shape)
+        dist[k] = d.astype(np.float32)
+        qi = (Rk * Rotation.from_rotvec(rng.normal(0, np.sqrt(imu_cov), size=(B, 3)))).as_quat()
+        imu[k, :, :4] = qi; imu[k, :, 4:7] = imu_cov
+    errs = np.full(dist.shape, err, dtype=np.float32)
+    init = np.zeros((7, B)); init[:3] = np.asarray(anchors).mean(axis=0)[:, None]; init[6] = 1.0
+    return dict(anchors=np.array(anchors), offset=off, dist=dist, err=errs, imu=imu, init=init, truth_t=truth_t, truth_q=truth_q)

@@ -756,3 +756,62 @@ int og_snapshot_batch(int B, int K, int M, const double* anchors, const float* d
     }
     return 0;
 }
+
+/* tf::poseEigenToMsg: Quaterniond(R), flipped to w >= 0; out x y z w */
+static void R_to_qxyzw(const double* R, double* q) {
+    double w[4];
+    og_R_to_quat(R, w);
+    double s = w[0] < 0 ? -1.0 : 1.0;
+    q[0] = s * w[1]; q[1] = s * w[2]; q[2] = s * w[3]; q[3] = s * w[0];
+}
+
+int og_fusion_batch(int B, int K, int M, const double* anchors, const double* off, const float* dist, const float* err,
+                    const double* imu, double* pose, double* out_pose, double* out_chi2, unsigned char* out_trials,
+                    int iterations, double gate, int gate_from_epoch, int jac_mode) {
+    const double I3[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+    for (int b = 0; b < B; ++b) {
+        double t[3] = { pose[0 * (size_t)B + b], pose[1 * (size_t)B + b], pose[2 * (size_t)B + b] };
+        double q0[4] = { pose[6 * (size_t)B + b], pose[3 * (size_t)B + b], pose[4 * (size_t)B + b], pose[5 * (size_t)B + b] };
+        double R[9];
+        og_quat_to_R(q0, R);
+        for (int k = 0; k < K; ++k) {
+            const double* im = imu + ((size_t)k * B + b) * 8;
+            double qi[4] = { im[3], im[0], im[1], im[2] };
+            og_quat_to_R(qi, R); /* rotation overwritten, translation kept */
+            og_graph* g = og_create();
+            og_add_vertex(g, 1000, R, t, 0);
+            double info[36];
+            memset(info, 0, sizeof(info));
+            info[3 * 6 + 3] = 1.0 / im[4]; info[4 * 6 + 4] = 1.0 / im[5]; info[5 * 6 + 5] = 1.0 / im[6];
+            og_add_prior_edge(g, 1000, R, t, info);
+            for (int m = 0; m < M; ++m) {
+                const double* a = anchors + 3 * m;
+                og_add_vertex(g, m, I3, a, 1);
+                size_t o = ((size_t)k * M + m) * (size_t)B + b;
+                double d = (double)dist[o], e = (double)err[o];
+                double dhat = sqrt((t[0] - a[0]) * (t[0] - a[0]) + (t[1] - a[1]) * (t[1] - a[1]) + (t[2] - a[2]) * (t[2] - a[2]));
+                if (gate > 0 && k >= gate_from_epoch && fabs(dhat - d) > gate) continue;
+                if (!(e > 0) || !isfinite(e) || !isfinite(d)) continue;
+                og_add_range_edge(g, 1000, m, d, 1.0 / pow(e, 2), off, NULL, 1);
+            }
+            og_stats st;
+            memset(&st, 0, sizeof(st));
+            og_optimize(g, iterations, jac_mode, &st);
+            double chi = og_chi2(g);
+            og_get_estimate(g, 1000, R, t);
+            og_destroy(g);
+            double q[4];
+            R_to_qxyzw(R, q);
+            double* op = out_pose + (size_t)k * 7 * B;
+            op[0 * (size_t)B + b] = t[0]; op[1 * (size_t)B + b] = t[1]; op[2 * (size_t)B + b] = t[2];
+            op[3 * (size_t)B + b] = q[0]; op[4 * (size_t)B + b] = q[1]; op[5 * (size_t)B + b] = q[2]; op[6 * (size_t)B + b] = q[3];
+            out_chi2[(size_t)k * B + b] = chi;
+            if (out_trials) out_trials[(size_t)k * B + b] = (unsigned char)(st.lm_trials > 255 ? 255 : st.lm_trials);
+        }
+        double q[4];
+        R_to_qxyzw(R, q);
+        pose[0 * (size_t)B + b] = t[0]; pose[1 * (size_t)B + b] = t[1]; pose[2 * (size_t)B + b] = t[2];
+        pose[3 * (size_t)B + b] = q[0]; pose[4 * (size_t)B + b] = q[1]; pose[5 * (size_t)B + b] = q[2]; pose[6 * (size_t)B + b] = q[3];
+    }
+    return 0;
+}

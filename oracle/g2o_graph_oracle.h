@@ -84,6 +84,15 @@ int og_snapshot_batch(int B, int K, int M, const double* anchors /*[M][3]*/,
                       double* out_pos, double* out_chi2, unsigned char* out_trials,
                       int iterations, double gate, int gate_from_epoch, int jac_mode);
 
+/* BASELINE config 3 through the general graph: per tag and epoch one 6-DoF vertex whose rotation is overwritten by the
+ * IMU quaternion (localization.cpp:505-513), a rotation-only EdgeSE3Prior with information 1/cov (:515-525), M range
+ * edges with the antenna lever arm on endpoint 0 (:331-336), the outlier gate on vertex origins (:306-313).
+ * Layouts: dist/err [K][M][B] float; imu [K][B][8] double (q xyzw, cov c0 c4 c8, pad); pose [7][B] double
+ * (t xyz, q xyzw; in: prior, out: last); out_pose [K][7][B]; out_chi2 [K][B]. */
+int og_fusion_batch(int B, int K, int M, const double* anchors, const double* offset_xyz, const float* dist,
+                    const float* err, const double* imu, double* pose, double* out_pose, double* out_chi2,
+                    unsigned char* out_trials, int iterations, double gate, int gate_from_epoch, int jac_mode);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,8 @@ def lib():
         L.og_cauchy_rho.restype = C.c_double
         L.og_snapshot_batch.argtypes = [C.c_int, C.c_int, C.c_int, dp, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                         dp, dp, dp, C.POINTER(C.c_ubyte), C.c_int, C.c_double, C.c_int, C.c_int]
+        L.og_fusion_batch.argtypes = [C.c_int, C.c_int, C.c_int, dp, dp, C.POINTER(C.c_float), C.POINTER(C.c_float), dp, dp, dp, dp,
+                                      C.POINTER(C.c_ubyte), C.c_int, C.c_double, C.c_int, C.c_int]
         L.lo_create.restype = C.c_void_p
         L.lo_create.argtypes = [C.POINTER(LoConfig), C.c_int, C.POINTER(C.c_int), dp, C.c_int, dp]
         L.lo_destroy.argtypes = [C.c_void_p]
@@ -170,6 +172,24 @@ def snapshot_batch(anchors, dist, err, pos, iterations=10, gate=1.0, jac_mode=JA
                                  trials.ctypes.data_as(C.POINTER(C.c_ubyte)), iterations, float(gate), int(gate_from_epoch), jac_mode)
     assert rc == 0
     return out_pos, out_chi2, trials, p
+
+
+def fusion_batch(anchors, offset, dist, err, imu, pose, iterations=10, gate=3.0, jac_mode=JAC_NUMERIC_G2O, gate_from_epoch=1):
+    """BASELINE config 3. dist/err [K][M][B] f32, imu [K][B][8] f64 (q xyzw, cov diag, pad), pose [7][B] (t, q xyzw).
+    Returns (out_pose[K,7,B], chi2[K,B], trials[K,B], pose_last[7,B])."""
+    anchors = np.ascontiguousarray(anchors, dtype=np.float64); offset = np.ascontiguousarray(offset, dtype=np.float64)
+    dist = np.ascontiguousarray(dist, dtype=np.float32); err = np.ascontiguousarray(err, dtype=np.float32)
+    imu = np.ascontiguousarray(imu, dtype=np.float64)
+    K, M, B = dist.shape
+    assert imu.shape == (K, B, 8) and anchors.shape == (M, 3)
+    p = np.array(pose, dtype=np.float64, order="C", copy=True)
+    assert p.shape == (7, B)
+    out_pose = np.zeros((K, 7, B)); out_chi2 = np.zeros((K, B)); trials = np.zeros((K, B), dtype=np.uint8)
+    rc = lib().og_fusion_batch(B, K, M, _dp(anchors), _dp(offset), dist.ctypes.data_as(C.POINTER(C.c_float)),
+                               err.ctypes.data_as(C.POINTER(C.c_float)), _dp(imu), _dp(p), _dp(out_pose), _dp(out_chi2),
+                               trials.ctypes.data_as(C.POINTER(C.c_ubyte)), iterations, float(gate), int(gate_from_epoch), jac_mode)
+    assert rc == 0
+    return out_pose, out_chi2, trials, p
 
 
 class LocalizationOracle:
