@@ -145,6 +145,8 @@ typedef struct loc_window_caps { int32_t nv_max, nr_max, np_max, ns_max; } loc_w
 int loc_window_create(loc_window** out, int32_t device, int64_t batch, const loc_window_caps* caps,
                       int32_t n_anchors, const double* anchors_xyz_host, int32_t maximum_iteration);
 int loc_window_destroy(loc_window* w);
+/* replace the fixed-vertex table (re-uploads; grows the device buffer when needed) */
+int loc_window_set_anchors(loc_window* w, int32_t n_anchors, const double* anchors_xyz_host);
 size_t loc_window_lds_bytes(const loc_window_caps* caps);
 /* Synchronous: stages the B instances over PCIe, runs one launch, copies poses and results back. */
 int loc_window_solve_host(loc_window* w, int64_t n_instances, const int32_t* counts, double* poses,

@@ -12,6 +12,7 @@ from .snapshot import SnapshotSolver, pack_ranges, unpack_ranges
 from .window import WindowBatch, WindowSolver
 from .node import LocalizationNode, solve_batch
 from .fusion import FusionSolver
+from . import ate, bag
 
 __all__ = [
     "LocalizationAmdError", "abi_version", "device_count", "lib", "library_path",

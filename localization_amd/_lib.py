@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = [
     "loc_snapshot_epochs_done", "loc_snapshot_set_epochs_done",
     "loc_snapshot_pack_ranges_host", "loc_snapshot_solve_device", "loc_snapshot_solve_host",
     "loc_snapshot_timing_begin", "loc_snapshot_timing_end",
-    "loc_window_create", "loc_window_destroy", "loc_window_lds_bytes", "loc_window_solve_host",
+    "loc_window_create", "loc_window_destroy", "loc_window_set_anchors", "loc_window_lds_bytes", "loc_window_solve_host",
     "loc_window_last_kernel_ms",
     "loc_node_default_config", "loc_node_create", "loc_node_destroy", "loc_node_add_range", "loc_node_add_imu",
     "loc_node_add_pose", "loc_node_add_twist", "loc_node_add_lidar", "loc_node_solve", "loc_node_get_path",
@@ -80,6 +80,7 @@ def lib():
     ip = C.POINTER(C.c_int32)
     L.loc_window_create.argtypes = [C.POINTER(vp), C.c_int32, C.c_int64, vp, C.c_int32, dp, C.c_int32]
     L.loc_window_destroy.argtypes = [vp]
+    L.loc_window_set_anchors.argtypes = [vp, C.c_int32, dp]
     L.loc_window_lds_bytes.argtypes = [vp]; L.loc_window_lds_bytes.restype = C.c_size_t
     L.loc_window_solve_host.argtypes = [vp, C.c_int64, ip, dp, ip, dp, ip, dp, ip, dp, dp]
     L.loc_window_last_kernel_ms.argtypes = [vp, dp]

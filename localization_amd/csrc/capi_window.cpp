@@ -21,7 +21,7 @@ struct loc_window {
     int device = 0;
     long long B = 0;
     locamd::WindowCaps caps{};
-    int n_anchors = 0;
+    int n_anchors = 0, anchors_cap = 0;
     int iterations = 10;
     double* d_anchors = nullptr;
     int32_t *d_counts = nullptr, *d_ridx = nullptr, *d_pidx = nullptr, *d_sidx = nullptr;
@@ -69,7 +69,7 @@ int loc_window_create(loc_window** out, int32_t device, int64_t batch, const loc
     LOC_HIP(hipSetDevice(device));
     loc_window* w = new (std::nothrow) loc_window();
     if (!w) return locamd_fail(LOC_ERR_INVALID, "out of host memory");
-    w->device = device; w->B = batch; w->n_anchors = n_anchors; w->iterations = maximum_iteration;
+    w->device = device; w->B = batch; w->n_anchors = n_anchors; w->anchors_cap = n_anchors > 0 ? n_anchors : 1; w->iterations = maximum_iteration;
     w->caps = locamd::WindowCaps{caps->nv_max, caps->nr_max, caps->np_max, caps->ns_max};
     const bool global_a = locamd::window_lds_bytes(w->caps, false) > 160 * 1024;
     const size_t B = (size_t)batch;
@@ -94,6 +94,21 @@ int loc_window_create(loc_window** out, int32_t device, int64_t batch, const loc
         return locamd_fail_hip(e, "loc_window_create");
     }
     *out = w;
+    return LOC_OK;
+}
+
+int loc_window_set_anchors(loc_window* w, int32_t n_anchors, const double* anchors) {
+    if (!w || n_anchors < 0 || (n_anchors > 0 && !anchors)) return locamd_fail(LOC_ERR_INVALID, "set_anchors");
+    LOC_HIP(hipSetDevice(w->device));
+    if (n_anchors > w->anchors_cap) {
+        double* p = nullptr;
+        LOC_HIP(hipMalloc((void**)&p, (size_t)n_anchors * 3 * sizeof(double)));
+        if (w->d_anchors) (void)hipFree(w->d_anchors);
+        w->d_anchors = p;
+        w->anchors_cap = n_anchors;
+    }
+    if (n_anchors > 0) LOC_HIP(hipMemcpy(w->d_anchors, anchors, (size_t)n_anchors * 3 * sizeof(double), hipMemcpyHostToDevice));
+    w->n_anchors = n_anchors;
     return LOC_OK;
 }
 

@@ -557,12 +557,21 @@ int loc_nodes_solve_batch(loc_node** nodes, int32_t n_nodes, loc_node_output* ou
         std::copy(p.s_val.begin(), p.s_val.end(), s_val.begin() + b * caps.ns_max * 48);
     }
     loc_node* first = nodes[todo[0]];
-    loc_window* w = nullptr;
-    int rc = loc_window_create(&w, first->device, (int64_t)B, &caps, (int32_t)(anchors.size() / 3), anchors.data(), first->cfg.maximum_iteration);
-    if (rc != LOC_OK) return rc;
-    rc = loc_window_solve_host(w, (int64_t)B, counts.data(), poses.data(), r_idx.data(), r_val.data(), p_idx.data(), p_val.data(),
-                               s_idx.data(), s_val.data(), res.data());
-    loc_window_destroy(w);
+    // one cached batch solver per thread: re-created only when the capacities, the device or the batch size grow
+    struct BatchCache { loc_window* w = nullptr; loc_window_caps caps{0, 0, 0, 0}; int device = -1; size_t B = 0; int iters = 0; };
+    static thread_local BatchCache cache;
+    if (!cache.w || cache.device != first->device || cache.B < B || cache.iters != first->cfg.maximum_iteration ||
+        std::memcmp(&cache.caps, &caps, sizeof(caps)) != 0) {
+        if (cache.w) { loc_window_destroy(cache.w); cache.w = nullptr; }
+        int rc0 = loc_window_create(&cache.w, first->device, (int64_t)B, &caps, (int32_t)(anchors.size() / 3), anchors.data(), first->cfg.maximum_iteration);
+        if (rc0 != LOC_OK) return rc0;
+        cache.caps = caps; cache.device = first->device; cache.B = B; cache.iters = first->cfg.maximum_iteration;
+    } else {
+        int rc0 = loc_window_set_anchors(cache.w, (int32_t)(anchors.size() / 3), anchors.data());
+        if (rc0 != LOC_OK) return rc0;
+    }
+    int rc = loc_window_solve_host(cache.w, (int64_t)B, counts.data(), poses.data(), r_idx.data(), r_val.data(), p_idx.data(), p_val.data(),
+                                   s_idx.data(), s_val.data(), res.data());
     if (rc != LOC_OK) return rc;
     for (size_t b = 0; b < B; ++b) {
         loc_node* n = nodes[todo[b]];

@@ -1,0 +1,102 @@
+"""§8(f) "next" rows on the CPU: the bag reader in front of the path, the ATE evaluation behind it, and the C++ shim header.
+No solver runs here (the product has no CPU path)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from localization_amd import ate, bag
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+REF_BAG = "/root/reference/bag/data_example.bag"
+
+
+def test_associate_and_horn_alignment_known_answers():
+    ta = np.arange(0, 10, 0.1)
+    tb = ta + 0.004                       # inside the 20 ms window
+    pairs = ate.associate(ta, tb)
+    assert pairs == [(i, i) for i in range(len(ta))]
+    assert ate.associate(ta, ta + 0.05) == []                    # 50 ms from every stamp: nothing within max_difference
+    assert ate.associate([0.0, 1.0], [0.001, 0.002]) == [(0, 0)]  # one-to-one, best first
+    rng = np.random.default_rng(0)
+    P = rng.normal(size=(3, 200))
+    th = 0.7
+    R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+    t = np.array([[1.0], [-2.0], [0.5]])
+    Q = R @ P + t
+    R2, t2, err = ate.horn_align(P, Q)
+    assert np.allclose(R2, R, atol=1e-12) and np.allclose(t2, t, atol=1e-12) and err.max() < 1e-12
+    est = np.column_stack([ta, P[:, :100].T]); tru = np.column_stack([tb, (R @ P[:, :100] + t).T])
+    r = ate.evaluate_ate(est, tru)
+    assert r["pairs"] == 100 and r["rmse"] < 1e-12
+    r2 = ate.evaluate_ate(est, tru, align=False)
+    assert r2["rmse"] > 1.0
+
+
+def test_tum_round_trip(tmp_path):
+    p = np.array([[1491129341.123456789, 0.1, -0.2, 1.1, 0.0, 0.0, 0.3826834, 0.9238795]])
+    f = tmp_path / "traj.txt"
+    ate.write_tum(str(f), p)
+    ate.write_tum(str(f), p + 1)
+    back = ate.read_tum(str(f))
+    assert back.shape == (2, 8) and abs(back[0, 0] - p[0, 0]) < 1e-6 and np.allclose(back[0, 1:], p[0, 1:], atol=1e-6)
+
+
+def test_ate_of_vicon_against_itself_and_fixture_sanity():
+    z = np.load(os.path.join(GOLD, "bag_example.npz"))
+    truth = np.column_stack([z["vicon_stamp"], z["vicon_pos"], z["vicon_q_xyzw"]])
+    r = ate.evaluate_ate(truth[::2], truth)
+    assert r["rmse"] < 1e-12 and r["pairs"] == len(truth[::2])
+    noisy = truth.copy(); noisy[:, 1:4] += np.random.default_rng(1).normal(0, 0.05, (len(truth), 3))
+    r = ate.evaluate_ate(noisy, truth)
+    assert 0.07 < r["rmse"] < 0.1                                # sqrt(3) * 0.05
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BAG), reason="the reference tree exists only in the build container")
+def test_bag_reader_reproduces_the_committed_fixture():
+    z = np.load(os.path.join(GOLD, "bag_example.npz"))
+    conns, msgs = bag.read_bag(REF_BAG)
+    types = {c.topic: c.msg_type for c in conns.values()}
+    assert types["/uwb_endorange_info"] == "uwb_driver/UwbRange" and types["/imu/data"] == "sensor_msgs/Imu"
+    assert [c.md5sum for c in conns.values() if c.msg_type == "uwb_driver/UwbRange"] == ["1b3efd633e416bfcfbaaf891dd23ac23"]
+    ev = list(bag.events(REF_BAG))
+    rng = [e for e in ev if e["kind"] == "range"]; imu = [e for e in ev if e["kind"] == "imu"]; tru = [e for e in ev if e["kind"] == "truth"]
+    assert (len(rng), len(imu), len(tru)) == (1444, 4514, 1965)
+    assert np.array_equal(np.array([e["distance"] for e in rng], dtype=np.float32), z["uwb_distance"][np.argsort(z["uwb_rectime"], kind="stable")])
+    assert all(a["record_time"] <= b["record_time"] for a, b in zip(ev, ev[1:]))
+    assert rng[0]["frame_id"] == "uwb" and imu[0]["frame_id"] == "imu_link" and rng[0]["antenna"] == 1
+
+
+def test_bz2_chunks_are_read(tmp_path):
+    """Synthesise a one-chunk bag with a bz2-compressed chunk holding one connection and one Imu message."""
+    import bz2
+    import struct
+
+    def rec(hdr, data):
+        h = b"".join(struct.pack("<I", len(k) + 1 + len(v)) + k + b"=" + v for k, v in hdr.items())
+        return struct.pack("<I", len(h)) + h + struct.pack("<I", len(data)) + data
+
+    conn_data = b"".join(struct.pack("<I", len(k) + 1 + len(v)) + k + b"=" + v for k, v in
+                         {b"topic": b"/imu/data", b"type": b"sensor_msgs/Imu", b"md5sum": b"x", b"message_definition": b"Header header"}.items())
+    msg = struct.pack("<III", 7, 100, 500000000) + struct.pack("<I", 8) + b"imu_link" + struct.pack("<4d", 0, 0, 0, 1) + struct.pack("<9d", *([1e-6] * 9)) + bytes(8 * 24)
+    inner = rec({b"op": b"\x07", b"conn": struct.pack("<I", 0), b"topic": b"/imu/data"}, conn_data) + \
+        rec({b"op": b"\x02", b"conn": struct.pack("<I", 0), b"time": struct.pack("<II", 100, 600000000)}, msg)
+    chunk = rec({b"op": b"\x05", b"compression": b"bz2", b"size": struct.pack("<I", len(inner))}, bz2.compress(inner))
+    path = tmp_path / "one.bag"
+    path.write_bytes(b"#ROSBAG V2.0\n" + rec({b"op": b"\x03", b"index_pos": struct.pack("<Q", 0), b"conn_count": struct.pack("<I", 1),
+                                              b"chunk_count": struct.pack("<I", 1)}, bytes(16)) + chunk)
+    ev = list(bag.events(str(path)))
+    assert len(ev) == 1 and ev[0]["kind"] == "imu" and ev[0]["stamp"] == 100.5 and ev[0]["q_xyzw"] == (0, 0, 0, 1)
+    assert ev[0]["record_time"] == pytest.approx(100.6)
+
+
+def test_shim_header_compiles_standalone(tmp_path):
+    src = tmp_path / "shim_use.cpp"
+    src.write_text('#include "localization_amd_shim.hpp"\n'
+                   "int use(localization_amd::Localization& l) {\n"
+                   '  bool s = l.addRangeEdge(200, 100, 1.0, 3.0f, 0.055f, 1, "uwb");\n'
+                   '  s |= l.addImuEdge(1.0, {{0, 0, 0, 1}}, {{1e-6, 0, 0, 0, 1e-6, 0, 0, 0, 1e-6}}, "imu_link");\n'
+                   "  return (int)s + (int)l.optimizedPath().size() + (int)l.published();\n}\n")
+    subprocess.check_call(["g++", "-std=c++14", "-fsyntax-only", "-Wall", "-I", os.path.join(ROOT, "include"), str(src)])
