@@ -25,6 +25,7 @@
 // This is the latency-oriented first version of the window path (one 64-lane wave per 60..96-unknown system);
 // DESIGN.md lists what the throughput version changes.
 #include "window_kernel.h"
+#include "device_math.h"
 
 #include <float.h>
 #include <math.h>
@@ -37,15 +38,36 @@ constexpr int RREC = 16;   // J0[6] J1[6] wr omega_r chi rho0
 constexpr int PREC = 56;   // J[36] W[6] omega_r[6] (+pad)
 constexpr int SREC = 152;  // J0[36] J1[36] WJ0[36] WJ1[36] omega_r[6] (+pad)
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
-    return v;
+// Wave-wide reductions on the VALU (DPP row shifts + row broadcasts, then one readlane): every lane gets the same
+// bits, no LDS crossbar round trips (a __shfl_xor butterfly on doubles costs ~6 dependent ds_bpermute pairs).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_or_zero(double v, double identity) {
+    const int ilo = __double2loint(identity), ihi = __double2hiint(identity);
+    const int lo = __builtin_amdgcn_update_dpp(ilo, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(ihi, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v = fmax(v, __shfl_xor(v, m));
-    return v;
+__device__ __forceinline__ double read_lane63(double v) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    v += dpp_or_zero<0x111, 0xF>(v, 0.0);  // row_shr:1
+    v += dpp_or_zero<0x112, 0xF>(v, 0.0);  // row_shr:2
+    v += dpp_or_zero<0x114, 0xF>(v, 0.0);  // row_shr:4
+    v += dpp_or_zero<0x118, 0xF>(v, 0.0);  // row_shr:8  -> lane 15 of each row holds the row sum
+    v += dpp_or_zero<0x142, 0xA>(v, 0.0);  // row_bcast:15 into rows 1 and 3
+    v += dpp_or_zero<0x143, 0xC>(v, 0.0);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    return read_lane63(v);
+}
+__device__ __forceinline__ double wave_max(double v) {  // for non-negative inputs (identity 0)
+    v = fmax(v, dpp_or_zero<0x111, 0xF>(v, 0.0));
+    v = fmax(v, dpp_or_zero<0x112, 0xF>(v, 0.0));
+    v = fmax(v, dpp_or_zero<0x114, 0xF>(v, 0.0));
+    v = fmax(v, dpp_or_zero<0x118, 0xF>(v, 0.0));
+    v = fmax(v, dpp_or_zero<0x142, 0xA>(v, 0.0));
+    v = fmax(v, dpp_or_zero<0x143, 0xC>(v, 0.0));
+    return read_lane63(v);
 }
 
 // ---- small SE3 algebra (row-major 3x3) -------------------------------------------------------------------------
@@ -69,27 +91,29 @@ __device__ __forceinline__ void mat_tvec(const double* A, const double* v, doubl
 #pragma unroll
     for (int i = 0; i < 3; ++i) o[i] = A[0 * 3 + i] * v[0] + A[1 * 3 + i] * v[1] + A[2 * 3 + i] * v[2];
 }
-// Eigen::Quaternion(Matrix3) — q = (w, x, y, z)
-__device__ void mat_to_quat(const double* R, double* q) {
+// Eigen::Quaternion(Matrix3) — q = (w, x, y, z).  Scalars, not an array: the optimiser otherwise merges the branches
+// into a computed index and the array lands in scratch memory.
+__device__ __forceinline__ void mat_to_quat(const double* R, double* q) {
+    double qw, qx, qy, qz;
     double t = R[0] + R[4] + R[8];
     if (t > 0) {
         t = sqrt(t + 1.0);
-        q[0] = 0.5 * t;
-        t = 0.5 / t;
-        q[1] = (R[7] - R[5]) * t; q[2] = (R[2] - R[6]) * t; q[3] = (R[3] - R[1]) * t;
+        qw = 0.5 * t; t = 0.5 / t;
+        qx = (R[7] - R[5]) * t; qy = (R[2] - R[6]) * t; qz = (R[3] - R[1]) * t;
     } else if (R[0] >= R[4] && R[0] >= R[8]) {  // i = 0, j = 1, k = 2
         t = sqrt(R[0] - R[4] - R[8] + 1.0);
-        q[1] = 0.5 * t; t = 0.5 / t;
-        q[0] = (R[7] - R[5]) * t; q[2] = (R[3] + R[1]) * t; q[3] = (R[6] + R[2]) * t;
+        qx = 0.5 * t; t = 0.5 / t;
+        qw = (R[7] - R[5]) * t; qy = (R[3] + R[1]) * t; qz = (R[6] + R[2]) * t;
     } else if (R[4] > R[0] && R[4] >= R[8]) {   // i = 1, j = 2, k = 0
         t = sqrt(R[4] - R[8] - R[0] + 1.0);
-        q[2] = 0.5 * t; t = 0.5 / t;
-        q[0] = (R[2] - R[6]) * t; q[3] = (R[7] + R[5]) * t; q[1] = (R[1] + R[3]) * t;
+        qy = 0.5 * t; t = 0.5 / t;
+        qw = (R[2] - R[6]) * t; qz = (R[7] + R[5]) * t; qx = (R[1] + R[3]) * t;
     } else {                                      // i = 2, j = 0, k = 1
         t = sqrt(R[8] - R[0] - R[4] + 1.0);
-        q[3] = 0.5 * t; t = 0.5 / t;
-        q[0] = (R[3] - R[1]) * t; q[1] = (R[2] + R[6]) * t; q[2] = (R[5] + R[7]) * t;
+        qz = 0.5 * t; t = 0.5 / t;
+        qw = (R[3] - R[1]) * t; qx = (R[2] + R[6]) * t; qy = (R[5] + R[7]) * t;
     }
+    q[0] = qw; q[1] = qx; q[2] = qy; q[3] = qz;
 }
 __device__ __forceinline__ void quat_mul(const double* a, const double* b, double* o) {
     o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
@@ -126,6 +150,7 @@ struct Lds {
     double* A; int ld;
     double *diagL, *b, *x, *pose, *bak, *rrec, *prec, *srec;
     int* first;  // skyline: leftmost column of each row of H
+    double* blk; // 6x6 scratch: the diagonal block being factored
     // this instance's edge tables, staged from HBM once per launch
     const int32_t *r_idx, *p_idx, *s_idx;
     const double *r_val, *p_val, *s_val;
@@ -133,7 +158,7 @@ struct Lds {
 
 // Evaluate every edge at the current poses: errors + chi sums always, Jacobian/weight records when FULL.
 template <bool FULL>
-__device__ void evaluate_edges(const WindowArgs& a, const Lds& L, int inst, int lane, int nr, int np, int ns,
+__device__ __forceinline__ void evaluate_edges(const WindowArgs& a, const Lds& L, int inst, int lane, int nr, int np, int ns,
                                double& robust_chi, double& plain_chi) {
     (void)inst;
     double rsum = 0.0, csum = 0.0;
@@ -296,7 +321,7 @@ __device__ void evaluate_edges(const WindowArgs& a, const Lds& L, int inst, int 
 }
 
 // Skyline of H, once per solve (the topology does not change between iterations).
-__device__ void compute_skyline(const Lds& L, int lane, int n, int nr, int ns) {
+__device__ __forceinline__ void compute_skyline(const Lds& L, int lane, int n, int nr, int ns) {
     // skyline of H: a pose's rows start at its leftmost neighbour's block (binary edges only couple two poses)
     if (lane == 0) {
         const int nv = n / 6;
@@ -316,7 +341,7 @@ __device__ void compute_skyline(const Lds& L, int lane, int n, int nr, int ns) {
 }
 
 // Fold the edge records into H (upper triangle of A, diagonal included) and b, one edge after the other.
-__device__ void build_system(const WindowArgs& a, const Lds& L, int inst, int lane, int n, int nr, int np, int ns) {
+__device__ __forceinline__ void build_system(const WindowArgs& a, const Lds& L, int inst, int lane, int n, int nr, int np, int ns) {
     (void)a; (void)inst;
     const int ld = L.ld;
     for (size_t i = lane; i < (size_t)(n + 1) * ld; i += 64) L.A[i] = 0.0;
@@ -398,59 +423,158 @@ __device__ void build_system(const WindowArgs& a, const Lds& L, int inst, int la
 //     envelope, so the k-loops run over the band only (<= 12 entries for the reference's chain topology).
 //   * Back substitution keeps y in registers and walks the rows of L: no LDS writes, no barriers.
 // L goes to the strict lower triangle of A (H stays in the upper one), pivots to diagL, x to L.x.
+// 6x6-BLOCKED version of the sweep described above (poses are 6-DoF blocks, so n = 6 nv):
+// per block column J   (a) every lane forms the 6-entry segment S_i = H[i][J] - sum_K L[i][K] L[J][K]^T of its rows,
+//                      (b) the six diagonal rows publish theirs (6x6 in LDS), every lane factors that block in
+//                          registers (redundantly: no broadcast of the factor needed),
+//                      (c) every lane finishes its rows with a 6x6 triangular solve and stores 6 entries.
+// Two barriers per BLOCK column instead of one per scalar column, six pivots per dependency step instead of one.
+// The right-hand side is row n of the factor; back-substitution walks block rows with y in registers.
 template <int RMAX>  // matrix rows per lane: row i = lane + 64 r, r < RMAX  (n + 1 <= 64 * RMAX)
-__device__ bool factor_and_solve(const Lds& L, int lane, int n, double lambda) {
+__device__ __forceinline__ bool factor_and_solve(const Lds& L, int lane, int n, double lambda) {
     const int ld = L.ld;
-    int fi[RMAX];
+    const int nvb = n / 6;
+    int fb[RMAX];  // first block of each owned row (rhs row: 0)
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r) { const int i = lane + 64 * r; fi[r] = (i < n) ? L.first[i] : 0; }
-    bool ok = true;
-    for (int j = 0; j < n; ++j) {
-        const int fj = L.first[j];
-        const double* rj = L.A + (size_t)j * ld;
-        double v[RMAX];
+    for (int r = 0; r < RMAX; ++r) { const int i = lane + 64 * r; fb[r] = (i < n) ? L.first[i] / 6 : 0; }
+    for (int J = 0; J < nvb; ++J) {
+        const int c0 = 6 * J;
+        const int fJ = L.first[c0] / 6;
+        double S[RMAX][6];
+        // (a) segments
 #pragma unroll
         for (int r = 0; r < RMAX; ++r) {
             const int i = lane + 64 * r;
-            v[r] = 0.0;
-            if (i >= j && i <= n) {
-                double vv = (i == n) ? L.b[j] : rj[i];
-                if (i == j) vv += lambda;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) S[r][c] = 0.0;
+            if (i >= c0 && i <= n) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    const int col = c0 + c;
+                    double v = (i == n) ? L.b[col] : (col <= i ? L.A[(size_t)col * ld + i] : L.A[(size_t)i * ld + col]);
+                    if (i == col) v += lambda;
+                    S[r][c] = v;
+                }
                 const double* ri = L.A + (size_t)i * ld;
-                int k = fj > fi[r] ? fj : fi[r];
-                double s0 = 0.0, s1 = 0.0;
-                for (; k + 1 < j; k += 2) { s0 += ri[k] * rj[k]; s1 += ri[k + 1] * rj[k + 1]; }
-                if (k < j) s0 += ri[k] * rj[k];
-                v[r] = vv - (s0 + s1);
+                for (int K = (fJ > fb[r] ? fJ : fb[r]); K < J; ++K) {
+                    double li[6];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) li[k] = ri[6 * K + k];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {
+                        const double* rj = L.A + (size_t)(c0 + c) * ld + 6 * K;
+                        double acc = 0.0;
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) acc = __builtin_fma(li[k], rj[k], acc);
+                        S[r][c] -= acc;
+                    }
+                }
             }
         }
-        double piv = 0.0;
+        // (b) publish the diagonal block, factor it everywhere
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r) { const double c = __shfl(v[r], j & 63); if ((j >> 6) == r) piv = c; }
-        if (!(piv > 0.0) || !(piv < DBL_MAX)) { ok = false; break; }
-        const double ljj = sqrt(piv), inv = 1.0 / ljj;
+        for (int r = 0; r < RMAX; ++r) {
+            const int i = lane + 64 * r;
+            if (i >= c0 && i < c0 + 6) {
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r) { const int i = lane + 64 * r; if (i > j && i <= n) L.A[(size_t)i * ld + j] = v[r] * inv; }
-        if (lane == 0) L.diagL[j] = ljj;
+                for (int c = 0; c < 6; ++c) L.blk[(i - c0) * 6 + c] = S[r][c];
+            }
+        }
+        __syncthreads();
+        double G[6][6], ig[6];
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            double dj = L.blk[j * 6 + j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) dj = __builtin_fma(-G[j][k], G[j][k], dj);
+            ok = ok && (dj > 0.0) && (dj < DBL_MAX);
+            // pivot and its reciprocal from the rsq seed (device_math.h): a dependent chain of ~10 FMAs instead of the
+            // IEEE sqrt + divide expansions (~55 instructions) — this chain is the kernel's critical path
+            double g, igj;
+            sqrt_and_rsqrt(fmax(dj, 1e-300), g, igj);
+            igj = __builtin_fma(igj, __builtin_fma(-g, igj, 1.0), igj);  // one Newton step: 1/g to ~1e-16
+            G[j][j] = g;
+            ig[j] = igj;
+#pragma unroll
+            for (int i2 = j + 1; i2 < 6; ++i2) {
+                double v = L.blk[i2 * 6 + j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) v = __builtin_fma(-G[i2][k], G[j][k], v);
+                G[i2][j] = v * ig[j];
+            }
+        }
+        if (!ok) return false;  // uniform: every lane factored the same block
+        // (c) finish the rows
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            const int i = lane + 64 * r;
+            if (i >= c0 + 6 && i <= n) {
+                double x[6];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    double v = S[r][c];
+#pragma unroll
+                    for (int k = 0; k < c; ++k) v = __builtin_fma(-x[k], G[c][k], v);
+                    x[c] = v * ig[c];
+                    L.A[(size_t)i * ld + c0 + c] = x[c];
+                }
+            } else if (i >= c0 && i < c0 + 6) {
+                // (static indices only: a runtime row index would push G into scratch memory)
+#pragma unroll
+                for (int rr = 0; rr < 6; ++rr) {
+                    if (i - c0 == rr) {
+#pragma unroll
+                        for (int c = 0; c < rr; ++c) L.A[(size_t)i * ld + c0 + c] = G[rr][c];
+                        L.diagL[i] = ig[rr];  // the INVERSE pivot: back-substitution multiplies
+                    }
+                }
+            }
+        }
         __syncthreads();
     }
-    if (!ok) return false;
-    // y (= row n of the factor) into registers: lane k holds y_k, y_{k+64}, ...
+    // back substitution, block rows from the bottom; lane k keeps y_k (and y_{k+64}, ...) in registers
     double y[RMAX];
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) { const int i = lane + 64 * r; y[r] = (i < n) ? L.A[(size_t)n * ld + i] : 0.0; }
-    for (int j = n - 1; j >= 0; --j) {
-        double yj = 0.0;
+    for (int J = nvb - 1; J >= 0; --J) {
+        const int c0 = 6 * J;
+        const int fJ6 = L.first[c0];
+        double yj[6], x[6], G[6][6];
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r) { const double c = __shfl(y[r], j & 63); if ((j >> 6) == r) yj = c; }
-        const double xj = yj / L.diagL[j];
-        const int fj = L.first[j];
-        const double* rj = L.A + (size_t)j * ld;
+        for (int c = 0; c < 6; ++c) {
+            const int row = c0 + c;
+            double v = 0.0;
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r) { const double t = __shfl(y[r], row & 63); if ((row >> 6) == r) v = t; }
+            yj[c] = v;
+        }
+        double igd[6];
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr) {
+            igd[rr] = L.diagL[c0 + rr];
+#pragma unroll
+            for (int c = 0; c < rr; ++c) G[rr][c] = L.A[(size_t)(c0 + rr) * ld + c0 + c];
+        }
+#pragma unroll
+        for (int rr = 5; rr >= 0; --rr) {
+            double v = yj[rr];
+#pragma unroll
+            for (int s2 = rr + 1; s2 < 6; ++s2) v = __builtin_fma(-G[s2][rr], x[s2], v);
+            x[rr] = v * igd[rr];
+        }
 #pragma unroll
         for (int r = 0; r < RMAX; ++r) {
             const int i = lane + 64 * r;
-            if (i == j) y[r] = xj;
-            else if (i < j && i >= fj) y[r] -= rj[i] * xj;
+            if (i >= c0 && i < c0 + 6) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) if (i - c0 == c) y[r] = x[c];
+            } else if (i < c0 && i >= fJ6) {
+                double acc = y[r];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) acc = __builtin_fma(-L.A[(size_t)(c0 + c) * ld + i], x[c], acc);
+                y[r] = acc;
+            }
         }
     }
 #pragma unroll
@@ -478,6 +602,7 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
     L.diagL = p; p += n_max;
     L.b = p; p += n_max;
     L.x = p; p += n_max;
+    L.blk = p; p += 36;
     L.pose = p; p += c.nv_max * 12;
     L.bak = p; p += c.nv_max * 12;
     L.rrec = p; p += c.nr_max * RREC;
@@ -506,16 +631,26 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
     constexpr double tau = 1e-5, good_lo = 1.0 / 3.0, good_hi = 2.0 / 3.0;
     constexpr int max_trials = 10;
     double lambda = 0.0, ni = 2.0, cur_chi = 0.0, last_plain = 0.0;
+#ifdef LOCAMD_WINDOW_TIMING  // diagnostic build only: phase cycle counts into result[6], result[7]
+    long long t_fs = 0, t_ev = 0, t_bd = 0, tt0 = 0; const long long t_start = clock64();
+#define LOCAMD_T0() tt0 = clock64()
+#define LOCAMD_T1(acc) acc += clock64() - tt0
+#else
+#define LOCAMD_T0()
+#define LOCAMD_T1(acc)
+#endif
     int it = 0, trials = 0, terminated = 0;
     const bool empty = (nv <= 0) || (nr + np + ns <= 0);
 
     bool ok = !empty;
     for (it = 0; it < a.iterations && ok; ++it) {
         double plain;
+        LOCAMD_T0();
         evaluate_edges<true>(a, L, inst, lane, nr, np, ns, cur_chi, plain);  // computeActiveErrors + linearize
         last_plain = plain;
         __syncthreads();
         build_system(a, L, inst, lane, n, nr, np, ns);
+        LOCAMD_T1(t_bd);
         if (it == 0) {  // computeLambdaInit
             double md = 0.0;
             for (int j = lane; j < n; j += 64) md = fmax(md, fabs(L.A[(size_t)j * L.ld + j]));
@@ -526,7 +661,9 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
         int q = 0;
         do {
             for (int i = lane; i < nv * 12; i += 64) L.bak[i] = L.pose[i];  // push
+            LOCAMD_T0();
             const bool ok2 = factor_and_solve<RMAX>(L, lane, n, lambda);
+            LOCAMD_T1(t_fs);
             if (!ok2) { for (int i = lane; i < n; i += 64) L.x[i] = 0.0; __syncthreads(); }
             // update: X <- X * fromVectorMQT(dx), one pose per lane
             for (int v = lane; v < nv; v += 64) {
@@ -546,7 +683,9 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
             __syncthreads();
             ++trials;
             double temp_chi, plain2;
+            LOCAMD_T0();
             evaluate_edges<false>(a, L, inst, lane, nr, np, ns, temp_chi, plain2);
+            LOCAMD_T1(t_ev);
             last_plain = plain2;
             if (!ok2) temp_chi = DBL_MAX;
             double sc = 0.0;
@@ -577,6 +716,9 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
         double* res = a.result + (size_t)inst * 8;
         res[0] = last_plain; res[1] = cur_chi; res[2] = lambda; res[3] = (double)it; res[4] = (double)trials;
         res[5] = (double)terminated; res[6] = 0.0; res[7] = 0.0;
+#ifdef LOCAMD_WINDOW_TIMING
+        res[6] = (double)t_fs * 1e6 + (double)t_ev * 1e-3; res[7] = (double)t_bd * 1e6 + (double)(clock64() - t_start) * 1e-3;
+#endif
     }
 }
 
@@ -585,7 +727,7 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
 size_t window_lds_bytes(const WindowCaps& c, bool global_a) {
     const size_t n_max = 6 * (size_t)c.nv_max;
     const size_t ld = n_max | 1;
-    size_t d = (global_a ? 0 : (n_max + 1) * ld) + 3 * n_max + (n_max + 2) / 2 + (size_t)c.nr_max * 6 + (size_t)c.np_max * 18 +
+    size_t d = (global_a ? 0 : (n_max + 1) * ld) + 3 * n_max + 36 + (n_max + 2) / 2 + (size_t)c.nr_max * 6 + (size_t)c.np_max * 18 +
                (c.np_max + 1) / 2 + (size_t)c.ns_max * 50 + 2 * (size_t)c.nv_max * 12 + (size_t)c.nr_max * RREC +
                (size_t)c.np_max * PREC + (size_t)c.ns_max * SREC;
     return d * sizeof(double);

@@ -89,6 +89,12 @@ def test_bag_uwb_only_full_replay_config1(gpu, bag):
     assert rg[0] < 0.08 and rg[1] < 0.08 and rg[2] < 0.25
     d = np.abs(g[:, 1:4] - o[:, 1:4]).max(axis=1)
     assert np.median(d) < 1e-4, (np.median(d), d.max())
+    # the reference's own evaluation loop (script/evaluate_ate.py: 20 ms association, Horn alignment, RMSE)
+    from localization_amd import ate
+    truth = np.column_stack([bag["vicon_stamp"], bag["vicon_pos"], bag["vicon_q_xyzw"]])
+    ra, rb = ate.evaluate_ate(g[gp], truth), ate.evaluate_ate(o[op], truth)
+    print(f"ATE (aligned) GPU front-end: rmse {ra['rmse']:.4f} m over {ra['pairs']} pairs; oracle: {rb['rmse']:.4f} m")
+    assert ra["pairs"] > 1300 and ra["rmse"] < 0.15 and abs(ra["rmse"] - rb["rmse"]) < 1e-3
     node.close()
 
 
