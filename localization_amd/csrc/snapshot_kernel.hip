@@ -87,13 +87,12 @@ __device__ __forceinline__ double range_norm_plain(double dx, double dy, double 
 #pragma clang fp contract(fast)
 
 // Residuals, robust weights, normal equations and both chi sums at point p, for this lane's APL anchors, combined
-// over the LPI lanes of the tag.  `gate_now`: this is the first evaluation of an update (at the prior estimate) and
-// the outlier gate is armed: ranges with | ||p - a|| - d | > gate lose their weight for the whole update.
+// over the LPI lanes of the tag.  `gate`: finite only on the first evaluation of an update (at the prior estimate) with
+// the outlier gate armed: ranges with | ||p - a|| - d | > gate lose their weight for the whole update.
 template <int LPI, int APL, int JAC>
 __device__ __forceinline__ System evaluate(const double px, const double py, const double pz,
                                            const double (&ax)[APL], const double (&ay)[APL], const double (&az)[APL],
-                                           const double (&d)[APL], double (&w)[APL], const bool gate_now,
-                                           const double gate) {
+                                           const double (&d)[APL], double (&w)[APL], const double gate) {
     System s = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     double prod = 1.0;
 #pragma unroll
@@ -118,7 +117,7 @@ __device__ __forceinline__ System evaluate(const double px, const double py, con
             jz = scalar * ((d[j] - range_norm_plain(dx, dy, zp)) - (d[j] - range_norm_plain(dx, dy, zm)));
         }
         const double e = d[j] - n;
-        if (gate_now && fabs(e) > gate) w[j] = 0.0;  // |d_hat - d| > distance_outlier, localization.cpp:309
+        w[j] = (fabs(e) > gate) ? 0.0 : w[j];  // |d_hat - d| > distance_outlier, localization.cpp:309 (gate = inf: off)
         const double we = w[j] * e;
         const double chi = e * we;
         const double aux = 1.0 + chi;
@@ -333,53 +332,41 @@ __global__ void __launch_bounds__(256) snapshot_lm_kernel(const SnapshotArgs a) 
         const bool ok2 = solve3(cur, lambda, x0, x1, x2) && !init;
         if (!ok2) { x0 = 0.0; x1 = 0.0; x2 = 0.0; }
         const double tx = px + x0, ty = py + x1, tz = pz + x2;  // oplus: t += R dt with R = I
+        // outlier gate armed only on the first pass of an update, after warm-up: an infinite threshold elsewhere
         const bool gate_now = active && init && (a.gate > 0.0) && (k >= a.gate_from_epoch);
-        const System tr = evaluate<LPI, APL, JAC>(tx, ty, tz, ax, ay, az, d, w, gate_now, a.gate);
+        const System tr = evaluate<LPI, APL, JAC>(tx, ty, tz, ax, ay, az, d, w, gate_now ? a.gate : DBL_MAX);
 
         // ---- per-lane LM bookkeeping (g2o OptimizationAlgorithmLevenberg::solve + SparseOptimizer::optimize) ---
-        bool finished = false;
-        if (active) {
-            if (init) {
-                init = false;
-                cur = tr;
-                cur_chi = tr.rchi;
-                last_chi = tr.chi;
-                lambda = tau * fmax(fabs(tr.h00), fmax(fabs(tr.h11), fabs(tr.h22)));  // computeLambdaInit
-                ni = 2.0;
-                it = 0; q = 0; trials = 0;
-                // no active edge ("0 vertices to optimize") or nothing to iterate
-                finished = (a.iterations <= 0) || !((tr.h00 + tr.h11 + tr.h22) > 0.0);
-            } else {
-                const double temp_chi = ok2 ? tr.rchi : DBL_MAX;
-                double scale = x0 * __builtin_fma(lambda, x0, cur.b0) + x1 * __builtin_fma(lambda, x1, cur.b1) +
-                               x2 * __builtin_fma(lambda, x2, cur.b2);
-                scale += 1e-3;
-                const double rho = (cur_chi - temp_chi) * fast_rcp(scale);
-                const bool accept = (rho > 0.0) && (fabs(temp_chi) < DBL_MAX) && ok2;
-                ++trials;
-                last_chi = tr.chi;
-                if (accept) {
-                    const double r21 = 2.0 * rho - 1.0;
-                    double alpha = 1.0 - r21 * r21 * r21;
-                    alpha = fmin(alpha, good_hi);
-                    lambda *= fmax(good_lo, alpha);
-                    ni = 2.0;
-                    cur_chi = temp_chi;
-                    px = tx; py = ty; pz = tz;
-                    cur = tr;
-                } else {
-                    lambda *= ni;
-                    ni *= 2.0;
-                }
-                ++q;
-                const bool again = (rho < 0.0) && (q < max_trials);
-                if (!again) {
-                    ++it;
-                    finished = (q == max_trials) || (rho == 0.0) || (it >= a.iterations);
-                    q = 0;
-                }
-            }
+        // Written as selects on per-lane predicates (one exec region only, for the 11-double system copy): a lone wave
+        // per SIMD pays a full issue slot for every branch-management instruction.
+        const bool first = active && init;   // this pass evaluated the prior: computeActiveErrors + buildSystem, iteration 0
+        const bool lm = active && !init;     // this pass was an LM trial
+        const double temp_chi = ok2 ? tr.rchi : DBL_MAX;
+        double scale = x0 * __builtin_fma(lambda, x0, cur.b0) + x1 * __builtin_fma(lambda, x1, cur.b1) +
+                       x2 * __builtin_fma(lambda, x2, cur.b2);  // computeScale
+        scale += 1e-3;
+        const double rho = (cur_chi - temp_chi) * fast_rcp(scale);
+        const bool accept = lm && (rho > 0.0) && (fabs(temp_chi) < DBL_MAX) && ok2;
+        if (first || accept) {  // the trial's system is the next iteration's system (discardTop); first: it IS the system
+            cur = tr;
+            cur_chi = tr.rchi;
+            px = tx; py = ty; pz = tz;  // (first: tx == px)
         }
+        const double r21 = 2.0 * rho - 1.0;
+        const double lam_acc = lambda * fmax(good_lo, fmin(1.0 - r21 * r21 * r21, good_hi));
+        const double lam_first = tau * fmax(fabs(tr.h00), fmax(fabs(tr.h11), fabs(tr.h22)));  // computeLambdaInit
+        lambda = first ? lam_first : (accept ? lam_acc : (lm ? lambda * ni : lambda));
+        ni = (first || accept) ? 2.0 : (lm ? ni * 2.0 : ni);
+        last_chi = active ? tr.chi : last_chi;
+        trials = first ? 0 : trials + (lm ? 1 : 0);
+        q = first ? 0 : q + (lm ? 1 : 0);
+        const bool end_iter = lm && !((rho < 0.0) && (q < max_trials));
+        it = first ? 0 : it + (end_iter ? 1 : 0);
+        // no active edge ("0 vertices to optimize") or nothing to iterate; LM: Terminate (10 failed trials or rho == 0) or done
+        const bool finished = (first && ((a.iterations <= 0) || !((tr.h00 + tr.h11 + tr.h22) > 0.0))) ||
+                              (end_iter && ((q == max_trials) || (rho == 0.0) || (it >= a.iterations)));
+        q = end_iter ? 0 : q;
+        init = active ? false : init;
 
         // ---- lanes that just finished an update: emit, then step into the next epoch or wait for the window ------
         if (__any(finished)) {
