@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--datagen", default="torch", choices=["torch", "numpy"],
                     help="numpy: generate the stream on the host and copy it (PMC profiling runs: no torch kernels)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the driver's multi-GPU runs); gloo only to rehearse N > 1 on a one-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tags", type=int, default=2048)
     ap.add_argument("--cpu-epochs", type=int, default=96)
@@ -76,10 +78,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    n_dev = torch.cuda.device_count()
+    if args.dist_backend == "gloo":
+        local_rank = local_rank % max(n_dev, 1)  # rehearsal: ranks may share a device
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     n_gpus = world
     if args.gpus != n_gpus and rank == 0:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
@@ -128,7 +136,7 @@ def main():
     n_launch, kern_ms_total, kern_ms_avg = solver.timing_end()
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
