@@ -178,6 +178,37 @@ def test_pose_twist_lidar_factors_match_oracle(gpu):
     node.close()
 
 
+def test_relative_range_mode_moving_responders(gpu):
+    """topic/relative_range present: every node is a moving robot with its own ring (localization.cpp:94-98) and each
+    range also adds the responder's smoothness edge (:360-369) — the closest thing the reference has to BASELINE
+    config 4's unknown anchors."""
+    import localization_amd as la
+    from oracle import oracle as O
+    ids = [1, 2, 3, 9]
+    pos = np.array([[3.0, -3.0, 0.5], [3.0, 3.0, 2.0], [-3.0, 0.0, 1.0], [0.2, 0.1, 1.0]])
+    cfg = dict(trajectory_length=4, maximum_velocity=1.0, distance_outlier=5.0, maximum_iteration=10,
+               minimum_optimize_error=1e9, publish_range=True, has_relative_range=True)
+    node = la.LocalizationNode(ids, pos.ravel(), **cfg)
+    ora = O.LocalizationOracle(ids, pos.ravel(), jac_mode=O.JAC_ANALYTIC, **cfg)
+    truth = pos.copy()
+    rng = np.random.default_rng(5)
+    worst, solved = 0.0, 0
+    for step in range(40):
+        t = 10.0 + 0.05 * step
+        a, b = (3, step % 3) if step % 2 == 0 else (step % 3, (step + 1) % 3)   # tag<->node and node<->node ranges
+        d = np.linalg.norm(truth[a] - truth[b]) + rng.normal(0, 0.02)
+        g = node.add_range(ids[a], ids[b], t, d, 0.055, 0, "uwb")
+        o = ora.add_range(ids[a], ids[b], t, d, 0.055, 0, "uwb")
+        assert g["solved"] == o["solved"]
+        if g["solved"]:
+            solved += 1
+            worst = max(worst, np.abs(g["realtime"][1:4] - o["realtime"][1:4]).max())
+            for nid in ids:
+                assert np.abs(node.path(nid)[:, 1:4] - ora.path(nid)[:, 1:4]).max() < 1e-6
+    assert solved > 30 and worst < 1e-6, (solved, worst)
+    node.close()
+
+
 def test_fleet_batch_equals_one_by_one(gpu, bag):
     """Deferred mode: N nodes fed different streams, every pending solve done by ONE window launch — bit-identical to
     solving each node on its own (instances are independent)."""

@@ -5,6 +5,8 @@ on synthetic instances in the reference's topology, next to the oracle on one ho
     python tools/bench_window.py --shape uwb_only   # T = 10, ranges + smoothness        (cfg/uwb_only.yaml shape)
     python tools/bench_window.py --shape uwb_imu    # T = 12, + IMU priors + lever arm   (cfg/uwb_imu.yaml shape)
     python tools/bench_window.py --shape fusion1    # 1 pose, 8 ranges + IMU prior       (BASELINE config 3 shape)
+    python tools/bench_window.py --shape pose64 --batch 1024   # 64-pose window, key-frame EdgeSE3 star + one range per pose
+                                                               # (BASELINE config 5 shape; matrix in the HBM workspace)
 """
 import argparse
 import json
@@ -25,6 +27,8 @@ def build(B, shape, seed=0):
     import localization_amd as la
     from localization_amd.synthetic import ANCHORS_8
     rng = np.random.default_rng(seed)
+    if shape == "pose64":
+        return build_pose64(B, rng)
     if shape == "fusion1":
         T, anchors, imu, lever, per_pose = 1, ANCHORS_8, True, True, 8
     elif shape == "uwb_imu":
@@ -54,6 +58,32 @@ def build(B, shape, seed=0):
     return wb, graphs, anchors, T
 
 
+def build_pose64(B, rng, T=64):
+    """cfg5: per pose one range (round-robin anchor) + one EdgeSE3 from the current key pose (new key
+    every 8 poses), Omega = diag(1e4), Cauchy."""
+    import localization_amd as la
+    wb = la.WindowBatch(B, T, T, 0, T)
+    graphs = []
+    info = np.eye(6) * 1e4
+    for i in range(B):
+        tt = np.cumsum(rng.normal(0, 0.05, (T, 3)), axis=0) + np.array([rng.uniform(-1.5, 1.5), rng.uniform(-1.5, 1.5), 1.1])
+        tR = Rotation.from_rotvec(np.cumsum(rng.normal(0, 0.03, (T, 3)), axis=0) + rng.normal(0, 0.3, 3))
+        et = tt + rng.normal(0, 0.05, (T, 3)); eR = (tR * Rotation.from_rotvec(rng.normal(0, 0.02, (T, 3)))).as_matrix()
+        g = dict(et=et, eR=eR, off=np.zeros(3), ranges=[], smooth=[], priors=[], se3=[])
+        for k in range(T):
+            wb.add_pose(i, et[k], eR[k])
+            a = k % 4
+            d = float(np.float32(np.linalg.norm(tt[k] - ANCH4[a]) + rng.normal(0, 0.03)))
+            wb.add_range(i, k, a, d, 1 / 0.055 ** 2, anchor=True); g["ranges"].append((k, a, d))
+            if k:
+                key = 0 if k < 8 else (k // 8) * 8 - 1
+                Zt = tR[key].inv().apply(tt[k] - tt[key]) + rng.normal(0, 0.01, 3)
+                ZR = (tR[key].inv() * tR[k] * Rotation.from_rotvec(rng.normal(0, 0.01, 3))).as_matrix()
+                wb.add_se3(i, key, k, Zt, ZR, info, True); g["se3"].append((key, k, Zt, ZR))
+        graphs.append(g)
+    return wb, graphs, ANCH4, T
+
+
 def oracle_time(graphs, anchors, T, n, iters=10):
     from oracle import oracle as O
     t0 = time.perf_counter()
@@ -65,6 +95,7 @@ def oracle_time(graphs, anchors, T, n, iters=10):
         for (k, a, d) in g["ranges"]: G.add_range_edge(100 + k, a, d, 1 / 0.055 ** 2, off0=g["off"])
         for (k0, k1) in g["smooth"]: G.add_range_edge(100 + k0, 100 + k1, 0.0, 1 / (5.0 / 32 / 3) ** 2)
         for (k, t, R, dg) in g["priors"]: G.add_prior_edge(100 + k, t, R, np.diag(dg))
+        for (ki, kj, t, R) in g.get("se3", []): G.add_se3_edge(100 + ki, 100 + kj, t, R, np.eye(6) * 1e4, True)
         G.optimize(iters, O.JAC_NUMERIC_G2O)
         out.append(np.array([G.estimate(100 + k)[1] for k in range(T)]))
     return time.perf_counter() - t0, np.array(out)
@@ -72,7 +103,7 @@ def oracle_time(graphs, anchors, T, n, iters=10):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--shape", default="uwb_only", choices=["uwb_only", "uwb_imu", "fusion1"])
+    ap.add_argument("--shape", default="uwb_only", choices=["uwb_only", "uwb_imu", "fusion1", "pose64"])
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--cpu-n", type=int, default=256)
