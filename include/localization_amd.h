@@ -135,12 +135,16 @@ int loc_snapshot_timing_end(loc_snapshot* s, int32_t* n_launches, double* total_
  *   s_val  double[B][ns_max][48]  INVERSE measurement Z^-1 as R(9), t(3); information 6x6 row-major
  *   result double[B][8]           chi2() over all edges at the last evaluated state, robust chi2 of the accepted
  *                                 state, final lambda, outer iterations run, LM trials, terminated flag, 0, 0
- * Limits: nv_max <= 64.  Up to 16 poses the (6 nv_max + 1)^2 matrix lives in LDS next to the edge tables; larger
- * windows keep it in a per-instance HBM workspace ((6 nv_max + 1)^2 doubles each).  In both cases the edge tables and
- * records must fit 160 KiB of LDS (loc_window_lds_bytes tells).
+ * The normal equations are kept in skyline form (per pose: columns from its leftmost neighbour to itself), so storage
+ * and work scale with nv_max * bw_max^2, not nv_max^3: cfg/uwb_pose.yaml's 500-pose chain is 3000 rows of ~12 entries.
+ * Windows whose per-instance arrays fit 160 KiB keep everything in LDS (loc_window_lds_bytes tells); larger ones keep
+ * them in a per-instance slice of an HBM workspace the handle allocates (a few MB for 500 poses).
  * ============================================================================================== */
 typedef struct loc_window loc_window;
-typedef struct loc_window_caps { int32_t nv_max, nr_max, np_max, ns_max; } loc_window_caps;
+typedef struct loc_window_caps {
+    int32_t nv_max, nr_max, np_max, ns_max;
+    int32_t bw_max; /* widest pose-to-pose coupling |vi - vj| of any binary edge, in pose slots; < 0 = nv_max - 1 (dense) */
+} loc_window_caps;
 
 int loc_window_create(loc_window** out, int32_t device, int64_t batch, const loc_window_caps* caps,
                       int32_t n_anchors, const double* anchors_xyz_host, int32_t maximum_iteration);
@@ -168,7 +172,7 @@ int loc_window_last_kernel_ms(loc_window* w, double* ms);
  *   loc_node_get_path      Robot::vertices2path                robot.cpp:61-72
  * add_* return 1 when the call ran a solve (out is filled), 0 when it did not, < 0 on error.
  * Poses are 8 doubles: stamp, x, y, z, qx, qy, qz, qw (the TUM order the reference logs, localization.cpp:630-642).
- * Limits of this kernel version: trajectory_length <= 16 moving poses in the window.
+ * Limits of this kernel version: trajectory_length (x number of nodes with topic/relative_range) <= 1024 poses.
  * ============================================================================================== */
 typedef struct loc_node loc_node;
 

@@ -34,11 +34,19 @@ struct loc_window {
 
 extern "C" {
 
+static locamd::WindowCaps to_caps(const loc_window_caps* caps) {
+    int bw = caps->bw_max < 0 ? caps->nv_max - 1 : caps->bw_max;
+    if (bw > caps->nv_max - 1) bw = caps->nv_max - 1;
+    if (bw < 0) bw = 0;
+    return locamd::WindowCaps{caps->nv_max, caps->nr_max, caps->np_max, caps->ns_max, bw};
+}
+
 size_t loc_window_lds_bytes(const loc_window_caps* caps) {
     if (!caps) return 0;
-    locamd::WindowCaps c{caps->nv_max, caps->nr_max, caps->np_max, caps->ns_max};
+    if (caps->nv_max <= 0) return 0;
+    locamd::WindowCaps c = to_caps(caps);
     const size_t in_lds = locamd::window_lds_bytes(c, false);
-    return in_lds <= 160 * 1024 ? in_lds : locamd::window_lds_bytes(c, true);
+    return in_lds <= 160 * 1024 - 512 ? in_lds : 36 * sizeof(double);  // large windows: everything else in the HBM workspace
 }
 
 int loc_window_destroy(loc_window* w) {
@@ -58,10 +66,9 @@ int loc_window_create(loc_window** out, int32_t device, int64_t batch, const loc
     if (!out) return locamd_fail(LOC_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (batch <= 0 || !caps || n_anchors < 0 || (n_anchors > 0 && !anchors)) return locamd_fail(LOC_ERR_INVALID, "window arguments");
-    if (caps->nv_max <= 0 || caps->nv_max > 64 || caps->nr_max < 0 || caps->np_max < 0 || caps->ns_max < 0)
-        return locamd_fail(LOC_ERR_UNSUPPORTED, "window capacities (1 <= nv_max <= 64)");
-    if (loc_window_lds_bytes(caps) > 160 * 1024)
-        return locamd_fail(LOC_ERR_UNSUPPORTED, "edge tables and records of this window do not fit 160 KiB of LDS");
+    if (caps->nv_max <= 0 || caps->nv_max > 4096 || caps->nr_max < 0 || caps->np_max < 0 || caps->ns_max < 0)
+        return locamd_fail(LOC_ERR_UNSUPPORTED, "window capacities (1 <= nv_max <= 4096)");
+
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return locamd_fail(LOC_ERR_NO_DEVICE, "no HIP device visible: localization_amd has no CPU fallback");
@@ -70,8 +77,8 @@ int loc_window_create(loc_window** out, int32_t device, int64_t batch, const loc
     loc_window* w = new (std::nothrow) loc_window();
     if (!w) return locamd_fail(LOC_ERR_INVALID, "out of host memory");
     w->device = device; w->B = batch; w->n_anchors = n_anchors; w->anchors_cap = n_anchors > 0 ? n_anchors : 1; w->iterations = maximum_iteration;
-    w->caps = locamd::WindowCaps{caps->nv_max, caps->nr_max, caps->np_max, caps->ns_max};
-    const bool global_a = locamd::window_lds_bytes(w->caps, false) > 160 * 1024;
+    w->caps = to_caps(caps);
+    const bool global_a = locamd::window_lds_bytes(w->caps, false) > 160 * 1024 - 512;
     const size_t B = (size_t)batch;
     const size_t na = (size_t)(n_anchors > 0 ? n_anchors : 1);
     hipError_t e;
@@ -129,6 +136,8 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
             const int32_t* ix = r_idx + ((size_t)i * c.nr_max + e) * 2;
             if (ix[0] < 0 || ix[0] >= cn[0] || ix[1] >= cn[0] || ix[1] < -w->n_anchors || ix[0] == ix[1])
                 return locamd_fail(LOC_ERR_INVALID, "range edge vertex index");
+            if (ix[1] >= 0 && (ix[0] - ix[1] > c.bw_max || ix[1] - ix[0] > c.bw_max))
+                return locamd_fail(LOC_ERR_INVALID, "range edge couples poses further apart than bw_max");
         }
         for (int e = 0; e < cn[2]; ++e) {
             const int32_t v = p_idx[(size_t)i * c.np_max + e];
@@ -138,6 +147,8 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
             const int32_t* ix = s_idx + ((size_t)i * c.ns_max + e) * 4;
             if (ix[0] < 0 || ix[0] >= cn[0] || ix[1] < 0 || ix[1] >= cn[0] || ix[0] == ix[1])
                 return locamd_fail(LOC_ERR_INVALID, "SE3 edge vertex index");
+            if (ix[0] - ix[1] > c.bw_max || ix[1] - ix[0] > c.bw_max)
+                return locamd_fail(LOC_ERR_INVALID, "SE3 edge couples poses further apart than bw_max");
         }
     }
     LOC_HIP(hipSetDevice(w->device));

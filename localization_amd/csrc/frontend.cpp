@@ -120,7 +120,7 @@ struct loc_node {
     bool deferred = false, pending = false;
     loc_window* win = nullptr;            // cached single-instance solver (anchors are part of its device state)
     std::vector<double> win_anchors;
-    loc_window_caps caps{16, 64, 32, 32};  // grown to the window's size in loc_node_create
+    loc_window_caps caps{16, 64, 32, 32, -1};  // sized for the window in loc_node_create
 
     RobotRing* robot(int id) { for (auto& r : robots) if (r.id == id) return &r; return nullptr; }
     void remove_vertex(int vid) {  // optimizer.removeVertex(v, false): the vertex and every edge touching it
@@ -166,6 +166,7 @@ struct Packed {
     std::vector<int32_t> counts, r_idx, p_idx, s_idx;
     std::vector<double> poses, r_val, p_val, s_val, anchors;
     std::vector<int> slot_vid;
+    int band = 0;  // widest |slot_i - slot_j| over the binary edges
 };
 
 int pack(const loc_node* n, Packed& P) {
@@ -181,11 +182,20 @@ int pack(const loc_node* n, Packed& P) {
     for (const auto& e : n->ranges) if (active2(e.v0, e.v1)) { touch(e.v0); touch(e.v1); }
     for (const auto& e : n->priors) if (!n->vertices.at(e.v).fixed) touch(e.v);
     for (const auto& e : n->se3s) if (active2(e.vi, e.vj)) { touch(e.vi); touch(e.vj); }
+    // Pose slots in AGE order per robot (oldest first), not in vertex-id order: consecutive poses then sit next to each
+    // other and the normal equations are banded (g2o orders by id; the order only changes round-off).
     int k = 0;
-    for (auto& kv : slot) kv.second = k++;
-    if ((int)slot.size() > c.nv_max) return locamd_fail(LOC_ERR_UNSUPPORTED, "window has more active poses than the node was sized for");
     P.slot_vid.clear();
-    for (auto& kv : slot) P.slot_vid.push_back(kv.first);
+    for (const RobotRing& r : n->robots) {
+        if (r.is_static) continue;
+        for (int i = 0; i < r.T; ++i) {
+            const int vid = r.slot_vertex((r.index + 1 + i) % r.T);
+            auto it = slot.find(vid);
+            if (it != slot.end()) { it->second = k++; P.slot_vid.push_back(vid); }
+        }
+    }
+    if ((int)slot.size() != k) return locamd_fail(LOC_ERR_INVALID, "internal: active vertex outside every robot ring");
+    if (k > c.nv_max) return locamd_fail(LOC_ERR_UNSUPPORTED, "window has more active poses than the node was sized for");
     P.counts.assign(4, 0);
     P.poses.assign((size_t)c.nv_max * 12, 0.0);
     P.r_idx.assign((size_t)c.nr_max * 2, 0); P.r_val.assign((size_t)c.nr_max * 5, 0.0);
@@ -210,6 +220,7 @@ int pack(const loc_node* n, Packed& P) {
         }
         P.r_idx[(size_t)nr * 2] = slot.at(a);
         P.r_idx[(size_t)nr * 2 + 1] = n->vertices.at(b).fixed ? -1 - anchor_ix.at(b) : slot.at(b);
+        if (!n->vertices.at(b).fixed) P.band = std::max(P.band, std::abs(slot.at(a) - slot.at(b)));
         double* v = &P.r_val[(size_t)nr * 5];
         v[0] = e.meas; v[1] = e.info; v[2] = off[0]; v[3] = off[1]; v[4] = off[2];
         ++nr;
@@ -229,6 +240,7 @@ int pack(const loc_node* n, Packed& P) {
         if (ns >= c.ns_max) return locamd_fail(LOC_ERR_UNSUPPORTED, "more SE3 edges in the window than the node was sized for");
         int32_t* ix = &P.s_idx[(size_t)ns * 4];
         ix[0] = slot.at(e.vi); ix[1] = slot.at(e.vj); ix[2] = e.robust ? 1 : 0; ix[3] = 0;
+        P.band = std::max(P.band, std::abs(ix[0] - ix[1]));
         double* v = &P.s_val[(size_t)ns * 48];
         std::memcpy(v, e.zinv.R, sizeof(double) * 9); std::memcpy(v + 9, e.zinv.t, sizeof(double) * 3);
         std::memcpy(v + 12, e.info, sizeof(double) * 36);
@@ -260,6 +272,11 @@ int solve_now(loc_node* n, loc_node_output* out) {
     if (P.counts[0] > 0) {
         // the anchor table is device state of the solver handle: keep one handle per node, rebuilt only when the set
         // of fixed vertices seen by the window changes
+        const int want_bw = n->caps.nv_max <= 16 ? -1 : std::min(n->caps.nv_max - 1, std::max(8, P.band));
+        if (want_bw >= 0 && (n->caps.bw_max < 0 || want_bw > n->caps.bw_max)) {  // grow the band capacity (rare)
+            n->caps.bw_max = want_bw;
+            if (n->win) { loc_window_destroy(n->win); n->win = nullptr; }
+        }
         if (!n->win || n->win_anchors != P.anchors) {
             if (n->win) { loc_window_destroy(n->win); n->win = nullptr; }
             rc = loc_window_create(&n->win, n->device, 1, &n->caps, (int32_t)(P.anchors.size() / 3), P.anchors.data(), n->cfg.maximum_iteration);
@@ -315,21 +332,23 @@ int loc_node_create(loc_node** out, int32_t device, const loc_node_config* cfg, 
     if (!cfg || n_nodes <= 0 || !ids || !pos_xyz) return locamd_fail(LOC_ERR_INVALID, "node arguments");
     if (cfg->trajectory_length <= 0) return locamd_fail(LOC_ERR_INVALID, "robot/trajectory_length must be set");
     if (loc_device_count() <= 0) return locamd_fail(LOC_ERR_NO_DEVICE, "no HIP device visible: localization_amd has no CPU fallback");
-    if (cfg->trajectory_length > 64 || (cfg->has_relative_range && cfg->trajectory_length * n_nodes > 64))
-        return locamd_fail(LOC_ERR_UNSUPPORTED, "windows of more than 64 moving poses are not supported by this kernel version");
+    if (cfg->trajectory_length > 1024 || (cfg->has_relative_range && cfg->trajectory_length * n_nodes > 1024))
+        return locamd_fail(LOC_ERR_UNSUPPORTED, "windows of more than 1024 moving poses are not supported by this kernel version");
     loc_node* n = new (std::nothrow) loc_node();
     if (!n) return locamd_fail(LOC_ERR_INVALID, "out of host memory");
     n->cfg = *cfg;
     n->device = device;
     n->self_id = ids[n_nodes - 1];  // nodesId.back(), localization.cpp:89
-    {   // capacities for this window: every pose can carry a range + a smoothness edge, one prior, one SE3 edge
+    {   // capacities for this window: every pose can carry a range + a smoothness edge, one prior, one SE3 edge.
+        // Band: poses are packed in ascending vertex id = ring-slot order, so consecutive poses are neighbours except
+        // across the ring's wrap point (oldest <-> newest slot), and key-frame pose factors reach back at most T - 1:
+        // dense up to 16 poses; beyond that a band is requested and grown on demand (pack() measures what it needs).
         const int tv = cfg->has_relative_range ? cfg->trajectory_length * n_nodes : cfg->trajectory_length;
         n->caps.nv_max = tv <= 16 ? 16 : tv;
         n->caps.nr_max = tv <= 16 ? 64 : 2 * tv + 8;
         n->caps.np_max = tv <= 16 ? 32 : tv;
         n->caps.ns_max = tv <= 16 ? 32 : tv;
-        if (loc_window_lds_bytes(&n->caps) > 160 * 1024) { n->caps.np_max = tv / 2; }
-        if (loc_window_lds_bytes(&n->caps) > 160 * 1024) { delete n; return locamd_fail(LOC_ERR_UNSUPPORTED, "window too large for this kernel version"); }
+        n->caps.bw_max = -1;
     }
     for (int i = 0; i < n_nodes; ++i) {  // :92-108 and Robot::init, robot.cpp:31-58
         RobotRing r;
@@ -537,7 +556,12 @@ int loc_nodes_solve_batch(loc_node** nodes, int32_t n_nodes, loc_node_output* ou
         todo.push_back(i);
     }
     if (todo.empty()) return 0;
-    const loc_window_caps caps = nodes[todo[0]]->caps;
+    loc_window_caps caps = nodes[todo[0]]->caps;
+    {
+        int band = 0;
+        for (int i : todo) band = std::max(band, P[(size_t)i].band);
+        caps.bw_max = caps.nv_max <= 16 ? -1 : std::min(caps.nv_max - 1, std::max(8, band));
+    }
     const size_t B = todo.size();
     std::vector<int32_t> counts(B * 4), r_idx(B * caps.nr_max * 2), p_idx(B * caps.np_max), s_idx(B * caps.ns_max * 4);
     std::vector<double> poses(B * caps.nv_max * 12), r_val(B * caps.nr_max * 5), p_val(B * caps.np_max * 18),

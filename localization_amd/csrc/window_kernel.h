@@ -7,10 +7,11 @@ namespace locamd {
 
 // Per-batch capacities; every instance owns fixed-size slices of the arrays below.
 struct WindowCaps {
-    int nv_max;  // moving poses per instance (<= 64; <= 16 keeps the matrix in LDS)
+    int nv_max;  // moving poses per instance
     int nr_max;  // range edges
     int np_max;  // unary SE3 priors
     int ns_max;  // binary SE3 edges   (edge tables and records must fit 160 KiB of LDS)
+    int bw_max;  // widest coupling between poses of one instance, in pose slots (|vi - vj| of any binary edge)
 };
 
 // Layout of one instance (all arrays are [B][...]):
@@ -32,7 +33,7 @@ struct WindowArgs {
     const int32_t* s_idx; const double* s_val;
     const double* anchors;  // [n_anchors][3] fixed vertices (identity rotation), shared by all instances
     double* result;
-    double* workspace;  // nullptr: H/L in LDS; else [B][(6 nv_max + 1) * ld] doubles in HBM (large windows)
+    double* workspace;  // nullptr: skyline H/L in LDS; else [B][window_workspace_doubles] in HBM (large windows)
     int n_anchors;
     int B;
     int iterations;

@@ -147,9 +147,9 @@ __device__ __forceinline__ void quat_right_jac(const double* q, double sgn, doub
 }
 
 struct Lds {
-    double* A; int ld;
-    double *diagL, *b, *x, *pose, *bak, *rrec, *prec, *srec;
-    int* first;  // skyline: leftmost column of each row of H
+    double *Hs, *Ls;  // skyline H (lower) and its Cholesky factor (LDS, or an HBM workspace slice for large windows)
+    double *diagL, *b, *x, *yrow, *pose, *bak, *rrec, *prec, *srec;
+    int *fb, *last, *rowoff;  // per block: first / last connected block; per row: skyline offset
     double* blk; // 6x6 scratch: the diagonal block being factored
     // this instance's edge tables, staged from HBM once per launch
     const int32_t *r_idx, *p_idx, *s_idx;
@@ -320,31 +320,56 @@ __device__ __forceinline__ void evaluate_edges(const WindowArgs& a, const Lds& L
     plain_chi = wave_sum(csum);
 }
 
-// Skyline of H, once per solve (the topology does not change between iterations).
+// ---- skyline storage ---------------------------------------------------------------------------------------------
+// H (lower triangle) and its Cholesky factor live in SKYLINE form: row i of pose block v keeps columns
+// [6 fb[v], i], fb[v] = the leftmost block v is connected to (itself if none).  Cholesky fill-in never leaves that
+// envelope, so storage and work are O(n * band^2) instead of O(n^2) / O(n^3): a 500-pose chain (cfg/uwb_pose.yaml) is
+// 3000 rows of ~12 entries.  rowoff[i] = offset of row i, rowoff[n] = nnz.
+__host__ __device__ inline size_t sky_nnz_bound(int nv, int bw) {
+    size_t s = 0;
+    for (int v = 0; v < nv; ++v) s += 36 * (size_t)(v < bw ? v : bw) + 21;
+    return s;
+}
+
+// doubles of one instance's arrays (skyline pair, dense vectors, poses, edge records, index tables) — the layout the
+// kernel carves, in LDS or in the HBM workspace
+__host__ __device__ inline size_t window_instance_doubles(const WindowCaps& c) {
+    const size_t n_max = 6 * (size_t)c.nv_max;
+    return 2 * sky_nnz_bound(c.nv_max, c.bw_max) + 4 * n_max + 2 * (size_t)c.nv_max * 12 + (size_t)c.nr_max * RREC + (size_t)c.np_max * PREC +
+           (size_t)c.ns_max * SREC + 2 * (((size_t)c.nv_max + 1) / 2) + (n_max + 2) / 2;
+}
+
+// Once per solve (the topology does not change between iterations): fb[], last[], rowoff[].
 __device__ __forceinline__ void compute_skyline(const Lds& L, int lane, int n, int nr, int ns) {
-    // skyline of H: a pose's rows start at its leftmost neighbour's block (binary edges only couple two poses)
+    const int nv = n / 6;
     if (lane == 0) {
-        const int nv = n / 6;
-        for (int v = 0; v < nv; ++v) L.first[v * 6] = v;
+        for (int v = 0; v < nv; ++v) { L.fb[v] = v; L.last[v] = v; }
         for (int e = 0; e < nr; ++e) {
             const int32_t* idx = L.r_idx + e * 2;
-            if (idx[1] >= 0) { const int lo = min(idx[0], idx[1]), hi = max(idx[0], idx[1]); L.first[hi * 6] = min(L.first[hi * 6], lo); }
+            if (idx[1] >= 0) { const int lo = min(idx[0], idx[1]), hi = max(idx[0], idx[1]); L.fb[hi] = min(L.fb[hi], lo); }
         }
         for (int e = 0; e < ns; ++e) {
             const int32_t* idx = L.s_idx + e * 4;
             const int lo = min(idx[0], idx[1]), hi = max(idx[0], idx[1]);
-            L.first[hi * 6] = min(L.first[hi * 6], lo);
+            L.fb[hi] = min(L.fb[hi], lo);
         }
-        for (int v = 0; v < nv; ++v) { const int f = L.first[v * 6] * 6; for (int r = 0; r < 6; ++r) L.first[v * 6 + r] = f; }
+        // last[J] = last block whose envelope reaches block column J
+        for (int v = 0; v < nv; ++v) for (int J = L.fb[v]; J <= v; ++J) L.last[J] = max(L.last[J], v);
+        int off = 0;
+        for (int v = 0; v < nv; ++v)
+            for (int r = 0; r < 6; ++r) { L.rowoff[v * 6 + r] = off; off += 6 * (v - L.fb[v]) + r + 1; }
+        L.rowoff[n] = off;
     }
     __syncthreads();
 }
+// address of H/L entry (row, col), col <= row, col inside row's envelope
+__device__ __forceinline__ int sky(const Lds& L, int row, int col) { return L.rowoff[row] + col - 6 * L.fb[row / 6]; }
 
-// Fold the edge records into H (upper triangle of A, diagonal included) and b, one edge after the other.
+// Fold the edge records into H (skyline lower triangle) and b, one edge after the other (fixed order: bit-reproducible).
 __device__ __forceinline__ void build_system(const WindowArgs& a, const Lds& L, int inst, int lane, int n, int nr, int np, int ns) {
     (void)a; (void)inst;
-    const int ld = L.ld;
-    for (size_t i = lane; i < (size_t)(n + 1) * ld; i += 64) L.A[i] = 0.0;
+    const int nnz = L.rowoff[n];
+    for (int i = lane; i < nnz; i += 64) L.Hs[i] = 0.0;
     for (int i = lane; i < n; i += 64) L.b[i] = 0.0;
     __syncthreads();
     const int r = lane / 6, cc = lane % 6;  // lanes 0..35: one entry of a 6x6 block
@@ -354,11 +379,11 @@ __device__ __forceinline__ void build_system(const WindowArgs& a, const Lds& L, 
         const double* rec = L.rrec + e * RREC;
         const double wr = rec[12], om = rec[13];
         if (lane < 36) {
-            if (r <= cc) L.A[(v0 * 6 + r) * ld + v0 * 6 + cc] += wr * rec[r] * rec[cc];
+            if (r >= cc) L.Hs[sky(L, v0 * 6 + r, v0 * 6 + cc)] += wr * rec[r] * rec[cc];
             if (v1 >= 0) {
-                if (r <= cc) L.A[(v1 * 6 + r) * ld + v1 * 6 + cc] += wr * rec[6 + r] * rec[6 + cc];
-                if (v0 < v1) L.A[(v0 * 6 + r) * ld + v1 * 6 + cc] += wr * rec[r] * rec[6 + cc];
-                else         L.A[(v1 * 6 + r) * ld + v0 * 6 + cc] += wr * rec[6 + r] * rec[cc];
+                if (r >= cc) L.Hs[sky(L, v1 * 6 + r, v1 * 6 + cc)] += wr * rec[6 + r] * rec[6 + cc];
+                if (v0 > v1) L.Hs[sky(L, v0 * 6 + r, v1 * 6 + cc)] += wr * rec[r] * rec[6 + cc];
+                else         L.Hs[sky(L, v1 * 6 + r, v0 * 6 + cc)] += wr * rec[6 + r] * rec[cc];
             }
         } else if (lane < 42) {
             L.b[v0 * 6 + lane - 36] += rec[lane - 36] * om;
@@ -370,11 +395,11 @@ __device__ __forceinline__ void build_system(const WindowArgs& a, const Lds& L, 
         const int v = L.p_idx[e];
         const double* rec = L.prec + e * PREC;
         if (lane < 36) {
-            if (r <= cc) {
+            if (r >= cc) {
                 double s = 0.0;
 #pragma unroll
                 for (int i = 0; i < 6; ++i) s += rec[i * 6 + r] * rec[36 + i] * rec[i * 6 + cc];
-                L.A[(v * 6 + r) * ld + v * 6 + cc] += s;
+                L.Hs[sky(L, v * 6 + r, v * 6 + cc)] += s;
             }
         } else if (lane < 42) {
             const int rr = lane - 36;
@@ -390,16 +415,16 @@ __device__ __forceinline__ void build_system(const WindowArgs& a, const Lds& L, 
         const double* rec = L.srec + e * SREC;
         const double *J0 = rec, *J1 = rec + 36, *WJ0 = rec + 72, *WJ1 = rec + 108, *om = rec + 144;
         if (lane < 36) {
-            double sii = 0.0, sjj = 0.0, sij = 0.0;
+            double sii = 0.0, sjj = 0.0, sx = 0.0;
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
                 sii += J0[i * 6 + r] * WJ0[i * 6 + cc];
                 sjj += J1[i * 6 + r] * WJ1[i * 6 + cc];
-                sij += (vi < vj) ? J0[i * 6 + r] * WJ1[i * 6 + cc] : J1[i * 6 + r] * WJ0[i * 6 + cc];
+                sx += (vi > vj) ? J0[i * 6 + r] * WJ1[i * 6 + cc] : J1[i * 6 + r] * WJ0[i * 6 + cc];  // rows of the later pose
             }
-            if (r <= cc) { L.A[(vi * 6 + r) * ld + vi * 6 + cc] += sii; L.A[(vj * 6 + r) * ld + vj * 6 + cc] += sjj; }
-            if (vi < vj) L.A[(vi * 6 + r) * ld + vj * 6 + cc] += sij;
-            else         L.A[(vj * 6 + r) * ld + vi * 6 + cc] += sij;
+            if (r >= cc) { L.Hs[sky(L, vi * 6 + r, vi * 6 + cc)] += sii; L.Hs[sky(L, vj * 6 + r, vj * 6 + cc)] += sjj; }
+            if (vi > vj) L.Hs[sky(L, vi * 6 + r, vj * 6 + cc)] += sx;
+            else         L.Hs[sky(L, vj * 6 + r, vi * 6 + cc)] += sx;
         } else if (lane < 48) {
             const bool second = lane >= 42;
             const int rr = second ? lane - 42 : lane - 36;
@@ -413,148 +438,126 @@ __device__ __forceinline__ void build_system(const WindowArgs& a, const Lds& L, 
     __syncthreads();
 }
 
-// (H + lambda I) x = b in one sweep.
-//   * Left-looking Cholesky, one matrix row per lane (two for n > 64): at column j every lane forms
-//     v_i = H[j][i] - sum_k L[i][k] L[j][k] for its rows i >= j; the pivot is lane j's own v, fetched with one
-//     cross-lane read, so there is no serial diagonal loop.
-//   * The right-hand side rides along as row n of the factor (forward substitution IS one more Cholesky row):
-//     after the sweep L[n][k] = y_k.
-//   * Skyline: row i has no entry left of first[i] (its leftmost graph neighbour's block), and Cholesky keeps that
-//     envelope, so the k-loops run over the band only (<= 12 entries for the reference's chain topology).
-//   * Back substitution keeps y in registers and walks the rows of L: no LDS writes, no barriers.
-// L goes to the strict lower triangle of A (H stays in the upper one), pivots to diagL, x to L.x.
-// 6x6-BLOCKED version of the sweep described above (poses are 6-DoF blocks, so n = 6 nv):
-// per block column J   (a) every lane forms the 6-entry segment S_i = H[i][J] - sum_K L[i][K] L[J][K]^T of its rows,
-//                      (b) the six diagonal rows publish theirs (6x6 in LDS), every lane factors that block in
-//                          registers (redundantly: no broadcast of the factor needed),
-//                      (c) every lane finishes its rows with a 6x6 triangular solve and stores 6 entries.
-// Two barriers per BLOCK column instead of one per scalar column, six pivots per dependency step instead of one.
-// The right-hand side is row n of the factor; back-substitution walks block rows with y in registers.
-template <int RMAX>  // matrix rows per lane: row i = lane + 64 r, r < RMAX  (n + 1 <= 64 * RMAX)
+// (H + lambda I) x = b in one sweep over 6x6 block columns (poses are 6-DoF blocks, n = 6 nv):
+//   per block column J the ACTIVE rows are those of blocks J..last[J] whose envelope reaches J, plus the right-hand side
+//   (it rides along as one more row of the factor: forward substitution is one more Cholesky row).  In chunks of 64:
+//   (a) every lane forms the 6-entry segment S_i = H[i][J] - sum_K L[i][K] L[J][K]^T of its row (K over the band),
+//   (b) the six diagonal rows publish theirs (6x6 in LDS) and every lane factors that block in registers (redundantly:
+//       no broadcast of the factor), pivots from the rsq seed,
+//   (c) every lane finishes its row with a 6x6 triangular solve and stores 6 entries.
+//   Back-substitution walks block rows with y in LDS.  Inverse pivots go to diagL, x to L.x.
 __device__ __forceinline__ bool factor_and_solve(const Lds& L, int lane, int n, double lambda) {
-    const int ld = L.ld;
     const int nvb = n / 6;
-    int fb[RMAX];  // first block of each owned row (rhs row: 0)
-#pragma unroll
-    for (int r = 0; r < RMAX; ++r) { const int i = lane + 64 * r; fb[r] = (i < n) ? L.first[i] / 6 : 0; }
     for (int J = 0; J < nvb; ++J) {
         const int c0 = 6 * J;
-        const int fJ = L.first[c0] / 6;
-        double S[RMAX][6];
-        // (a) segments
+        const int fJ = L.fb[J];
+        const int nrows = 6 * (L.last[J] - J + 1);  // matrix rows c0 .. c0 + nrows - 1, then the rhs
+        const int total = nrows + 1;
+        double G[6][6], ig[6];
+        for (int base = 0; base < total; base += 64) {
+            const int idx = base + lane;
+            const bool is_rhs = idx == nrows;
+            const int row = is_rhs ? n : c0 + idx;
+            const int fbi = (is_rhs || idx > nrows) ? 0 : L.fb[row / 6];
+            const bool part = (idx < total) && (is_rhs || fbi <= J);
+            const int roff = part && !is_rhs ? L.rowoff[row] - 6 * fbi : 0;  // row's skyline base: entry (row, col) at roff + col
+            double S[6];
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
-            const int i = lane + 64 * r;
-#pragma unroll
-            for (int c = 0; c < 6; ++c) S[r][c] = 0.0;
-            if (i >= c0 && i <= n) {
+            for (int c = 0; c < 6; ++c) S[c] = 0.0;
+            if (part) {
 #pragma unroll
                 for (int c = 0; c < 6; ++c) {
                     const int col = c0 + c;
-                    double v = (i == n) ? L.b[col] : (col <= i ? L.A[(size_t)col * ld + i] : L.A[(size_t)i * ld + col]);
-                    if (i == col) v += lambda;
-                    S[r][c] = v;
+                    double v;
+                    if (is_rhs) v = L.b[col];
+                    else if (col <= row) v = L.Hs[roff + col];
+                    else v = L.Hs[L.rowoff[col] - 6 * fJ + row];  // symmetric entry inside the diagonal block
+                    if (row == col) v += lambda;
+                    S[c] = v;
                 }
-                const double* ri = L.A + (size_t)i * ld;
-                for (int K = (fJ > fb[r] ? fJ : fb[r]); K < J; ++K) {
+                const double* ri = is_rhs ? L.yrow : L.Ls + roff;
+                for (int K = (fJ > fbi ? fJ : fbi); K < J; ++K) {
                     double li[6];
 #pragma unroll
                     for (int k = 0; k < 6; ++k) li[k] = ri[6 * K + k];
 #pragma unroll
                     for (int c = 0; c < 6; ++c) {
-                        const double* rj = L.A + (size_t)(c0 + c) * ld + 6 * K;
+                        const double* rj = L.Ls + L.rowoff[c0 + c] - 6 * fJ + 6 * K;
                         double acc = 0.0;
 #pragma unroll
                         for (int k = 0; k < 6; ++k) acc = __builtin_fma(li[k], rj[k], acc);
-                        S[r][c] -= acc;
+                        S[c] -= acc;
                     }
                 }
             }
-        }
-        // (b) publish the diagonal block, factor it everywhere
+            if (base == 0) {
+                // (b) publish the diagonal block (rows idx 0..5), factor it everywhere
+                if (idx < 6) {
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
-            const int i = lane + 64 * r;
-            if (i >= c0 && i < c0 + 6) {
+                    for (int c = 0; c < 6; ++c) L.blk[idx * 6 + c] = S[c];
+                }
+                __syncthreads();
+                bool ok = true;
 #pragma unroll
-                for (int c = 0; c < 6; ++c) L.blk[(i - c0) * 6 + c] = S[r][c];
+                for (int j = 0; j < 6; ++j) {
+                    double dj = L.blk[j * 6 + j];
+#pragma unroll
+                    for (int k = 0; k < j; ++k) dj = __builtin_fma(-G[j][k], G[j][k], dj);
+                    ok = ok && (dj > 0.0) && (dj < DBL_MAX);
+                    double g, igj;
+                    sqrt_and_rsqrt(fmax(dj, 1e-300), g, igj);
+                    igj = __builtin_fma(igj, __builtin_fma(-g, igj, 1.0), igj);  // one Newton step: 1/g to ~1e-16
+                    G[j][j] = g;
+                    ig[j] = igj;
+#pragma unroll
+                    for (int i2 = j + 1; i2 < 6; ++i2) {
+                        double v = L.blk[i2 * 6 + j];
+#pragma unroll
+                        for (int k = 0; k < j; ++k) v = __builtin_fma(-G[i2][k], G[j][k], v);
+                        G[i2][j] = v * ig[j];
+                    }
+                }
+                if (!ok) return false;  // uniform: every lane factored the same block
             }
-        }
-        __syncthreads();
-        double G[6][6], ig[6];
-        bool ok = true;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            double dj = L.blk[j * 6 + j];
-#pragma unroll
-            for (int k = 0; k < j; ++k) dj = __builtin_fma(-G[j][k], G[j][k], dj);
-            ok = ok && (dj > 0.0) && (dj < DBL_MAX);
-            // pivot and its reciprocal from the rsq seed (device_math.h): a dependent chain of ~10 FMAs instead of the
-            // IEEE sqrt + divide expansions (~55 instructions) — this chain is the kernel's critical path
-            double g, igj;
-            sqrt_and_rsqrt(fmax(dj, 1e-300), g, igj);
-            igj = __builtin_fma(igj, __builtin_fma(-g, igj, 1.0), igj);  // one Newton step: 1/g to ~1e-16
-            G[j][j] = g;
-            ig[j] = igj;
-#pragma unroll
-            for (int i2 = j + 1; i2 < 6; ++i2) {
-                double v = L.blk[i2 * 6 + j];
-#pragma unroll
-                for (int k = 0; k < j; ++k) v = __builtin_fma(-G[i2][k], G[j][k], v);
-                G[i2][j] = v * ig[j];
-            }
-        }
-        if (!ok) return false;  // uniform: every lane factored the same block
-        // (c) finish the rows
-#pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
-            const int i = lane + 64 * r;
-            if (i >= c0 + 6 && i <= n) {
+            // (c) finish the rows
+            if (part && (is_rhs || idx >= 6)) {
                 double x[6];
 #pragma unroll
                 for (int c = 0; c < 6; ++c) {
-                    double v = S[r][c];
+                    double v = S[c];
 #pragma unroll
                     for (int k = 0; k < c; ++k) v = __builtin_fma(-x[k], G[c][k], v);
                     x[c] = v * ig[c];
-                    L.A[(size_t)i * ld + c0 + c] = x[c];
                 }
-            } else if (i >= c0 && i < c0 + 6) {
+                double* dst = is_rhs ? L.yrow + c0 : L.Ls + roff + c0;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) dst[c] = x[c];
+            } else if (base == 0 && idx < 6) {
                 // (static indices only: a runtime row index would push G into scratch memory)
 #pragma unroll
                 for (int rr = 0; rr < 6; ++rr) {
-                    if (i - c0 == rr) {
+                    if (idx == rr) {
 #pragma unroll
-                        for (int c = 0; c < rr; ++c) L.A[(size_t)i * ld + c0 + c] = G[rr][c];
-                        L.diagL[i] = ig[rr];  // the INVERSE pivot: back-substitution multiplies
+                        for (int c = 0; c < rr; ++c) L.Ls[roff + c0 + c] = G[rr][c];
+                        L.diagL[row] = ig[rr];  // the INVERSE pivot: back-substitution multiplies
                     }
                 }
             }
         }
         __syncthreads();
     }
-    // back substitution, block rows from the bottom; lane k keeps y_k (and y_{k+64}, ...) in registers
-    double y[RMAX];
-#pragma unroll
-    for (int r = 0; r < RMAX; ++r) { const int i = lane + 64 * r; y[r] = (i < n) ? L.A[(size_t)n * ld + i] : 0.0; }
+    // back substitution, block rows from the bottom; y (= row n of the factor) is updated in place in LDS
     for (int J = nvb - 1; J >= 0; --J) {
         const int c0 = 6 * J;
-        const int fJ6 = L.first[c0];
-        double yj[6], x[6], G[6][6];
+        const int fJ6 = 6 * L.fb[J];
+        double yj[6], x[6], G[6][6], igd[6];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            const int row = c0 + c;
-            double v = 0.0;
-#pragma unroll
-            for (int r = 0; r < RMAX; ++r) { const double t = __shfl(y[r], row & 63); if ((row >> 6) == r) v = t; }
-            yj[c] = v;
-        }
-        double igd[6];
+        for (int c = 0; c < 6; ++c) yj[c] = L.yrow[c0 + c];
 #pragma unroll
         for (int rr = 0; rr < 6; ++rr) {
             igd[rr] = L.diagL[c0 + rr];
 #pragma unroll
-            for (int c = 0; c < rr; ++c) G[rr][c] = L.A[(size_t)(c0 + rr) * ld + c0 + c];
+            for (int c = 0; c < rr; ++c) G[rr][c] = L.Ls[L.rowoff[c0 + rr] - fJ6 + c0 + c];
         }
 #pragma unroll
         for (int rr = 5; rr >= 0; --rr) {
@@ -563,29 +566,24 @@ __device__ __forceinline__ bool factor_and_solve(const Lds& L, int lane, int n, 
             for (int s2 = rr + 1; s2 < 6; ++s2) v = __builtin_fma(-G[s2][rr], x[s2], v);
             x[rr] = v * igd[rr];
         }
+        if (lane < 6) {
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
-            const int i = lane + 64 * r;
-            if (i >= c0 && i < c0 + 6) {
-#pragma unroll
-                for (int c = 0; c < 6; ++c) if (i - c0 == c) y[r] = x[c];
-            } else if (i < c0 && i >= fJ6) {
-                double acc = y[r];
-#pragma unroll
-                for (int c = 0; c < 6; ++c) acc = __builtin_fma(-L.A[(size_t)(c0 + c) * ld + i], x[c], acc);
-                y[r] = acc;
-            }
+            for (int c = 0; c < 6; ++c) if (lane == c) L.x[c0 + c] = x[c];
         }
-    }
+        for (int k = fJ6 + lane; k < c0; k += 64) {
+            double acc = L.yrow[k];
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r) { const int i = lane + 64 * r; if (i < n) L.x[i] = y[r]; }
-    __syncthreads();
+            for (int c = 0; c < 6; ++c) acc = __builtin_fma(-L.Ls[L.rowoff[c0 + c] - fJ6 + k], x[c], acc);
+            L.yrow[k] = acc;
+        }
+        __syncthreads();
+    }
     return true;
 }
 
-// GLOBAL_A: the (n+1) x ld matrix lives in an HBM workspace slice instead of LDS (windows of more than 16 poses);
+// GLOBAL_A: the skyline arrays (H and its factor) live in an HBM workspace slice instead of LDS (large windows);
 // a workgroup is one wave on one CU, whose L1 is coherent for its own stores after the workgroup barrier.
-template <int RMAX, bool GLOBAL_A>
+template <bool GLOBAL_A>
 __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int inst = blockIdx.x;
@@ -594,37 +592,49 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
     const int nv = a.counts[inst * 4 + 0], nr = a.counts[inst * 4 + 1], np = a.counts[inst * 4 + 2], ns = a.counts[inst * 4 + 3];
     const int n = 6 * nv;
     const int n_max = 6 * c.nv_max;
+    const size_t nnz_max = sky_nnz_bound(c.nv_max, c.bw_max);
     Lds L;
-    L.ld = n_max | 1;
-    double* p = lds;
-    if (GLOBAL_A) L.A = a.workspace + (size_t)inst * (size_t)(n_max + 1) * L.ld;
-    else { L.A = p; p += (size_t)(n_max + 1) * L.ld; }  // +1 row: the right-hand side rides along as row n
+    // Small windows: everything per-instance lives in LDS.  Large windows (GLOBAL_A): everything lives in this
+    // instance's slice of the HBM workspace (L1/L2-cached), edge tables are read where the caller put them; only the
+    // 6x6 exchange block stays in LDS.
+    __shared__ double s_blk[36];
+    double* p = GLOBAL_A ? a.workspace + (size_t)inst * window_instance_doubles(c) : lds;
+    L.Hs = p; p += nnz_max;
+    L.Ls = p; p += nnz_max;
     L.diagL = p; p += n_max;
     L.b = p; p += n_max;
     L.x = p; p += n_max;
-    L.blk = p; p += 36;
+    L.yrow = p; p += n_max;
+    L.blk = s_blk;
     L.pose = p; p += c.nv_max * 12;
     L.bak = p; p += c.nv_max * 12;
     L.rrec = p; p += c.nr_max * RREC;
     L.prec = p; p += c.np_max * PREC;
     L.srec = p; p += c.ns_max * SREC;
-    L.first = reinterpret_cast<int*>(p); p += (n_max + 2) / 2;
-    double* st_rval = p; p += c.nr_max * 5;
-    double* st_pval = p; p += c.np_max * 18;
-    double* st_sval = p; p += c.ns_max * 48;
-    int32_t* st_ridx = reinterpret_cast<int32_t*>(p); p += c.nr_max;        // nr_max * 2 ints
-    int32_t* st_pidx = reinterpret_cast<int32_t*>(p); p += (c.np_max + 1) / 2;
-    int32_t* st_sidx = reinterpret_cast<int32_t*>(p);                        // ns_max * 4 ints
-    L.r_idx = st_ridx; L.p_idx = st_pidx; L.s_idx = st_sidx; L.r_val = st_rval; L.p_val = st_pval; L.s_val = st_sval;
-
+    L.fb = reinterpret_cast<int*>(p); p += (c.nv_max + 1) / 2;
+    L.last = reinterpret_cast<int*>(p); p += (c.nv_max + 1) / 2;
+    L.rowoff = reinterpret_cast<int*>(p); p += (n_max + 2) / 2;
     double* gpose = a.poses + (size_t)inst * c.nv_max * 12;
     for (int i = lane; i < nv * 12; i += 64) L.pose[i] = gpose[i];
-    for (int i = lane; i < nr * 2; i += 64) st_ridx[i] = a.r_idx[(size_t)inst * c.nr_max * 2 + i];
-    for (int i = lane; i < nr * 5; i += 64) st_rval[i] = a.r_val[(size_t)inst * c.nr_max * 5 + i];
-    for (int i = lane; i < np; i += 64) st_pidx[i] = a.p_idx[(size_t)inst * c.np_max + i];
-    for (int i = lane; i < np * 18; i += 64) st_pval[i] = a.p_val[(size_t)inst * c.np_max * 18 + i];
-    for (int i = lane; i < ns * 4; i += 64) st_sidx[i] = a.s_idx[(size_t)inst * c.ns_max * 4 + i];
-    for (int i = lane; i < ns * 48; i += 64) st_sval[i] = a.s_val[(size_t)inst * c.ns_max * 48 + i];
+    if (GLOBAL_A) {
+        L.r_idx = a.r_idx + (size_t)inst * c.nr_max * 2; L.r_val = a.r_val + (size_t)inst * c.nr_max * 5;
+        L.p_idx = a.p_idx + (size_t)inst * c.np_max;     L.p_val = a.p_val + (size_t)inst * c.np_max * 18;
+        L.s_idx = a.s_idx + (size_t)inst * c.ns_max * 4; L.s_val = a.s_val + (size_t)inst * c.ns_max * 48;
+    } else {
+        double* st_rval = p; p += c.nr_max * 5;
+        double* st_pval = p; p += c.np_max * 18;
+        double* st_sval = p; p += c.ns_max * 48;
+        int32_t* st_ridx = reinterpret_cast<int32_t*>(p); p += c.nr_max;        // nr_max * 2 ints
+        int32_t* st_pidx = reinterpret_cast<int32_t*>(p); p += (c.np_max + 1) / 2;
+        int32_t* st_sidx = reinterpret_cast<int32_t*>(p);                        // ns_max * 4 ints
+        L.r_idx = st_ridx; L.p_idx = st_pidx; L.s_idx = st_sidx; L.r_val = st_rval; L.p_val = st_pval; L.s_val = st_sval;
+        for (int i = lane; i < nr * 2; i += 64) st_ridx[i] = a.r_idx[(size_t)inst * c.nr_max * 2 + i];
+        for (int i = lane; i < nr * 5; i += 64) st_rval[i] = a.r_val[(size_t)inst * c.nr_max * 5 + i];
+        for (int i = lane; i < np; i += 64) st_pidx[i] = a.p_idx[(size_t)inst * c.np_max + i];
+        for (int i = lane; i < np * 18; i += 64) st_pval[i] = a.p_val[(size_t)inst * c.np_max * 18 + i];
+        for (int i = lane; i < ns * 4; i += 64) st_sidx[i] = a.s_idx[(size_t)inst * c.ns_max * 4 + i];
+        for (int i = lane; i < ns * 48; i += 64) st_sval[i] = a.s_val[(size_t)inst * c.ns_max * 48 + i];
+    }
     __syncthreads();
     compute_skyline(L, lane, n, nr, ns);
 
@@ -653,7 +663,7 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
         LOCAMD_T1(t_bd);
         if (it == 0) {  // computeLambdaInit
             double md = 0.0;
-            for (int j = lane; j < n; j += 64) md = fmax(md, fabs(L.A[(size_t)j * L.ld + j]));
+            for (int j = lane; j < n; j += 64) md = fmax(md, fabs(L.Hs[sky(L, j, j)]));
             lambda = tau * wave_max(md);
             ni = 2.0;
         }
@@ -662,7 +672,7 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
         do {
             for (int i = lane; i < nv * 12; i += 64) L.bak[i] = L.pose[i];  // push
             LOCAMD_T0();
-            const bool ok2 = factor_and_solve<RMAX>(L, lane, n, lambda);
+            const bool ok2 = factor_and_solve(L, lane, n, lambda);
             LOCAMD_T1(t_fs);
             if (!ok2) { for (int i = lane; i < n; i += 64) L.x[i] = 0.0; __syncthreads(); }
             // update: X <- X * fromVectorMQT(dx), one pose per lane
@@ -725,44 +735,31 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
 }  // namespace
 
 size_t window_lds_bytes(const WindowCaps& c, bool global_a) {
-    const size_t n_max = 6 * (size_t)c.nv_max;
-    const size_t ld = n_max | 1;
-    size_t d = (global_a ? 0 : (n_max + 1) * ld) + 3 * n_max + 36 + (n_max + 2) / 2 + (size_t)c.nr_max * 6 + (size_t)c.np_max * 18 +
-               (c.np_max + 1) / 2 + (size_t)c.ns_max * 50 + 2 * (size_t)c.nv_max * 12 + (size_t)c.nr_max * RREC +
-               (size_t)c.np_max * PREC + (size_t)c.ns_max * SREC;
-    return d * sizeof(double);
+    if (global_a) return 0;  // (the 6x6 exchange block is static LDS)
+    const size_t tables = (size_t)c.nr_max * 6 + (size_t)c.np_max * 18 + (c.np_max + 1) / 2 + (size_t)c.ns_max * 50;
+    return (window_instance_doubles(c) + tables) * sizeof(double);
 }
-size_t window_workspace_doubles(const WindowCaps& c) {
-    const size_t n_max = 6 * (size_t)c.nv_max;
-    return (n_max + 1) * (n_max | 1);
-}
+size_t window_workspace_doubles(const WindowCaps& c) { return window_instance_doubles(c); }
 
-template <int RMAX, bool GLOBAL_A>
+template <bool GLOBAL_A>
 static hipError_t launch_window_t(const WindowArgs& a, size_t lds, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&window_lm_kernel<RMAX, GLOBAL_A>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&window_lm_kernel<GLOBAL_A>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);  // 288 B of static LDS on top
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((window_lm_kernel<RMAX, GLOBAL_A>), dim3((unsigned)a.B), dim3(64), lds, stream, a);
+    hipLaunchKernelGGL((window_lm_kernel<GLOBAL_A>), dim3((unsigned)a.B), dim3(64), lds, stream, a);
     return hipGetLastError();
 }
 
 hipError_t launch_window(const WindowArgs& a, hipStream_t stream) {
-    if (a.B <= 0) return hipErrorInvalidValue;
+    if (a.B <= 0 || a.caps.bw_max < 0 || a.caps.bw_max >= a.caps.nv_max + (a.caps.nv_max == 1)) return hipErrorInvalidValue;
     const bool global_a = a.workspace != nullptr;
     const size_t lds = window_lds_bytes(a.caps, global_a);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    const int rows = 6 * a.caps.nv_max + 1;
-    if (!global_a) {
-        if (rows > 128) return hipErrorInvalidValue;
-        return launch_window_t<2, false>(a, lds, stream);
-    }
-    if (rows <= 128) return launch_window_t<2, true>(a, lds, stream);
-    if (rows <= 448) return launch_window_t<7, true>(a, lds, stream);
-    return hipErrorInvalidValue;
+    if (lds > 160 * 1024 - 512) return hipErrorInvalidValue;
+    return global_a ? launch_window_t<true>(a, lds, stream) : launch_window_t<false>(a, lds, stream);
 }
 
 }  // namespace locamd

@@ -8,7 +8,7 @@ from ._lib import check, lib
 
 
 class WindowCaps(C.Structure):
-    _fields_ = [("nv_max", C.c_int32), ("nr_max", C.c_int32), ("np_max", C.c_int32), ("ns_max", C.c_int32)]
+    _fields_ = [("nv_max", C.c_int32), ("nr_max", C.c_int32), ("np_max", C.c_int32), ("ns_max", C.c_int32), ("bw_max", C.c_int32)]
 
 
 def _inv_iso(R, t):
@@ -70,12 +70,12 @@ class WindowBatch:
 
 
 class WindowSolver:
-    def __init__(self, anchors, batch, nv_max, nr_max, np_max=0, ns_max=0, maximum_iteration=10, device=0):
+    def __init__(self, anchors, batch, nv_max, nr_max, np_max=0, ns_max=0, maximum_iteration=10, device=0, bw_max=-1):
         L = lib()
         if L.loc_device_count() <= 0:
             raise _lib.LocalizationAmdError(_lib.LOC_ERR_NO_DEVICE, "no HIP device visible: localization_amd has no CPU fallback")
         anchors = np.ascontiguousarray(anchors, dtype=np.float64).reshape(-1, 3)
-        caps = WindowCaps(nv_max, nr_max, np_max, ns_max)
+        caps = WindowCaps(nv_max, nr_max, np_max, ns_max, bw_max)
         h = C.c_void_p()
         check(L.loc_window_create(C.byref(h), device, int(batch), C.byref(caps), anchors.shape[0],
                                   anchors.ctypes.data_as(C.POINTER(C.c_double)), int(maximum_iteration)))

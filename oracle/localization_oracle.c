@@ -153,6 +153,12 @@ static void solve_and_publish(lo_state* s, lo_output* out) {
     pose_from_vertex(s, slot_vertex_id(r, idx), r->header[idx].stamp, out->optimized);
 }
 
+int lo_solve(lo_state* s, lo_output* out) {
+    if (out) memset(out, 0, sizeof(*out));
+    solve_and_publish(s, out);
+    return 1;
+}
+
 /* Localization::addRangeEdge, localization.cpp:297-376 */
 int lo_add_range(lo_state* s, int requester_id, int responder_id, double stamp, float distance,
                  float distance_err, int antenna, const char* frame_id, lo_output* out) {

@@ -53,6 +53,9 @@ int lo_add_twist(lo_state* s, double stamp, const double* twist_lin_ang6, const 
                  const char* frame_id, lo_output* out);
 int lo_add_lidar(lo_state* s, double stamp, double z, const char* frame_id, lo_output* out);
 
+/* Localization::solve() + publish() on demand (localization.cpp:164-251) */
+int lo_solve(lo_state* s, lo_output* out);
+
 /* Robot::vertices2path for a node: out[T][8] (stamp, xyz, qxyzw), oldest first. Returns T. */
 int lo_get_path(lo_state* s, int node_id, double* out);
 int lo_number_measurements(lo_state* s);

@@ -83,6 +83,7 @@ def lib():
         L.lo_add_pose.argtypes = [C.c_void_p, C.c_double, dp, dp, C.c_char_p, C.POINTER(LoOutput)]
         L.lo_add_twist.argtypes = [C.c_void_p, C.c_double, dp, dp, C.c_char_p, C.POINTER(LoOutput)]
         L.lo_add_lidar.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_char_p, C.POINTER(LoOutput)]
+        L.lo_solve.argtypes = [C.c_void_p, C.POINTER(LoOutput)]
         L.lo_get_path.argtypes = [C.c_void_p, C.c_int, dp]
         L.lo_number_measurements.argtypes = [C.c_void_p]
         _LIB = L
@@ -252,6 +253,11 @@ class LocalizationOracle:
     def add_lidar(self, stamp, z, frame_id="lidar"):
         o = LoOutput()
         rc = self.L.lo_add_lidar(self.h, stamp, float(z), frame_id.encode(), C.byref(o))
+        return self._out(o, rc)
+
+    def solve(self):
+        o = LoOutput()
+        rc = self.L.lo_solve(self.h, C.byref(o))
         return self._out(o, rc)
 
     def path(self, node_id):

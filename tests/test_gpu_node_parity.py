@@ -178,6 +178,41 @@ def test_pose_twist_lidar_factors_match_oracle(gpu):
     node.close()
 
 
+def test_uwb_pose_500_pose_window(gpu):
+    """cfg/uwb_pose.yaml: trajectory_length 500 (3000 unknowns), range + key-frame pose factors.  The skyline solver keeps
+    this at ~3000 x 50 entries; the oracle factors the dense 3000 x 3000 system."""
+    import localization_amd as la
+    from oracle import oracle as O
+    anch = np.array([[3, -3, 0.58], [3, 3, 1.97], [-3, 3, 0.54], [-3, -3, 1.76]], dtype=float)
+    ids = [100, 101, 102, 103, 200]
+    pos = np.concatenate([anch, [[0.0, 0.0, 1.0]]])
+    cfg = dict(trajectory_length=500, maximum_velocity=0.5, distance_outlier=1.0, maximum_iteration=10,
+               minimum_optimize_error=1e9, publish_range=False, publish_pose=False)
+    node = la.LocalizationNode(ids, pos, **cfg)
+    ora = O.LocalizationOracle(ids, pos, jac_mode=O.JAC_ANALYTIC, **cfg)
+    rng = np.random.default_rng(11)
+    truth = np.array([0.0, 0.0, 1.0])
+    cov = (np.eye(6) * 1e-4).ravel()
+    t = 100.0
+    for step in range(520):
+        t += 0.05
+        truth = truth + np.array([0.004, 0.002 * np.sin(step / 20.0), 0.0])
+        rel = np.array([0.004 * ((step % 8) + 1), 0.0, 0.0, 0.0, 0.0, 0.0, 1.0]) + np.concatenate([rng.normal(0, 1e-3, 3), np.zeros(4)])
+        for obj in (node, ora):
+            assert obj.add_pose(t, rel, cov, f"key_{step // 8}")["rc"] == 0
+            a = step % 4
+            assert obj.add_range(200, ids[a], t + 0.01, np.linalg.norm(truth - anch[a]), 0.055, 0, "uwb")["rc"] == 0
+    g = node.solve()
+    o = ora.solve()
+    assert g["solved"] and o["solved"] and g["outer_iterations"] == o["outer_iterations"]
+    gp, op_ = node.path(200), ora.path(200)
+    assert gp.shape == (500, 8) and np.array_equal(gp[:, 0], op_[:, 0])
+    assert np.abs(gp[:, 1:4] - op_[:, 1:4]).max() < 1e-6, np.abs(gp[:, 1:4] - op_[:, 1:4]).max()
+    assert np.abs(gp[:, 4:] - op_[:, 4:]).max() < 1e-6
+    assert abs(g["chi2"] - o["chi2"]) <= 1e-6 * max(1.0, abs(o["chi2"]))
+    node.close()
+
+
 def test_relative_range_mode_moving_responders(gpu):
     """topic/relative_range present: every node is a moving robot with its own ring (localization.cpp:94-98) and each
     range also adds the responder's smoothness edge (:360-369) — the closest thing the reference has to BASELINE
@@ -251,5 +286,5 @@ def test_node_errors(gpu, bag):
         node.add_range(200, 177, 1.0, 3.0, 0.055)         # reference: std::map::at throws (localization.cpp:306)
     assert e.value.code == -4
     with pytest.raises(la.LocalizationAmdError):
-        la.LocalizationNode(ids, pos, trajectory_length=500)  # uwb_pose.yaml's T = 500: beyond this kernel version
+        la.LocalizationNode(ids, pos, trajectory_length=2000)  # beyond this kernel version (<= 1024 poses)
     node.close()
