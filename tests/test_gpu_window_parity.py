@@ -104,6 +104,38 @@ def test_window_matches_oracle(gpu, T, with_imu, with_pose_edges, lever):
         assert (res[:, 4] != want_trials).mean() < 0.05
 
 
+def test_selfcalibration_arrowhead_graph(gpu):
+    """BASELINE config 4's shape at test size: every node moves (topic/relative_range, localization.cpp:94-98) — A unknown
+    anchors ranged from every pose of a tag trajectory, weak position priors on the anchor hypotheses.  Tag poses first,
+    anchors last: the skyline is an arrowhead (long rows only for the anchors)."""
+    import os
+    import sys
+    import localization_amd as la
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import bench_window as bw
+    rng = np.random.default_rng(3)
+    T, A, B = 24, 4, 6
+    wb, graphs, anchors, nv = bw.build_selfcal(B, rng, T=T, A=A)
+    solver = la.WindowSolver(anchors, B, *wb.caps, maximum_iteration=10)
+    res = solver.solve(wb)
+    solver.close()
+    from oracle import oracle as O
+    worst = 0.0
+    for i in range(B):
+        g = graphs[i]
+        G = O.Graph()
+        for k in range(T): G.add_vertex(100 + k, g["et"][k])
+        for a in range(A):
+            G.add_vertex(100 + T + a, g["hyp"][a]); G.add_prior_edge(100 + T + a, g["hyp"][a], np.eye(3), np.diag([1.0, 1, 1, 0, 0, 0]))
+        for (k, a, d) in g["ranges"]: G.add_range_edge(100 + k, 100 + T + a, d, 1 / 0.055 ** 2)
+        for (k0, k1) in g["smooth"]: G.add_range_edge(100 + k0, 100 + k1, 0.0, 1 / (5.0 / 32 / 3) ** 2)
+        G.optimize(10, O.JAC_ANALYTIC)
+        want = np.array([G.estimate(100 + k)[1] for k in range(T + A)])
+        worst = max(worst, np.abs(wb.poses[i, :, 9:] - want).max())
+        assert abs(res[i, 0] - G.chi2()) <= 1e-6 * max(1.0, G.chi2())
+    assert worst < 1e-6, worst
+
+
 def test_window_converged_matches_oracle_tightly(gpu):
     got_t, got_R, res, want_t, want_R, _, _, _ = _solve_both(gpu, 32, 10, 60, 99, True, False, True)
     assert np.abs(got_t - want_t).max() < 1e-7

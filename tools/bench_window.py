@@ -5,6 +5,7 @@ on synthetic instances in the reference's topology, next to the oracle on one ho
     python tools/bench_window.py --shape uwb_only   # T = 10, ranges + smoothness        (cfg/uwb_only.yaml shape)
     python tools/bench_window.py --shape uwb_imu    # T = 12, + IMU priors + lever arm   (cfg/uwb_imu.yaml shape)
     python tools/bench_window.py --shape fusion1    # 1 pose, 8 ranges + IMU prior       (BASELINE config 3 shape)
+    python tools/bench_window.py --shape selfcal --batch 128   # cfg4 shape: 10 unknown anchors x 256 timesteps per hypothesis
     python tools/bench_window.py --shape pose64 --batch 1024   # 64-pose window, key-frame EdgeSE3 star + one range per pose
                                                                # (BASELINE config 5 shape; matrix in the HBM workspace)
 """
@@ -29,6 +30,8 @@ def build(B, shape, seed=0):
     rng = np.random.default_rng(seed)
     if shape == "pose64":
         return build_pose64(B, rng)
+    if shape == "selfcal":
+        return build_selfcal(B, rng)
     if shape == "fusion1":
         T, anchors, imu, lever, per_pose = 1, ANCHORS_8, True, True, 8
     elif shape == "uwb_imu":
@@ -84,10 +87,55 @@ def build_pose64(B, rng, T=64):
     return wb, graphs, ANCH4, T
 
 
+def build_selfcal(B, rng, T=256, A=10):
+    """cfg4: anchor self-calibration. Every node moves (localization.cpp:94-98): A unknown anchors, one
+    tag with T timesteps, A ranges per timestep, smoothness edges along the tag; each instance is one Monte-Carlo
+    hypothesis = a seeded perturbation (sigma 1 m) of the anchor initialisation, held by a weak position prior.
+    Tag poses take slots 0..T-1 (time order), anchors the LAST A slots, so the skyline is an arrowhead."""
+    import localization_amd as la
+    true_anchors = np.column_stack([rng.uniform(-4, 4, A), rng.uniform(-4, 4, A), rng.uniform(0, 3, A)])
+    wb = la.WindowBatch(B, T + A, T * A + T, A, 0)
+    graphs = []
+    tt = np.cumsum(rng.normal(0, 0.05, (T, 3)), axis=0) + np.array([0.0, 0.0, 1.2])
+    d_true = np.linalg.norm(tt[:, None, :] - true_anchors[None], axis=2) + rng.normal(0, 0.03, (T, A))
+    pinfo = np.array([1.0, 1.0, 1.0, 0, 0, 0])
+    for i in range(B):
+        hyp = true_anchors + rng.normal(0, 1.0, true_anchors.shape)
+        et = tt + rng.normal(0, 0.05, tt.shape)
+        g = dict(et=et, hyp=hyp, ranges=[], smooth=[])
+        for k in range(T): wb.add_pose(i, et[k])
+        for a in range(A):
+            wb.add_pose(i, hyp[a]); wb.add_prior(i, T + a, hyp[a], np.eye(3), pinfo)
+        for k in range(T):
+            for a in range(A):
+                d = float(np.float32(d_true[k, a])); wb.add_range(i, k, T + a, d, 1 / 0.055 ** 2); g["ranges"].append((k, a, d))
+            if k: wb.add_range(i, k - 1, k, 0.0, 1 / (5.0 / 32 / 3) ** 2); g["smooth"].append((k - 1, k))
+        graphs.append(g)
+    return wb, graphs, np.zeros((0, 3)), T + A
+
+
+def oracle_selfcal(g, T, A, iters=10):
+    from oracle import oracle as O
+    G = O.Graph()
+    for k in range(T): G.add_vertex(100 + k, g["et"][k])
+    info = np.diag([1.0, 1.0, 1.0, 0, 0, 0])
+    for a in range(A):
+        G.add_vertex(100 + T + a, g["hyp"][a]); G.add_prior_edge(100 + T + a, g["hyp"][a], np.eye(3), info)
+    for (k, a, d) in g["ranges"]: G.add_range_edge(100 + k, 100 + T + a, d, 1 / 0.055 ** 2)
+    for (k0, k1) in g["smooth"]: G.add_range_edge(100 + k0, 100 + k1, 0.0, 1 / (5.0 / 32 / 3) ** 2)
+    G.optimize(iters, O.JAC_NUMERIC_G2O)
+    return np.array([G.estimate(100 + k)[1] for k in range(T + A)])
+
+
 def oracle_time(graphs, anchors, T, n, iters=10):
     from oracle import oracle as O
     t0 = time.perf_counter()
     out = []
+    if graphs and "hyp" in graphs[0]:
+        A = len(graphs[0]["hyp"])
+        for g in graphs[:n]:
+            out.append(oracle_selfcal(g, T - A, A, iters))
+        return time.perf_counter() - t0, np.array(out)
     for g in graphs[:n]:
         G = O.Graph()
         for m, a in enumerate(anchors): G.add_vertex(m, a, fixed=True)
@@ -103,7 +151,7 @@ def oracle_time(graphs, anchors, T, n, iters=10):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--shape", default="uwb_only", choices=["uwb_only", "uwb_imu", "fusion1", "pose64"])
+    ap.add_argument("--shape", default="uwb_only", choices=["uwb_only", "uwb_imu", "fusion1", "pose64", "selfcal"])
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--cpu-n", type=int, default=256)
