@@ -176,3 +176,15 @@ def test_bag_uwb_imu_config(bag):
     j = np.searchsorted(bag["imu_stamp"], rt[k, 0])
     q_pub = Rotation.from_quat(rt[k, 4:8]); q_imu = Rotation.from_quat(bag["imu_q_xyzw"][max(j - 1, 0)])
     assert (q_pub.inv() * q_imu).magnitude() < 0.05
+
+
+def test_fusion_batch_helper_matches_scipy(gold):
+    """og_fusion_batch (the batched config-3 driver used by the GPU fusion tests) against the same scipy minima."""
+    N = gold["b_dist"].shape[0]
+    init = np.zeros((7, N)); init[:3] = gold["b_init_t"].T; init[6] = 1.0
+    imu = np.zeros((1, N, 8)); imu[0, :, :4] = gold["b_imu_q_xyzw"]; imu[0, :, 4:7] = float(gold["b_cov"])
+    pose, chi2, trials, _ = O.fusion_batch(gold["b_anchors"], gold["b_offset"], gold["b_dist"].T[None], gold["b_err"].T[None], imu,
+                                           init, iterations=300, gate=0.0, jac_mode=O.JAC_NUMERIC_G2O)
+    assert np.abs(pose[0, :3].T - gold["b_min_t"]).max() < 2e-6
+    dq = (Rotation.from_quat(pose[0, 3:7].T).inv() * Rotation.from_quat(gold["b_min_q_xyzw"])).magnitude()
+    assert dq.max() < 2e-6
