@@ -150,13 +150,14 @@ def main():
         err_last = torch.from_numpy(np.sqrt(((out_pos[-1].cpu().numpy() - stream["truth_last"].cpu().numpy()) ** 2).sum(axis=0)))
         # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process); they apply
         # to the default launch shape only
-        traffic, traffic_src, f64_flop = None, None, None
+        traffic, traffic_src, f64_flop, issue_slots, issue_ceiling = None, None, None, None, None
         prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(prof) and (B, E) == (65536, 128) and args.jacobian == "analytic":
             try:
                 with open(prof) as f:
                     pj = json.load(f)
                 traffic, traffic_src, f64_flop = pj["hbm_bytes_per_launch"], pj["source"], pj.get("f64_flop_per_launch")
+                issue_slots, issue_ceiling = pj.get("issue_lane_slots_per_launch"), pj.get("measured_issue_ceiling_lane_slots_per_s")
             except Exception:
                 traffic = None
         res = {
@@ -186,6 +187,11 @@ def main():
             res["valu_f64"] = {"achieved_tflops": tf, "peak_tflops": 78.6, "frac": tf / 78.6,
                                "note": "f64 add+mul+2*fma+trans lane-ops per launch (PMC, profiles/) / live kernel time; "
                                        "the kernel is VALU-issue bound at one wave per SIMD, not HBM bound"}
+        if issue_slots and issue_ceiling:
+            rate = issue_slots / (kern_ms_avg * 1e-3)
+            res["valu_issue"] = {"achieved_lane_slots_per_s": rate, "measured_ceiling": issue_ceiling, "frac": rate / issue_ceiling,
+                                 "note": "(VALU + SALU wave-instructions per launch) x 64 lanes (PMC) / live kernel time, against the "
+                                         "measured one-wave-per-SIMD issue ceiling (tools/fp64_probe.hip): what actually bounds this kernel"}
         if not args.no_cpu_baseline and n_gpus == 1:
             res["cpu_baseline"] = cpu_baseline(ANCHORS_8, dist_t, err_t, stream["init"], min(args.cpu_tags, B),
                                                min(args.cpu_epochs, E * total_steps), out_pos, M)
