@@ -2,7 +2,7 @@
 time-ordered range / IMU / pose event stream the node front-end consumes (reference wiring:
 launch/localization_bag_play.launch:12, localization_node.cpp:52-88).
 
-Supports uncompressed and bz2 chunks (lz4 needs a module this image does not have: such bags raise).  Only the message
+Supports uncompressed, bz2 and lz4 chunks (lz4 through the plain-Python frame decoder in lz4frame.py).  Only the message
 types the path uses are decoded: uwb_driver/UwbRange, sensor_msgs/Imu, geometry_msgs/PoseWithCovarianceStamped,
 geometry_msgs/TwistWithCovarianceStamped and any message that starts with Header + geometry_msgs/Pose (Vicon truth).
 """
@@ -10,6 +10,8 @@ import bz2
 import struct
 from dataclasses import dataclass
 from typing import Dict, Iterator, List, Tuple
+
+from . import lz4frame
 
 
 @dataclass
@@ -66,8 +68,11 @@ def read_bag(path) -> Tuple[Dict[int, Connection], List[Tuple[int, float, bytes]
                 chunk = data
             elif comp == b"bz2":
                 chunk = memoryview(bz2.decompress(bytes(data)))
+            elif comp == b"lz4":
+                size = struct.unpack("<I", hdr["size"])[0] if "size" in hdr else None
+                chunk = memoryview(lz4frame.decompress(data, size))
             else:
-                raise NotImplementedError(f"chunk compression {comp!r} (lz4 is not available in this image)")
+                raise NotImplementedError(f"chunk compression {comp!r}")
             for h2, d2 in _records(chunk, 0, len(chunk)):
                 op2 = h2["op"][0]
                 if op2 == 0x07:

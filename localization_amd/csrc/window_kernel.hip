@@ -151,6 +151,9 @@ struct Lds {
     double *diagL, *b, *x, *yrow, *pose, *bak, *rrec, *prec, *srec;
     int *fb, *last, *rowoff;  // per block: first / last connected block; per row: skyline offset
     double* blk; // 6x6 scratch: the diagonal block being factored
+#ifdef LOCAMD_WINDOW_TIMING
+    long long* tim;  // diagnostic build: cycles in (a) segments, (b) block exchange+factor, (c) row finish, back-substitution
+#endif
     // this instance's edge tables, staged from HBM once per launch
     const int32_t *r_idx, *p_idx, *s_idx;
     const double *r_val, *p_val, *s_val;
@@ -455,6 +458,9 @@ __device__ __forceinline__ bool factor_and_solve(const Lds& L, int lane, int n, 
         const int total = nrows + 1;
         double G[6][6], ig[6];
         for (int base = 0; base < total; base += 64) {
+#ifdef LOCAMD_WINDOW_TIMING
+            long long ts0 = clock64();
+#endif
             const int idx = base + lane;
             const bool is_rhs = idx == nrows;
             const int row = is_rhs ? n : c0 + idx;
@@ -490,6 +496,9 @@ __device__ __forceinline__ bool factor_and_solve(const Lds& L, int lane, int n, 
                     }
                 }
             }
+#ifdef LOCAMD_WINDOW_TIMING
+            long long ts1 = clock64();
+#endif
             if (base == 0) {
                 // (b) publish the diagonal block (rows idx 0..5), factor it everywhere
                 if (idx < 6) {
@@ -519,6 +528,9 @@ __device__ __forceinline__ bool factor_and_solve(const Lds& L, int lane, int n, 
                 }
                 if (!ok) return false;  // uniform: every lane factored the same block
             }
+#ifdef LOCAMD_WINDOW_TIMING
+            long long ts2 = clock64();
+#endif
             // (c) finish the rows
             if (part && (is_rhs || idx >= 6)) {
                 double x[6];
@@ -543,9 +555,15 @@ __device__ __forceinline__ bool factor_and_solve(const Lds& L, int lane, int n, 
                     }
                 }
             }
+#ifdef LOCAMD_WINDOW_TIMING
+            if (lane == 0) { const long long ts3 = clock64(); L.tim[0] += ts1 - ts0; L.tim[1] += ts2 - ts1; L.tim[2] += ts3 - ts2; }
+#endif
         }
         __syncthreads();
     }
+#ifdef LOCAMD_WINDOW_TIMING
+    const long long tb0 = clock64();
+#endif
     // back substitution, block rows from the bottom; y (= row n of the factor) is updated in place in LDS
     for (int J = nvb - 1; J >= 0; --J) {
         const int c0 = 6 * J;
@@ -578,6 +596,9 @@ __device__ __forceinline__ bool factor_and_solve(const Lds& L, int lane, int n, 
         }
         __syncthreads();
     }
+#ifdef LOCAMD_WINDOW_TIMING
+    if (lane == 0) L.tim[3] += clock64() - tb0;
+#endif
     return true;
 }
 
@@ -598,6 +619,11 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
     // instance's slice of the HBM workspace (L1/L2-cached), edge tables are read where the caller put them; only the
     // 6x6 exchange block stays in LDS.
     __shared__ double s_blk[36];
+#ifdef LOCAMD_WINDOW_TIMING
+    __shared__ long long s_tim[4];
+    if (lane < 4) s_tim[lane] = 0;
+    L.tim = s_tim;
+#endif
     double* p = GLOBAL_A ? a.workspace + (size_t)inst * window_instance_doubles(c) : lds;
     L.Hs = p; p += nnz_max;
     L.Ls = p; p += nnz_max;
@@ -728,6 +754,7 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
         res[5] = (double)terminated; res[6] = 0.0; res[7] = 0.0;
 #ifdef LOCAMD_WINDOW_TIMING
         res[6] = (double)t_fs * 1e6 + (double)t_ev * 1e-3; res[7] = (double)t_bd * 1e6 + (double)(clock64() - t_start) * 1e-3;
+        res[0] = (double)L.tim[0]; res[1] = (double)L.tim[1]; res[2] = (double)L.tim[2]; res[5] = (double)L.tim[3];
 #endif
     }
 }

@@ -155,10 +155,21 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--cpu-n", type=int, default=256)
+    ap.add_argument("--bw", default="auto", help="'auto' = the widest pose-pose coupling in the batch (what the node front-end passes), "
+                    "'dense' = nv_max - 1, or a number")
     a = ap.parse_args()
     import localization_amd as la
     wb, graphs, anchors, T = build(a.batch, a.shape)
-    solver = la.WindowSolver(anchors, a.batch, *wb.caps, maximum_iteration=10)
+    if a.bw == "auto":
+        bw = 0
+        for b in range(a.batch):
+            nr, ns = int(wb.counts[b, 1]), int(wb.counts[b, 3])
+            r = wb.r_idx[b, :nr]; pp = r[r[:, 1] >= 0]
+            if len(pp): bw = max(bw, int(np.abs(pp[:, 0] - pp[:, 1]).max()))
+            if ns: bw = max(bw, int(np.abs(wb.s_idx[b, :ns, 0] - wb.s_idx[b, :ns, 1]).max()))
+    else:
+        bw = -1 if a.bw == "dense" else int(a.bw)
+    solver = la.WindowSolver(anchors, a.batch, *wb.caps, maximum_iteration=10, bw_max=bw)
     poses0 = wb.poses.copy()
     ms = []
     for r in range(a.reps + 1):
@@ -169,7 +180,7 @@ def main():
     one = la.WindowBatch(1, *wb.caps)
     for name in ("counts", "poses", "r_idx", "r_val", "p_idx", "p_val", "s_idx", "s_val"):
         getattr(one, name)[:] = getattr(wb, name)[:1] if name != "poses" else poses0[:1]
-    s1 = la.WindowSolver(anchors, 1, *wb.caps, maximum_iteration=10)
+    s1 = la.WindowSolver(anchors, 1, *wb.caps, maximum_iteration=10, bw_max=bw)
     lat = []
     for r in range(20):
         one.poses[:] = poses0[:1]
@@ -177,7 +188,7 @@ def main():
     cpu_s, cpu_t = oracle_time(graphs, anchors, T, min(a.cpu_n, a.batch))
     diff = float(np.abs(wb.poses[: len(cpu_t), :, 9:] - cpu_t).max())
     print(json.dumps({
-        "shape": a.shape, "poses_per_window": T, "unknowns": 6 * T, "batch": a.batch, "lds_bytes_per_instance": solver.lds_bytes,
+        "shape": a.shape, "poses_per_window": T, "unknowns": 6 * T, "batch": a.batch, "bw_max": bw, "lds_bytes_per_instance": solver.lds_bytes,
         "gpu_kernel_ms_per_batch": k_ms, "gpu_windows_per_s_kernel": a.batch / (k_ms * 1e-3),
         "gpu_windows_per_s_incl_pcie": a.batch / (w_ms * 1e-3),
         "gpu_single_window_latency_ms_incl_pcie": float(np.median(lat)), "gpu_single_window_kernel_ms": s1.last_kernel_ms(),

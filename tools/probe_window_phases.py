@@ -26,3 +26,5 @@ print(f"{shape}: trials {r[:, 4].mean():.1f} iters {r[:, 3].mean():.1f}; cycles 
       f"factor+solve {fs.mean():.0f} ({(fs / r[:, 4]).mean():.0f}/trial, {100 * fs.mean() / tot.mean():.0f} %); "
       f"trial errors {ev.mean():.0f} ({(ev / r[:, 4]).mean():.0f}/trial, {100 * ev.mean() / tot.mean():.0f} %); "
       f"linearise+build {bd.mean():.0f} ({(bd / r[:, 3]).mean():.0f}/iteration, {100 * bd.mean() / tot.mean():.0f} %)")
+print(f"  inside factor+solve (cycles per solve): (a) band segments {r[:, 0].mean():.0f}, (b) block exchange + 6x6 factor {r[:, 1].mean():.0f}, "
+      f"(c) row finish {r[:, 2].mean():.0f}, back-substitution {r[:, 5].mean():.0f}")
