@@ -17,7 +17,8 @@ import localization_amd as la
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import bench_window as bw
 wb, graphs, anchors, T = bw.build(64, shape)
-s = la.WindowSolver(anchors, 64, *wb.caps, maximum_iteration=10)
+bwm = int(sys.argv[3]) if len(sys.argv) > 3 else -1   # pose band (argv[3]); -1 = dense
+s = la.WindowSolver(anchors, 64, *wb.caps, maximum_iteration=10, bw_max=bwm)
 s.solve(wb)
 r = wb.result
 fs = np.floor(r[:, 6] / 1e6); ev = (r[:, 6] - fs * 1e6) * 1e3
