@@ -16,9 +16,10 @@ _lib._SO = os.path.abspath(so)
 import localization_amd as la
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import bench_window as bw
-wb, graphs, anchors, T = bw.build(64, shape)
+NB = int(sys.argv[4]) if len(sys.argv) > 4 else 64   # instances (argv[4]): 64 = unloaded GPU, thousands = under load
+wb, graphs, anchors, T = bw.build(NB, shape)
 bwm = int(sys.argv[3]) if len(sys.argv) > 3 else -1   # pose band (argv[3]); -1 = dense
-s = la.WindowSolver(anchors, 64, *wb.caps, maximum_iteration=10, bw_max=bwm)
+s = la.WindowSolver(anchors, NB, *wb.caps, maximum_iteration=10, bw_max=bwm)
 s.solve(wb)
 r = wb.result
 fs = np.floor(r[:, 6] / 1e6); ev = (r[:, 6] - fs * 1e6) * 1e3
