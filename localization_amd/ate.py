@@ -7,8 +7,14 @@ run under Python 3.
 import numpy as np
 
 
-def write_tum(path, poses8):
-    """rows: stamp x y z qx qy qz qw  — '%.9f' on the stamp, default float formatting otherwise (localization.cpp:633-641)"""
+def write_tum(path, poses8, header=None):
+    """rows: stamp x y z qx qy qz qw  — '%.9f' on the stamp, default float formatting otherwise (localization.cpp:633-641).
+    Appends, like save_file; with `header` (list of strings) the file is started afresh with '# ' comment lines, like
+    set_file (localization.cpp:647-668)."""
+    if header is not None:
+        with open(path, "w") as f:
+            for h in header:
+                f.write("# " + h + "\n")
     with open(path, "a") as f:
         for p in np.asarray(poses8):
             f.write("%.9f" % p[0] + " " + " ".join("%g" % v for v in p[1:]) + "\n")

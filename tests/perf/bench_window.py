@@ -2,11 +2,11 @@
 """Secondary measurements of the sliding-window path (not the headline bench): windows/s of the general graph kernel
 on synthetic instances in the reference's topology, next to the oracle on one host core.
 
-    python tools/bench_window.py --shape uwb_only   # T = 10, ranges + smoothness        (cfg/uwb_only.yaml shape)
-    python tools/bench_window.py --shape uwb_imu    # T = 12, + IMU priors + lever arm   (cfg/uwb_imu.yaml shape)
-    python tools/bench_window.py --shape fusion1    # 1 pose, 8 ranges + IMU prior       (BASELINE config 3 shape)
-    python tools/bench_window.py --shape selfcal --batch 128   # cfg4 shape: 10 unknown anchors x 256 timesteps per hypothesis
-    python tools/bench_window.py --shape pose64 --batch 1024   # 64-pose window, key-frame EdgeSE3 star + one range per pose
+    python tests/perf/bench_window.py --shape uwb_only   # T = 10, ranges + smoothness        (cfg/uwb_only.yaml shape)
+    python tests/perf/bench_window.py --shape uwb_imu    # T = 12, + IMU priors + lever arm   (cfg/uwb_imu.yaml shape)
+    python tests/perf/bench_window.py --shape fusion1    # 1 pose, 8 ranges + IMU prior       (BASELINE config 3 shape)
+    python tests/perf/bench_window.py --shape selfcal --batch 128   # cfg4 shape: 10 unknown anchors x 256 timesteps per hypothesis
+    python tests/perf/bench_window.py --shape pose64 --batch 1024   # 64-pose window, key-frame EdgeSE3 star + one range per pose
                                                                # (BASELINE config 5 shape; matrix in the HBM workspace)
 """
 import argparse
@@ -18,7 +18,7 @@ import time
 import numpy as np
 from scipy.spatial.transform import Rotation
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 ANCH4 = np.array([[3, -3, 0.58], [3, 3, 1.97], [-3, 3, 0.54], [-3, -3, 1.76]], dtype=float)

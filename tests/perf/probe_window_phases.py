@@ -7,14 +7,14 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 so = sys.argv[1]
 shape = sys.argv[2] if len(sys.argv) > 2 else "uwb_only"
 import localization_amd._lib as _lib
 _lib._SO = os.path.abspath(so)
 import localization_amd as la
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "perf"))
 import bench_window as bw
 NB = int(sys.argv[4]) if len(sys.argv) > 4 else 64   # instances (argv[4]): 64 = unloaded GPU, thousands = under load
 wb, graphs, anchors, T = bw.build(NB, shape)

@@ -288,3 +288,44 @@ def test_node_errors(gpu, bag):
     with pytest.raises(la.LocalizationAmdError):
         la.LocalizationNode(ids, pos, trajectory_length=2000)  # beyond this kernel version (<= 1024 poses)
     node.close()
+
+
+def test_one_command_bag_replay_tool(gpu, bag, tmp_path):
+    """tools/replay_bag.py (the launch-file equivalent: bag + cfg yaml -> node on the GPU -> reference-format logs -> ATE)
+    on a rosbag synthesised from the fixture (lz4 chunks when pyarrow is there): the logged realtime trajectory equals a
+    direct replay through the Python harness, the log format parses as TUM, and the ATE is the bag's usual few cm."""
+    import json
+    import subprocess
+    import sys
+    import localization_amd as la
+    from localization_amd import ate
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _bagwriter import write_bag
+    try:
+        import pyarrow  # noqa: F401
+        compression = "lz4"
+    except ImportError:
+        compression = "bz2"
+    n = 600
+    path = str(tmp_path / "synth.bag")
+    write_bag(path, bag, n_ranges=n, compression=compression)
+    cfg = tmp_path / "uwb_only.yaml"   # the reference profile's solver parameters (cfg/uwb_only.yaml), its /lpsrange topic kept on purpose
+    cfg.write_text("robot:\n  trajectory_length: 10\n  maximum_velocity: 5\n  distance_outlier: 1\n"
+                   "optimizer:\n  maximum_iteration: 10\n  minimum_optimize_error: 2000\n  verbose: false\n"
+                   "topic:\n  range: /lpsrange\npublish_flag:\n  range: true\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "replay_bag.py"), path, str(cfg), "--prefix", str(tmp_path / "run")],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rep = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rep["range_topic"] == "/uwb_endorange_info" and rep["nodes_id"] == [int(i) for i in bag["anchor_ids"]] + [200]
+    logged = ate.read_tum(rep["files"]["realtime"])
+    assert open(rep["files"]["realtime"]).readline().startswith("# iteration_max:10")
+    ids = list(bag["anchor_ids"]) + [200]
+    pos = np.concatenate([bag["anchor_pos"], [[0.0, 0.0, 1.0]]])
+    node = la.LocalizationNode(ids, pos, trajectory_length=10, maximum_velocity=5.0, distance_outlier=1.0, maximum_iteration=10,
+                               minimum_optimize_error=2000.0, publish_range=True)
+    rt, pub, _ = _replay(bag, node, _events(bag, False, n))
+    assert rep["solves"] == len(rt) and rep["published"] == int(pub.sum()) == len(logged)
+    assert np.abs(logged[:, 1:4] - rt[pub.astype(bool), 1:4]).max() < 1e-5   # '%g' keeps 6 significant digits
+    assert rep["ate_realtime"]["pairs"] > 100 and rep["ate_realtime"]["rmse"] < 0.25

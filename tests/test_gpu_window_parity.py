@@ -111,7 +111,7 @@ def test_selfcalibration_arrowhead_graph(gpu):
     import os
     import sys
     import localization_amd as la
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "perf"))
     import bench_window as bw
     rng = np.random.default_rng(3)
     T, A, B = 24, 4, 6
