@@ -149,7 +149,7 @@ __device__ __forceinline__ void quat_right_jac(const double* q, double sgn, doub
 struct Lds {
     double *Hs, *Ls;  // skyline H (lower) and its Cholesky factor (LDS, or an HBM workspace slice for large windows)
     double *diagL, *b, *x, *yrow, *pose, *bak, *rrec, *prec, *srec;
-    int *fb, *last, *rowoff;  // per block: first / last connected block; per row: skyline offset
+    int *fb, *last, *boff;  // per block row: first / last connected block, offset of the block row's storage
     double* blk; // 6x6 scratch: the diagonal block being factored
 #ifdef LOCAMD_WINDOW_TIMING
     long long* tim;  // diagnostic build: cycles in (a) segments, (b) block exchange+factor, (c) row finish, back-substitution
@@ -324,13 +324,16 @@ __device__ __forceinline__ void evaluate_edges(const WindowArgs& a, const Lds& L
 }
 
 // ---- skyline storage ---------------------------------------------------------------------------------------------
-// H (lower triangle) and its Cholesky factor live in SKYLINE form: row i of pose block v keeps columns
-// [6 fb[v], i], fb[v] = the leftmost block v is connected to (itself if none).  Cholesky fill-in never leaves that
+// H (lower triangle) and its Cholesky factor live in SKYLINE form: the six rows of pose block v keep columns
+// [6 fb[v], 6 v + 5], fb[v] = the leftmost block v is connected to (itself if none).  Cholesky fill-in never leaves that
 // envelope, so storage and work are O(n * band^2) instead of O(n^2) / O(n^3): a 500-pose chain (cfg/uwb_pose.yaml) is
-// 3000 rows of ~12 entries.  rowoff[i] = offset of row i, rowoff[n] = nnz.
+// 3000 rows of ~12 entries.  A block row is stored COLUMN-MAJOR (6 rows x its columns): entry (6 v + r, col) sits at
+// boff[v] + 6 (col - 6 fb[v]) + r, so the six lanes working on one block row read one contiguous 48-byte piece per column
+// and a 6-column step of the sweep touches 288 contiguous bytes per block row (it was six separate row segments);
+// the back-substitution's per-column reads are contiguous across lanes.  boff[nv] = stored entries.
 __host__ __device__ inline size_t sky_nnz_bound(int nv, int bw) {
     size_t s = 0;
-    for (int v = 0; v < nv; ++v) s += 36 * (size_t)(v < bw ? v : bw) + 21;
+    for (int v = 0; v < nv; ++v) s += 36 * ((size_t)(v < bw ? v : bw) + 1);
     return s;
 }
 
@@ -342,7 +345,7 @@ __host__ __device__ inline size_t window_instance_doubles(const WindowCaps& c) {
            (size_t)c.ns_max * SREC + 2 * (((size_t)c.nv_max + 1) / 2) + (n_max + 2) / 2;
 }
 
-// Once per solve (the topology does not change between iterations): fb[], last[], rowoff[].
+// Once per solve (the topology does not change between iterations): fb[], last[], boff[].
 __device__ __forceinline__ void compute_skyline(const Lds& L, int lane, int n, int nr, int ns) {
     const int nv = n / 6;
     if (lane == 0) {
@@ -359,19 +362,21 @@ __device__ __forceinline__ void compute_skyline(const Lds& L, int lane, int n, i
         // last[J] = last block whose envelope reaches block column J
         for (int v = 0; v < nv; ++v) for (int J = L.fb[v]; J <= v; ++J) L.last[J] = max(L.last[J], v);
         int off = 0;
-        for (int v = 0; v < nv; ++v)
-            for (int r = 0; r < 6; ++r) { L.rowoff[v * 6 + r] = off; off += 6 * (v - L.fb[v]) + r + 1; }
-        L.rowoff[n] = off;
+        for (int v = 0; v < nv; ++v) { L.boff[v] = off; off += 36 * (v - L.fb[v] + 1); }
+        L.boff[nv] = off;
     }
     __syncthreads();
 }
 // address of H/L entry (row, col), col <= row, col inside row's envelope
-__device__ __forceinline__ int sky(const Lds& L, int row, int col) { return L.rowoff[row] + col - 6 * L.fb[row / 6]; }
+__device__ __forceinline__ int sky(const Lds& L, int row, int col) {
+    const int v = row / 6;
+    return L.boff[v] + 6 * (col - 6 * L.fb[v]) + (row - 6 * v);
+}
 
 // Fold the edge records into H (skyline lower triangle) and b, one edge after the other (fixed order: bit-reproducible).
 __device__ __forceinline__ void build_system(const WindowArgs& a, const Lds& L, int inst, int lane, int n, int nr, int np, int ns) {
     (void)a; (void)inst;
-    const int nnz = L.rowoff[n];
+    const int nnz = L.boff[n / 6];
     for (int i = lane; i < nnz; i += 64) L.Hs[i] = 0.0;
     for (int i = lane; i < n; i += 64) L.b[i] = 0.0;
     __syncthreads();
@@ -466,7 +471,10 @@ __device__ __forceinline__ bool factor_and_solve(const Lds& L, int lane, int n, 
             const int row = is_rhs ? n : c0 + idx;
             const int fbi = (is_rhs || idx > nrows) ? 0 : L.fb[row / 6];
             const bool part = (idx < total) && (is_rhs || fbi <= J);
-            const int roff = part && !is_rhs ? L.rowoff[row] - 6 * fbi : 0;  // row's skyline base: entry (row, col) at roff + col
+            // a matrix row's base and stride: entry (row, col) at roff + rs * col (the rhs row is a plain vector: stride 1)
+            const int roff = part && !is_rhs ? L.boff[row / 6] - 36 * fbi + row % 6 : 0;
+            const int rs = is_rhs ? 1 : 6;
+            const int jb = L.boff[J] - 36 * fJ;  // block row J: entry (c0 + c, col) at jb + 6 col + c
             double S[6];
 #pragma unroll
             for (int c = 0; c < 6; ++c) S[c] = 0.0;
@@ -476,22 +484,22 @@ __device__ __forceinline__ bool factor_and_solve(const Lds& L, int lane, int n, 
                     const int col = c0 + c;
                     double v;
                     if (is_rhs) v = L.b[col];
-                    else if (col <= row) v = L.Hs[roff + col];
-                    else v = L.Hs[L.rowoff[col] - 6 * fJ + row];  // symmetric entry inside the diagonal block
+                    else if (col <= row) v = L.Hs[roff + 6 * col];
+                    else v = L.Hs[jb + 6 * row + c];  // symmetric entry inside the diagonal block
                     if (row == col) v += lambda;
                     S[c] = v;
                 }
-                const double* ri = is_rhs ? L.yrow : L.Ls + roff;
+                const double* ri = is_rhs ? L.yrow : L.Ls;
                 for (int K = (fJ > fbi ? fJ : fbi); K < J; ++K) {
                     double li[6];
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) li[k] = ri[6 * K + k];
+                    for (int k = 0; k < 6; ++k) li[k] = ri[roff + rs * (6 * K + k)];
+                    const double* rj = L.Ls + jb + 36 * K;  // the 6x6 block (rows c0.., columns 6K..) is contiguous: [k][c]
 #pragma unroll
                     for (int c = 0; c < 6; ++c) {
-                        const double* rj = L.Ls + L.rowoff[c0 + c] - 6 * fJ + 6 * K;
                         double acc = 0.0;
 #pragma unroll
-                        for (int k = 0; k < 6; ++k) acc = __builtin_fma(li[k], rj[k], acc);
+                        for (int k = 0; k < 6; ++k) acc = __builtin_fma(li[k], rj[6 * k + c], acc);
                         S[c] -= acc;
                     }
                 }
@@ -541,16 +549,16 @@ __device__ __forceinline__ bool factor_and_solve(const Lds& L, int lane, int n, 
                     for (int k = 0; k < c; ++k) v = __builtin_fma(-x[k], G[c][k], v);
                     x[c] = v * ig[c];
                 }
-                double* dst = is_rhs ? L.yrow + c0 : L.Ls + roff + c0;
+                double* dst = is_rhs ? L.yrow : L.Ls;
 #pragma unroll
-                for (int c = 0; c < 6; ++c) dst[c] = x[c];
+                for (int c = 0; c < 6; ++c) dst[roff + rs * (c0 + c)] = x[c];
             } else if (base == 0 && idx < 6) {
                 // (static indices only: a runtime row index would push G into scratch memory)
 #pragma unroll
                 for (int rr = 0; rr < 6; ++rr) {
                     if (idx == rr) {
 #pragma unroll
-                        for (int c = 0; c < rr; ++c) L.Ls[roff + c0 + c] = G[rr][c];
+                        for (int c = 0; c < rr; ++c) L.Ls[roff + 6 * (c0 + c)] = G[rr][c];
                         L.diagL[row] = ig[rr];  // the INVERSE pivot: back-substitution multiplies
                     }
                 }
@@ -568,6 +576,7 @@ __device__ __forceinline__ bool factor_and_solve(const Lds& L, int lane, int n, 
     for (int J = nvb - 1; J >= 0; --J) {
         const int c0 = 6 * J;
         const int fJ6 = 6 * L.fb[J];
+        const int jb = L.boff[J] - 6 * fJ6;  // block row J: entry (c0 + c, col) at jb + 6 col + c
         double yj[6], x[6], G[6][6], igd[6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) yj[c] = L.yrow[c0 + c];
@@ -575,7 +584,7 @@ __device__ __forceinline__ bool factor_and_solve(const Lds& L, int lane, int n, 
         for (int rr = 0; rr < 6; ++rr) {
             igd[rr] = L.diagL[c0 + rr];
 #pragma unroll
-            for (int c = 0; c < rr; ++c) G[rr][c] = L.Ls[L.rowoff[c0 + rr] - fJ6 + c0 + c];
+            for (int c = 0; c < rr; ++c) G[rr][c] = L.Ls[jb + 6 * (c0 + c) + rr];
         }
 #pragma unroll
         for (int rr = 5; rr >= 0; --rr) {
@@ -591,7 +600,7 @@ __device__ __forceinline__ bool factor_and_solve(const Lds& L, int lane, int n, 
         for (int k = fJ6 + lane; k < c0; k += 64) {
             double acc = L.yrow[k];
 #pragma unroll
-            for (int c = 0; c < 6; ++c) acc = __builtin_fma(-L.Ls[L.rowoff[c0 + c] - fJ6 + k], x[c], acc);
+            for (int c = 0; c < 6; ++c) acc = __builtin_fma(-L.Ls[jb + 6 * k + c], x[c], acc);
             L.yrow[k] = acc;
         }
         __syncthreads();
@@ -639,7 +648,7 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
     L.srec = p; p += c.ns_max * SREC;
     L.fb = reinterpret_cast<int*>(p); p += (c.nv_max + 1) / 2;
     L.last = reinterpret_cast<int*>(p); p += (c.nv_max + 1) / 2;
-    L.rowoff = reinterpret_cast<int*>(p); p += (n_max + 2) / 2;
+    L.boff = reinterpret_cast<int*>(p); p += (n_max + 2) / 2;
     double* gpose = a.poses + (size_t)inst * c.nv_max * 12;
     for (int i = lane; i < nv * 12; i += 64) L.pose[i] = gpose[i];
     if (GLOBAL_A) {
