@@ -49,6 +49,25 @@ def cpu_baseline(anchors, dist_tiles, err_tiles, init, n_tags, n_epochs, gpu_pos
     return out
 
 
+def host_core_share(cap=16):
+    """Cores this process may really use: the affinity mask, cut to the cgroup CPU quota when one is set, and never more
+    than `cap` — a GPU box shows the whole host's cores in its affinity mask but gives one GPU's job a 16-core share."""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                n = min(n, max(1, int(float(quota) / period)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(n, cap))
+
+
 def cpu_baseline_all_cores(anchors, dist_tiles, err_tiles, init, tags_per_core, n_epochs, M):
     """the same oracle with a static split of the tags over every host core this process may use
     (one single-threaded worker process per core, oracle/parallel.py) — the fair throughput baseline.  The reference
@@ -56,7 +75,7 @@ def cpu_baseline_all_cores(anchors, dist_tiles, err_tiles, init, tags_per_core, 
     from localization_amd.snapshot import unpack_ranges
     from oracle import oracle as O
     from oracle.parallel import snapshot_batch_all_cores
-    cores = len(os.sched_getaffinity(0))
+    cores = host_core_share()
     n_tags = min(tags_per_core * cores, dist_tiles.shape[2])
     d = unpack_ranges(dist_tiles[:n_epochs, :, :n_tags, :].cpu().numpy(), M)
     e = unpack_ranges(err_tiles[:n_epochs, :, :n_tags, :].cpu().numpy(), M)
