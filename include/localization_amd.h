@@ -108,6 +108,19 @@ int loc_snapshot_solve_host(loc_snapshot* s, int32_t epochs, const float* dist_t
                             const float* err_tiles_host, double* out_pos_host, double* out_chi2_host,
                             uint8_t* out_trials_host);
 
+/* The batched mirror of the reference's per-message callback for callers that hold plain host arrays
+ * (SURVEY.md 8(b) `batch_push_ranges` + `batch_solve` + `batch_get_positions`): distance / distance_err as
+ * [K][M][B] float32 (epoch, anchor, tag — what K rounds of addRangeEdge, localization.cpp:297-376, would have been fed),
+ * outputs [K][3][B] / [K][B].  Copy-in, tile packing + solve, and copy-out run as a chunked three-stream pipeline, so the
+ * call costs about max(PCIe in, solve, PCIe out) rather than their sum — when the host buffers are page-locked
+ * (loc_host_alloc); with pageable memory the result is the same, the copies just do not overlap.  Synchronous. */
+int loc_snapshot_solve_host_kmb(loc_snapshot* s, int32_t epochs, const float* dist_kmb_host, const float* err_kmb_host,
+                                double* out_pos_host, double* out_chi2_host, uint8_t* out_trials_host);
+
+/* Page-locked host memory for the host paths above (hipHostMalloc / hipHostFree). */
+int loc_host_alloc(void** out, size_t bytes);
+int loc_host_free(void* p);
+
 /* HIP-event timing of the solve kernel on the stream it is launched on (bench.py's roofline leg).
  * loc_snapshot_timing_begin() arms per-launch event pairs; _end() synchronises and returns the number of
  * timed launches, their total and average duration in milliseconds. */

@@ -35,6 +35,7 @@ EXPORTED_SYMBOLS = [
     "loc_snapshot_set_positions", "loc_snapshot_get_positions", "loc_snapshot_positions_device",
     "loc_snapshot_epochs_done", "loc_snapshot_set_epochs_done",
     "loc_snapshot_pack_ranges_host", "loc_snapshot_solve_device", "loc_snapshot_solve_host",
+    "loc_snapshot_solve_host_kmb", "loc_host_alloc", "loc_host_free",
     "loc_snapshot_timing_begin", "loc_snapshot_timing_end",
     "loc_window_create", "loc_window_destroy", "loc_window_set_anchors", "loc_window_lds_bytes", "loc_window_solve_host",
     "loc_window_last_kernel_ms",
@@ -75,6 +76,9 @@ def lib():
     L.loc_snapshot_pack_ranges_host.argtypes = [vp, C.c_int32, fp, fp, C.c_float]
     L.loc_snapshot_solve_device.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp]
     L.loc_snapshot_solve_host.argtypes = [vp, C.c_int32, fp, fp, dp, dp, C.POINTER(C.c_uint8)]
+    L.loc_snapshot_solve_host_kmb.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp]
+    L.loc_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
+    L.loc_host_free.argtypes = [vp]
     L.loc_snapshot_timing_begin.argtypes = [vp, C.c_int32]
     L.loc_snapshot_timing_end.argtypes = [vp, C.POINTER(C.c_int32), dp, dp]
     ip = C.POINTER(C.c_int32)

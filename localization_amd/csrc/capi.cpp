@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -51,6 +52,11 @@ struct loc_snapshot {
     uint8_t* d_out_trials = nullptr;
     int staged_epochs = 0;
     long long epochs_done = 0;
+    // pipelined host path (loc_snapshot_solve_host_kmb): raw [K][M][B] staging, copy streams, per-chunk events
+    float *d_raw_dist = nullptr, *d_raw_err = nullptr;
+    int raw_epochs = 0;
+    hipStream_t in_stream = nullptr, out_stream = nullptr;
+    std::vector<hipEvent_t> pipe_ev;
     // timing
     std::vector<hipEvent_t> ev;
     int ev_used = 0;
@@ -128,12 +134,29 @@ static void free_staging(loc_snapshot* s) {
     s->d_dist = s->d_err = nullptr; s->d_out_pos = s->d_out_chi2 = nullptr; s->d_out_trials = nullptr;
     s->staged_epochs = 0;
 }
+static int ensure_staging(loc_snapshot* s, int32_t epochs) {
+    if (epochs <= s->staged_epochs) return LOC_OK;
+    const size_t nf = loc_snapshot_range_floats(s, epochs), B = (size_t)s->B;
+    free_staging(s);
+    LOC_HIP(hipMalloc((void**)&s->d_dist, nf * sizeof(float)));
+    LOC_HIP(hipMalloc((void**)&s->d_err, nf * sizeof(float)));
+    LOC_HIP(hipMalloc((void**)&s->d_out_pos, sizeof(double) * 3 * B * (size_t)epochs));
+    LOC_HIP(hipMalloc((void**)&s->d_out_chi2, sizeof(double) * B * (size_t)epochs));
+    LOC_HIP(hipMalloc((void**)&s->d_out_trials, B * (size_t)epochs));
+    s->staged_epochs = epochs;
+    return LOC_OK;
+}
 
 int loc_snapshot_destroy(loc_snapshot* s) {
     if (!s) return LOC_OK;
     (void)hipSetDevice(s->device);
     free_staging(s);
     for (hipEvent_t ev : s->ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : s->pipe_ev) (void)hipEventDestroy(ev);
+    if (s->d_raw_dist) (void)hipFree(s->d_raw_dist);
+    if (s->d_raw_err) (void)hipFree(s->d_raw_err);
+    if (s->in_stream) (void)hipStreamDestroy(s->in_stream);
+    if (s->out_stream) (void)hipStreamDestroy(s->out_stream);
     if (s->d_anchors) (void)hipFree(s->d_anchors);
     if (s->d_pos) (void)hipFree(s->d_pos);
     if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
@@ -219,15 +242,7 @@ int loc_snapshot_solve_host(loc_snapshot* s, int32_t epochs, const float* dist_h
     LOC_HIP(hipSetDevice(s->device));
     const size_t nf = loc_snapshot_range_floats(s, epochs);
     const size_t B = (size_t)s->B;
-    if (epochs > s->staged_epochs) {
-        free_staging(s);
-        LOC_HIP(hipMalloc((void**)&s->d_dist, nf * sizeof(float)));
-        LOC_HIP(hipMalloc((void**)&s->d_err, nf * sizeof(float)));
-        LOC_HIP(hipMalloc((void**)&s->d_out_pos, sizeof(double) * 3 * B * (size_t)epochs));
-        LOC_HIP(hipMalloc((void**)&s->d_out_chi2, sizeof(double) * B * (size_t)epochs));
-        LOC_HIP(hipMalloc((void**)&s->d_out_trials, B * (size_t)epochs));
-        s->staged_epochs = epochs;
-    }
+    if (int rc = ensure_staging(s, epochs)) return rc;
     LOC_HIP(hipMemcpyAsync(s->d_dist, dist_h, nf * sizeof(float), hipMemcpyHostToDevice, s->own_stream));
     LOC_HIP(hipMemcpyAsync(s->d_err, err_h, nf * sizeof(float), hipMemcpyHostToDevice, s->own_stream));
     int rc = loc_snapshot_solve_device(s, epochs, s->d_dist, s->d_err, s->d_out_pos, s->d_out_chi2, s->d_out_trials, s->own_stream);
@@ -236,6 +251,75 @@ int loc_snapshot_solve_host(loc_snapshot* s, int32_t epochs, const float* dist_h
     LOC_HIP(hipMemcpyAsync(out_chi2_h, s->d_out_chi2, sizeof(double) * B * (size_t)epochs, hipMemcpyDeviceToHost, s->own_stream));
     if (out_trials_h) LOC_HIP(hipMemcpyAsync(out_trials_h, s->d_out_trials, B * (size_t)epochs, hipMemcpyDeviceToHost, s->own_stream));
     LOC_HIP(hipStreamSynchronize(s->own_stream));
+    return LOC_OK;
+}
+
+int loc_snapshot_solve_host_kmb(loc_snapshot* s, int32_t epochs, const float* dist_kmb, const float* err_kmb,
+                                double* out_pos_h, double* out_chi2_h, uint8_t* out_trials_h) {
+    if (!s) return fail(LOC_ERR_INVALID, "null handle");
+    if (epochs <= 0 || !dist_kmb || !err_kmb || !out_pos_h || !out_chi2_h) return fail(LOC_ERR_INVALID, "solve arguments");
+    LOC_HIP(hipSetDevice(s->device));
+    const size_t B = (size_t)s->B, M = (size_t)s->M, M4 = (size_t)s->M4;
+    if (int rc = ensure_staging(s, epochs)) return rc;
+    if (epochs > s->raw_epochs) {
+        if (s->d_raw_dist) (void)hipFree(s->d_raw_dist);
+        if (s->d_raw_err) (void)hipFree(s->d_raw_err);
+        s->d_raw_dist = s->d_raw_err = nullptr; s->raw_epochs = 0;
+        LOC_HIP(hipMalloc((void**)&s->d_raw_dist, sizeof(float) * M * B * (size_t)epochs));
+        LOC_HIP(hipMalloc((void**)&s->d_raw_err, sizeof(float) * M * B * (size_t)epochs));
+        s->raw_epochs = epochs;
+    }
+    if (!s->in_stream) LOC_HIP(hipStreamCreateWithFlags(&s->in_stream, hipStreamNonBlocking));
+    if (!s->out_stream) LOC_HIP(hipStreamCreateWithFlags(&s->out_stream, hipStreamNonBlocking));
+    // chunks of ~8 MB per input array: small enough that copy-in, solve and copy-out of neighbouring chunks overlap,
+    // large enough that a chunk's launch fills the GPU (epochs of one chunk stay sequential per tag inside the kernel)
+    // (pageable buffers cannot overlap anyway — the runtime stages them synchronously — so they go as one chunk)
+    auto pinned = [](const void* p) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return at.type == hipMemoryTypeHost;
+    };
+    const bool overlap = pinned(dist_kmb) && pinned(err_kmb) && pinned(out_pos_h) && pinned(out_chi2_h);
+    const int ce = overlap ? (int)std::max<size_t>(1, (8u << 20) / (M * B * sizeof(float))) : epochs;
+    const int nchunks = (epochs + ce - 1) / ce;
+    while ((int)s->pipe_ev.size() < 2 * nchunks) {
+        hipEvent_t ev;
+        LOC_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        s->pipe_ev.push_back(ev);
+    }
+    for (int c = 0; c < nchunks; ++c) {
+        const int k0 = c * ce, kc = std::min(ce, epochs - k0);
+        const size_t roff = (size_t)k0 * M * B, rn = (size_t)kc * M * B, toff = (size_t)k0 * M4 * B * 4;
+        LOC_HIP(hipMemcpyAsync(s->d_raw_dist + roff, dist_kmb + roff, rn * sizeof(float), hipMemcpyHostToDevice, s->in_stream));
+        LOC_HIP(hipMemcpyAsync(s->d_raw_err + roff, err_kmb + roff, rn * sizeof(float), hipMemcpyHostToDevice, s->in_stream));
+        LOC_HIP(hipEventRecord(s->pipe_ev[2 * c], s->in_stream));
+        LOC_HIP(hipStreamWaitEvent(s->own_stream, s->pipe_ev[2 * c], 0));
+        hipError_t e = locamd::launch_pack_kmb(s->d_raw_dist + roff, s->d_dist + toff, s->B, s->M, s->M4, kc, 0.f, s->own_stream);
+        if (e == hipSuccess) e = locamd::launch_pack_kmb(s->d_raw_err + roff, s->d_err + toff, s->B, s->M, s->M4, kc, 0.f, s->own_stream);
+        if (e != hipSuccess) return fail_hip(e, "launch_pack_kmb");
+        int rc = loc_snapshot_solve_device(s, kc, s->d_dist + toff, s->d_err + toff, s->d_out_pos + (size_t)k0 * 3 * B,
+                                           s->d_out_chi2 + (size_t)k0 * B, s->d_out_trials + (size_t)k0 * B, s->own_stream);
+        if (rc != LOC_OK) return rc;
+        LOC_HIP(hipEventRecord(s->pipe_ev[2 * c + 1], s->own_stream));
+        LOC_HIP(hipStreamWaitEvent(s->out_stream, s->pipe_ev[2 * c + 1], 0));
+        LOC_HIP(hipMemcpyAsync(out_pos_h + (size_t)k0 * 3 * B, s->d_out_pos + (size_t)k0 * 3 * B, sizeof(double) * 3 * B * (size_t)kc, hipMemcpyDeviceToHost, s->out_stream));
+        LOC_HIP(hipMemcpyAsync(out_chi2_h + (size_t)k0 * B, s->d_out_chi2 + (size_t)k0 * B, sizeof(double) * B * (size_t)kc, hipMemcpyDeviceToHost, s->out_stream));
+        if (out_trials_h) LOC_HIP(hipMemcpyAsync(out_trials_h + (size_t)k0 * B, s->d_out_trials + (size_t)k0 * B, B * (size_t)kc, hipMemcpyDeviceToHost, s->out_stream));
+    }
+    LOC_HIP(hipStreamSynchronize(s->out_stream));
+    LOC_HIP(hipStreamSynchronize(s->own_stream));
+    return LOC_OK;
+}
+
+int loc_host_alloc(void** out, size_t bytes) {
+    if (!out || bytes == 0) return fail(LOC_ERR_INVALID, "loc_host_alloc");
+    *out = nullptr;
+    LOC_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return LOC_OK;
+}
+int loc_host_free(void* p) {
+    if (!p) return LOC_OK;
+    LOC_HIP(hipHostFree(p));
     return LOC_OK;
 }
 

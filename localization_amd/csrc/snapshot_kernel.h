@@ -25,5 +25,8 @@ struct SnapshotArgs {
 hipError_t launch_snapshot(const SnapshotArgs& a, int m_pad, int lpi, int jac, int block_threads, hipStream_t stream);
 // true if a kernel exists for this combination
 bool snapshot_supported(int m_pad, int lpi);
+// [K][M][B] float (anchor-major SoA, the layout a host caller naturally holds) -> float4 tiles [K][M4][B][4], slots
+// m >= M filled with `pad`.  HBM-bound transpose, one float4 store per thread.
+hipError_t launch_pack_kmb(const float* src_kmb, float* dst_tiles, long long B, int M, int M4, int K, float pad, hipStream_t stream);
 
 }  // namespace locamd

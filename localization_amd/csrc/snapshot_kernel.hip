@@ -427,6 +427,33 @@ hipError_t launch_jac(const SnapshotArgs& a, int jac, int block_threads, hipStre
 
 }  // namespace
 
+namespace {
+__global__ void __launch_bounds__(256) pack_kmb_kernel(const float* __restrict__ src, float4* __restrict__ dst, long long B, int M, int M4,
+                                                       long long total, float pad) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // (k, g, b), b fastest: reads and stores are coalesced
+    if (i >= total) return;
+    const long long b = i % B, kg = i / B;
+    const int g = (int)(kg % M4);
+    const long long k = kg / M4;
+    const float* row = src + (k * M + 4 * g) * B + b;
+    float4 v;
+    v.x = 4 * g + 0 < M ? row[0] : pad;
+    v.y = 4 * g + 1 < M ? row[B] : pad;
+    v.z = 4 * g + 2 < M ? row[2 * B] : pad;
+    v.w = 4 * g + 3 < M ? row[3 * B] : pad;
+    dst[i] = v;
+}
+}  // namespace
+
+hipError_t launch_pack_kmb(const float* src_kmb, float* dst_tiles, long long B, int M, int M4, int K, float pad, hipStream_t stream) {
+    const long long total = (long long)K * M4 * B;
+    if (total <= 0 || M <= 0 || M > 4 * M4) return hipErrorInvalidValue;
+    const long long blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pack_kmb_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src_kmb, reinterpret_cast<float4*>(dst_tiles), B, M, M4, total, pad);
+    return hipGetLastError();
+}
+
 bool snapshot_supported(int m_pad, int lpi) {
     if (lpi != 1 && lpi != 2 && lpi != 4 && lpi != 8) return false;
     if (m_pad != 4 && m_pad != 8 && m_pad != 12 && m_pad != 16) return false;

@@ -59,11 +59,15 @@ class SnapshotSolver:
                                     anchors.ctypes.data_as(C.POINTER(C.c_double)), C.byref(prm)))
         self.h = h
         self.L = L
+        self._pinned = []
         self.M4 = L.loc_snapshot_anchor_groups(h)
         self.lanes_per_instance = L.loc_snapshot_lanes_per_instance(h)
 
     def close(self):
         if getattr(self, "h", None):
+            for p in getattr(self, "_pinned", []):
+                self.L.loc_host_free(p)
+            self._pinned = []
             self.L.loc_snapshot_destroy(self.h)
             self.h = None
 
@@ -128,6 +132,28 @@ class SnapshotSolver:
                                              out_chi2.ctypes.data_as(C.POINTER(C.c_double)),
                                              trials.ctypes.data_as(C.POINTER(C.c_uint8))))
         return out_pos, out_chi2, trials
+
+    def pinned(self, shape, dtype):
+        """A page-locked numpy array (loc_host_alloc); freed when the solver is closed."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        check(self.L.loc_host_alloc(C.byref(p), n))
+        self._pinned.append(p)
+        return np.frombuffer((C.c_char * n).from_address(p.value), dtype=dtype).reshape(shape)
+
+    def solve_stream(self, dist_kmb, err_kmb, out=None):
+        """The pipelined host path (loc_snapshot_solve_host_kmb): [K][M][B] float32 host arrays in their natural layout,
+        packed into tiles on the GPU, copy-in / solve / copy-out overlapped.  `out` = (pos, chi2, trials) to reuse
+        (e.g. pinned) output arrays."""
+        d = np.ascontiguousarray(dist_kmb, dtype=np.float32); e = np.ascontiguousarray(err_kmb, dtype=np.float32)
+        K = d.shape[0]
+        assert d.shape == (K, self.M, self.B) and e.shape == d.shape
+        if out is None:
+            out = (np.empty((K, 3, self.B)), np.empty((K, self.B)), np.empty((K, self.B), dtype=np.uint8))
+        pos, chi2, trials = out
+        assert pos.shape == (K, 3, self.B) and pos.dtype == np.float64 and chi2.shape == (K, self.B) and trials.shape == (K, self.B)
+        check(self.L.loc_snapshot_solve_host_kmb(self.h, K, d.ctypes.data, e.ctypes.data, pos.ctypes.data, chi2.ctypes.data, trials.ctypes.data))
+        return pos, chi2, trials
 
     # ---- HIP-event kernel timing -------------------------------------------------------------------
     def timing_begin(self, max_launches):

@@ -188,3 +188,32 @@ def test_device_resident_path_and_timing(gpu):
     e = ((out_pos[-1] - s["truth_last"]) ** 2).sum(dim=0).sqrt()
     assert float(e.median()) < 0.1 and float((e > 0.5).double().mean()) < 0.02
     solver.close(); host.close()
+
+
+@pytest.mark.parametrize("B,K,M", [(1000, 7, 8), (65536, 9, 8), (4096, 5, 5)])
+def test_pipelined_host_path_equals_the_staged_one(gpu, B, K, M):
+    """loc_snapshot_solve_host_kmb (natural [K][M][B] layout, packed on the GPU, chunked three-stream pipeline, pinned or
+    pageable buffers) returns bit-identical positions, chi2 and trial counts to loc_snapshot_solve_host on host-packed
+    tiles — including the warm-up epoch's un-gated solve when a chunk boundary falls after it, a ragged last chunk and
+    an anchor count that needs padding."""
+    import localization_amd as la
+    from localization_amd.synthetic import ANCHORS_8, make_snapshot_stream
+    s = make_snapshot_stream(B, K, seed=3)
+    anchors = ANCHORS_8[:M]
+    dist, err = s["dist"][:, :M], s["err"][:, :M]
+    a = la.SnapshotSolver(anchors, B, maximum_iteration=10, distance_outlier=1.0)
+    a.set_positions(s["init"])
+    ref = a.solve(dist, err)
+    b = la.SnapshotSolver(anchors, B, maximum_iteration=10, distance_outlier=1.0)
+    b.set_positions(s["init"])
+    got = b.solve_stream(dist, err)
+    for x, y in zip(ref, got):
+        assert np.array_equal(x, y)
+    assert np.array_equal(a.get_positions(), b.get_positions())
+    pd = b.pinned(dist.shape, np.float32); pe = b.pinned(err.shape, np.float32)
+    pd[:] = dist; pe[:] = err
+    b.set_positions(s["init"])
+    got2 = b.solve_stream(pd, pe, (b.pinned((K, 3, B), np.float64), b.pinned((K, B), np.float64), b.pinned((K, B), np.uint8)))
+    for x, y in zip(ref, got2):
+        assert np.array_equal(x, y)
+    a.close(); b.close()
