@@ -82,7 +82,10 @@ def decompress(data, expected_size=None) -> bytes:
         if raw:
             out += block
         else:
-            decode_block(block, out)
+            try:
+                decode_block(block, out)
+            except IndexError:
+                raise ValueError("lz4: block ends inside a sequence") from None
     if content_checksum:
         if pos + 4 > len(data):
             raise ValueError("lz4: truncated content checksum")

@@ -117,6 +117,10 @@ def test_lz4_frame_decoder():
         lz4frame.decompress(pa.compress(b"abc" * 100, codec="lz4", asbytes=True)[:-6], 300)
     with pytest.raises(ValueError):
         lz4frame.decompress(b"\x00" * 16)
+    good = bytearray(pa.compress(b"abcabcabc" * 1000, codec="lz4", asbytes=True))
+    for cut in range(8, len(good) - 1, 3):      # every truncation is reported as ValueError, never an IndexError or a hang
+        with pytest.raises(ValueError):
+            lz4frame.decompress(bytes(good[:cut]), 9000)
 
 
 def test_lz4_chunks_are_read(tmp_path):
