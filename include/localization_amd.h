@@ -263,6 +263,10 @@ int loc_fusion_solve_device(loc_fusion* f, int32_t epochs, const float* dist_dev
                             double* out_pose_dev, double* out_chi2_dev, uint8_t* out_trials_dev, void* hip_stream);
 int loc_fusion_solve_host(loc_fusion* f, int32_t epochs, const float* dist_tiles_host, const float* err_tiles_host,
                           const double* imu_host, double* out_pose_host, double* out_chi2_host, uint8_t* out_trials_host);
+/* Host arrays in their natural layout: dist/err [K][M][B] float32, imu [K][B][8]; tiles are packed on the GPU and the call
+ * is pipelined like loc_snapshot_solve_host_kmb (page-locked buffers from loc_host_alloc overlap the copies). */
+int loc_fusion_solve_host_kmb(loc_fusion* f, int32_t epochs, const float* dist_kmb_host, const float* err_kmb_host,
+                              const double* imu_host, double* out_pose_host, double* out_chi2_host, uint8_t* out_trials_host);
 int loc_fusion_last_kernel_ms(loc_fusion* f, double* ms);
 
 #ifdef __cplusplus

@@ -43,7 +43,7 @@ EXPORTED_SYMBOLS = [
     "loc_node_add_pose", "loc_node_add_twist", "loc_node_add_lidar", "loc_node_solve", "loc_node_get_path",
     "loc_node_number_measurements", "loc_node_set_deferred", "loc_node_solve_pending", "loc_nodes_solve_batch",
     "loc_fusion_default_params", "loc_fusion_create", "loc_fusion_destroy", "loc_fusion_set_poses", "loc_fusion_get_poses",
-    "loc_fusion_solve_device", "loc_fusion_solve_host", "loc_fusion_last_kernel_ms",
+    "loc_fusion_solve_device", "loc_fusion_solve_host", "loc_fusion_solve_host_kmb", "loc_fusion_last_kernel_ms",
 ]
 
 

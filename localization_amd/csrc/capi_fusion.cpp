@@ -3,11 +3,13 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <vector>
 
 #include "fusion_kernel.h"
+#include "snapshot_kernel.h"  // launch_pack_kmb
 
 extern int locamd_fail(int code, const char* what);
 extern int locamd_fail_hip(hipError_t e, const char* where);
@@ -32,7 +34,14 @@ struct loc_fusion {
     double *d_imu = nullptr, *d_out_pose = nullptr, *d_out_chi2 = nullptr;
     uint8_t* d_out_trials = nullptr;
     int staged = 0;
+    // pipelined host path (loc_fusion_solve_host_kmb)
+    float *d_raw_dist = nullptr, *d_raw_err = nullptr;
+    int raw_epochs = 0;
+    hipStream_t in_stream = nullptr, out_stream = nullptr;
+    std::vector<hipEvent_t> pipe_ev;
 };
+
+static int fusion_ensure_staging(loc_fusion* f, int32_t epochs);
 
 static void fusion_free_staging(loc_fusion* f) {
     void* p[] = {f->d_dist, f->d_err, f->d_imu, f->d_out_pose, f->d_out_chi2, f->d_out_trials};
@@ -52,6 +61,11 @@ int loc_fusion_destroy(loc_fusion* f) {
     if (!f) return LOC_OK;
     (void)hipSetDevice(f->device);
     fusion_free_staging(f);
+    for (hipEvent_t ev : f->pipe_ev) (void)hipEventDestroy(ev);
+    if (f->d_raw_dist) (void)hipFree(f->d_raw_dist);
+    if (f->d_raw_err) (void)hipFree(f->d_raw_err);
+    if (f->in_stream) (void)hipStreamDestroy(f->in_stream);
+    if (f->out_stream) (void)hipStreamDestroy(f->out_stream);
     if (f->d_anchors) (void)hipFree(f->d_anchors);
     if (f->d_offset) (void)hipFree(f->d_offset);
     if (f->d_pose) (void)hipFree(f->d_pose);
@@ -144,16 +158,7 @@ int loc_fusion_solve_host(loc_fusion* f, int32_t epochs, const float* dist_h, co
     LOC_HIP(hipSetDevice(f->device));
     const size_t B = (size_t)f->B, K = (size_t)epochs;
     const size_t nf = K * 2 * B * 4;
-    if (epochs > f->staged) {
-        fusion_free_staging(f);
-        LOC_HIP(hipMalloc((void**)&f->d_dist, nf * sizeof(float)));
-        LOC_HIP(hipMalloc((void**)&f->d_err, nf * sizeof(float)));
-        LOC_HIP(hipMalloc((void**)&f->d_imu, K * B * 8 * sizeof(double)));
-        LOC_HIP(hipMalloc((void**)&f->d_out_pose, K * 7 * B * sizeof(double)));
-        LOC_HIP(hipMalloc((void**)&f->d_out_chi2, K * B * sizeof(double)));
-        LOC_HIP(hipMalloc((void**)&f->d_out_trials, K * B));
-        f->staged = epochs;
-    }
+    if (int rc = fusion_ensure_staging(f, epochs)) return rc;
     LOC_HIP(hipMemcpyAsync(f->d_dist, dist_h, nf * sizeof(float), hipMemcpyHostToDevice, f->stream));
     LOC_HIP(hipMemcpyAsync(f->d_err, err_h, nf * sizeof(float), hipMemcpyHostToDevice, f->stream));
     LOC_HIP(hipMemcpyAsync(f->d_imu, imu_h, K * B * 8 * sizeof(double), hipMemcpyHostToDevice, f->stream));
@@ -162,6 +167,62 @@ int loc_fusion_solve_host(loc_fusion* f, int32_t epochs, const float* dist_h, co
     LOC_HIP(hipMemcpyAsync(out_pose_h, f->d_out_pose, K * 7 * B * sizeof(double), hipMemcpyDeviceToHost, f->stream));
     LOC_HIP(hipMemcpyAsync(out_chi2_h, f->d_out_chi2, K * B * sizeof(double), hipMemcpyDeviceToHost, f->stream));
     if (out_trials_h) LOC_HIP(hipMemcpyAsync(out_trials_h, f->d_out_trials, K * B, hipMemcpyDeviceToHost, f->stream));
+    LOC_HIP(hipStreamSynchronize(f->stream));
+    return LOC_OK;
+}
+
+int loc_fusion_solve_host_kmb(loc_fusion* f, int32_t epochs, const float* dist_kmb, const float* err_kmb, const double* imu_h,
+                              double* out_pose_h, double* out_chi2_h, uint8_t* out_trials_h) {
+    if (!f) return locamd_fail(LOC_ERR_INVALID, "null handle");
+    if (epochs <= 0 || !dist_kmb || !err_kmb || !imu_h || !out_pose_h || !out_chi2_h) return locamd_fail(LOC_ERR_INVALID, "solve arguments");
+    LOC_HIP(hipSetDevice(f->device));
+    const size_t B = (size_t)f->B, M = (size_t)f->M;
+    if (int rc = fusion_ensure_staging(f, epochs)) return rc;
+    if (epochs > f->raw_epochs) {
+        if (f->d_raw_dist) (void)hipFree(f->d_raw_dist);
+        if (f->d_raw_err) (void)hipFree(f->d_raw_err);
+        f->d_raw_dist = f->d_raw_err = nullptr; f->raw_epochs = 0;
+        LOC_HIP(hipMalloc((void**)&f->d_raw_dist, sizeof(float) * M * B * (size_t)epochs));
+        LOC_HIP(hipMalloc((void**)&f->d_raw_err, sizeof(float) * M * B * (size_t)epochs));
+        f->raw_epochs = epochs;
+    }
+    if (!f->in_stream) LOC_HIP(hipStreamCreateWithFlags(&f->in_stream, hipStreamNonBlocking));
+    if (!f->out_stream) LOC_HIP(hipStreamCreateWithFlags(&f->out_stream, hipStreamNonBlocking));
+    // same chunked three-stream pipeline as loc_snapshot_solve_host_kmb (capi.cpp); pageable buffers go as one chunk
+    auto pinned = [](const void* p) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return at.type == hipMemoryTypeHost;
+    };
+    const bool overlap = pinned(dist_kmb) && pinned(err_kmb) && pinned(imu_h) && pinned(out_pose_h) && pinned(out_chi2_h);
+    const int ce = overlap ? (int)std::max<size_t>(1, (8u << 20) / (B * 8 * sizeof(double))) : epochs;
+    const int nchunks = (epochs + ce - 1) / ce;
+    while ((int)f->pipe_ev.size() < 2 * nchunks) {
+        hipEvent_t ev;
+        LOC_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        f->pipe_ev.push_back(ev);
+    }
+    for (int c = 0; c < nchunks; ++c) {
+        const int k0 = c * ce, kc = std::min(ce, epochs - k0);
+        const size_t roff = (size_t)k0 * M * B, rn = (size_t)kc * M * B, toff = (size_t)k0 * 2 * B * 4, ioff = (size_t)k0 * B * 8;
+        LOC_HIP(hipMemcpyAsync(f->d_raw_dist + roff, dist_kmb + roff, rn * sizeof(float), hipMemcpyHostToDevice, f->in_stream));
+        LOC_HIP(hipMemcpyAsync(f->d_raw_err + roff, err_kmb + roff, rn * sizeof(float), hipMemcpyHostToDevice, f->in_stream));
+        LOC_HIP(hipMemcpyAsync(f->d_imu + ioff, imu_h + ioff, (size_t)kc * B * 8 * sizeof(double), hipMemcpyHostToDevice, f->in_stream));
+        LOC_HIP(hipEventRecord(f->pipe_ev[2 * c], f->in_stream));
+        LOC_HIP(hipStreamWaitEvent(f->stream, f->pipe_ev[2 * c], 0));
+        hipError_t e = locamd::launch_pack_kmb(f->d_raw_dist + roff, f->d_dist + toff, f->B, f->M, 2, kc, 0.f, f->stream);
+        if (e == hipSuccess) e = locamd::launch_pack_kmb(f->d_raw_err + roff, f->d_err + toff, f->B, f->M, 2, kc, 0.f, f->stream);
+        if (e != hipSuccess) return locamd_fail_hip(e, "launch_pack_kmb");
+        int rc = loc_fusion_solve_device(f, kc, f->d_dist + toff, f->d_err + toff, f->d_imu + ioff, f->d_out_pose + (size_t)k0 * 7 * B,
+                                         f->d_out_chi2 + (size_t)k0 * B, f->d_out_trials + (size_t)k0 * B, f->stream);
+        if (rc != LOC_OK) return rc;
+        LOC_HIP(hipEventRecord(f->pipe_ev[2 * c + 1], f->stream));
+        LOC_HIP(hipStreamWaitEvent(f->out_stream, f->pipe_ev[2 * c + 1], 0));
+        LOC_HIP(hipMemcpyAsync(out_pose_h + (size_t)k0 * 7 * B, f->d_out_pose + (size_t)k0 * 7 * B, sizeof(double) * 7 * B * (size_t)kc, hipMemcpyDeviceToHost, f->out_stream));
+        LOC_HIP(hipMemcpyAsync(out_chi2_h + (size_t)k0 * B, f->d_out_chi2 + (size_t)k0 * B, sizeof(double) * B * (size_t)kc, hipMemcpyDeviceToHost, f->out_stream));
+        if (out_trials_h) LOC_HIP(hipMemcpyAsync(out_trials_h + (size_t)k0 * B, f->d_out_trials + (size_t)k0 * B, B * (size_t)kc, hipMemcpyDeviceToHost, f->out_stream));
+    }
+    LOC_HIP(hipStreamSynchronize(f->out_stream));
     LOC_HIP(hipStreamSynchronize(f->stream));
     return LOC_OK;
 }
@@ -178,3 +239,17 @@ int loc_fusion_last_kernel_ms(loc_fusion* f, double* ms) {
 }
 
 }  // extern "C"
+
+static int fusion_ensure_staging(loc_fusion* f, int32_t epochs) {
+    if (epochs <= f->staged) return LOC_OK;
+    const size_t B = (size_t)f->B, K = (size_t)epochs, nf = K * 2 * B * 4;
+    fusion_free_staging(f);
+    LOC_HIP(hipMalloc((void**)&f->d_dist, nf * sizeof(float)));
+    LOC_HIP(hipMalloc((void**)&f->d_err, nf * sizeof(float)));
+    LOC_HIP(hipMalloc((void**)&f->d_imu, K * B * 8 * sizeof(double)));
+    LOC_HIP(hipMalloc((void**)&f->d_out_pose, K * 7 * B * sizeof(double)));
+    LOC_HIP(hipMalloc((void**)&f->d_out_chi2, K * B * sizeof(double)));
+    LOC_HIP(hipMalloc((void**)&f->d_out_trials, K * B));
+    f->staged = epochs;
+    return LOC_OK;
+}

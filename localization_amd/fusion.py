@@ -81,6 +81,18 @@ class FusionSolver:
                                            pose.ctypes.data_as(dp), chi2.ctypes.data_as(dp), trials.ctypes.data_as(C.POINTER(C.c_uint8))))
         return pose, chi2, trials
 
+    def solve_stream(self, dist_kmb, err_kmb, imu_kb8):
+        """The pipelined host path (loc_fusion_solve_host_kmb): natural [K][M][B] arrays, tiles packed on the GPU."""
+        d = np.ascontiguousarray(dist_kmb, dtype=np.float32); e = np.ascontiguousarray(err_kmb, dtype=np.float32)
+        imu = np.ascontiguousarray(imu_kb8, dtype=np.float64)
+        K = d.shape[0]
+        assert d.shape == (K, self.M, self.B) and e.shape == d.shape and imu.shape == (K, self.B, 8)
+        pose = np.empty((K, 7, self.B)); chi2 = np.empty((K, self.B)); trials = np.empty((K, self.B), dtype=np.uint8)
+        self.L.loc_fusion_solve_host_kmb.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 6
+        check(self.L.loc_fusion_solve_host_kmb(self.h, K, d.ctypes.data, e.ctypes.data, imu.ctypes.data, pose.ctypes.data,
+                                               chi2.ctypes.data, trials.ctypes.data))
+        return pose, chi2, trials
+
     def solve_device(self, dist_tiles, err_tiles, imu, out_pose, out_chi2, out_trials=None):
         import torch
         K = dist_tiles.shape[0]

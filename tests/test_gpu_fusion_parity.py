@@ -77,3 +77,24 @@ def test_fusion_accuracy_and_properties(gpu):
     from scipy.spatial.transform import Rotation
     dq = (Rotation.from_quat(pose[-1, 3:7].T).inv() * Rotation.from_quat(s["truth_q"][-1])).magnitude()
     assert np.median(dq) < 0.02
+
+
+@pytest.mark.parametrize("B,K,M", [(777, 5, 8), (65536, 6, 8), (2048, 4, 6)])
+def test_fusion_pipelined_host_path_equals_the_staged_one(gpu, B, K, M):
+    """loc_fusion_solve_host_kmb (natural [K][M][B] layout, tiles packed on the GPU, chunked three-stream pipeline) is
+    bit-identical to loc_fusion_solve_host on host-packed tiles, incl. an anchor count that needs padding."""
+    import localization_amd as la
+    from localization_amd.synthetic import make_fusion_stream
+    s = make_fusion_stream(B, K, seed=9)
+    anchors = s["anchors"][:M]
+    dist, err = s["dist"][:, :M], s["err"][:, :M]
+    a = la.FusionSolver(anchors, B, antenna_offset=s["offset"], maximum_iteration=10, distance_outlier=3.0)
+    a.set_poses(s["init"])
+    ref = a.solve(dist, err, s["imu"])
+    b = la.FusionSolver(anchors, B, antenna_offset=s["offset"], maximum_iteration=10, distance_outlier=3.0)
+    b.set_poses(s["init"])
+    got = b.solve_stream(dist, err, s["imu"])
+    for x, y in zip(ref, got):
+        assert np.array_equal(x, y)
+    assert np.array_equal(a.get_poses(), b.get_poses())
+    a.close(); b.close()
