@@ -217,3 +217,36 @@ def test_pipelined_host_path_equals_the_staged_one(gpu, B, K, M):
     for x, y in zip(ref, got2):
         assert np.array_equal(x, y)
     a.close(); b.close()
+
+
+def test_degenerate_inputs_start_on_an_anchor_and_non_finite_ranges(gpu):
+    """Collisions and bad data, as the domain has them: (1) the estimate starts exactly ON an anchor (r = 0 for that edge:
+    the analytic Jacobian is 0/0, g2o's numeric one is finite) — both Jacobian modes stay finite and match the oracle;
+    (2) NaN / +-Inf distances and zero / negative / NaN distance_err mark a slot invalid: it is skipped, never poisons
+    the estimate, and GPU and oracle agree."""
+    import localization_amd as la
+    from localization_amd.synthetic import ANCHORS_8, make_snapshot_stream
+    from oracle import oracle as O
+    B, K = 64, 3
+    s = make_snapshot_stream(B, K, seed=5)
+    init = s["init"].copy()
+    for b in range(B):
+        init[:, b] = ANCHORS_8[b % 8]
+    for jm, oj, tol in (("analytic", O.JAC_ANALYTIC, 1e-7), ("numeric", O.JAC_NUMERIC_G2O, 1e-5)):
+        sol = la.SnapshotSolver(ANCHORS_8, B, maximum_iteration=10, distance_outlier=0.0, jacobian=jm)
+        sol.set_positions(init)
+        gp, gc, _ = sol.solve(s["dist"], s["err"])
+        rp, rc, _, _ = O.snapshot_batch(ANCHORS_8, s["dist"], s["err"], init, iterations=10, gate=0.0, jac_mode=oj)
+        assert np.isfinite(gp).all() and np.isfinite(gc).all() and np.isfinite(rp).all()
+        assert np.abs(gp - rp).max() < tol
+        sol.close()
+    d = s["dist"].copy(); e = s["err"].copy()
+    d[0, 0, :8] = np.nan; d[1, 1, :8] = np.inf; d[2, 5, :8] = -np.inf
+    e[0, 2, :8] = 0.0; e[1, 3, :8] = -1.0; e[2, 4, :8] = np.nan
+    sol = la.SnapshotSolver(ANCHORS_8, B, maximum_iteration=10, distance_outlier=1.0)
+    sol.set_positions(s["init"])
+    gp, gc, _ = sol.solve(d, e)
+    rp, rc, _, _ = O.snapshot_batch(ANCHORS_8, d, e, s["init"], iterations=10, gate=1.0, jac_mode=O.JAC_ANALYTIC, gate_from_epoch=1)
+    assert np.isfinite(gp).all() and np.isfinite(gc).all()
+    assert np.abs(gp - rp).max() < 1e-9 and np.abs(gc - rc).max() < 1e-9 * max(1.0, np.abs(rc).max())
+    sol.close()
