@@ -46,7 +46,7 @@ size_t loc_window_lds_bytes(const loc_window_caps* caps) {
     if (caps->nv_max <= 0) return 0;
     locamd::WindowCaps c = to_caps(caps);
     const size_t in_lds = locamd::window_lds_bytes(c, false);
-    return in_lds <= 160 * 1024 - 512 ? in_lds : 36 * sizeof(double);  // large windows: everything else in the HBM workspace
+    return in_lds <= 160 * 1024 - 512 ? in_lds : locamd::window_lds_bytes(c, true) + 36 * sizeof(double);  // large windows: index tables + exchange block; the rest in the HBM workspace
 }
 
 int loc_window_destroy(loc_window* w) {

@@ -381,26 +381,41 @@ __device__ __forceinline__ void build_system(const WindowArgs& a, const Lds& L, 
     for (int i = lane; i < n; i += 64) L.b[i] = 0.0;
     __syncthreads();
     const int r = lane / 6, cc = lane % 6;  // lanes 0..35: one entry of a 6x6 block
+    // (the endpoints of edge e + 1 are fetched while edge e is folded: with the tables in HBM the fold of one edge is
+    //  otherwise two dependent round trips, indices then H entries; the compiler may not hoist the load over the stores)
+    int nv0 = nr > 0 ? L.r_idx[0] : 0, nv1 = nr > 0 ? L.r_idx[1] : 0;
     for (int e = 0; e < nr; ++e) {
-        const int32_t* idx = L.r_idx + e * 2;
-        const int v0 = idx[0], v1 = idx[1];
+        const int v0 = nv0, v1 = nv1;
+        if (e + 1 < nr) { nv0 = L.r_idx[2 * e + 2]; nv1 = L.r_idx[2 * e + 3]; }
         const double* rec = L.rrec + e * RREC;
         const double wr = rec[12], om = rec[13];
         if (lane < 36) {
-            if (r >= cc) L.Hs[sky(L, v0 * 6 + r, v0 * 6 + cc)] += wr * rec[r] * rec[cc];
-            if (v1 >= 0) {
-                if (r >= cc) L.Hs[sky(L, v1 * 6 + r, v1 * 6 + cc)] += wr * rec[6 + r] * rec[6 + cc];
-                if (v0 > v1) L.Hs[sky(L, v0 * 6 + r, v1 * 6 + cc)] += wr * rec[r] * rec[6 + cc];
-                else         L.Hs[sky(L, v1 * 6 + r, v0 * 6 + cc)] += wr * rec[6 + r] * rec[cc];
+            // the (up to) three blocks an edge touches are distinct: read all three entries, then add, then store — one
+            // memory round trip per edge instead of three dependent read-modify-writes
+            const bool lower = r >= cc, bin = v1 >= 0;
+            const int a0 = lower ? sky(L, v0 * 6 + r, v0 * 6 + cc) : 0;
+            const int a1 = (bin && lower) ? sky(L, v1 * 6 + r, v1 * 6 + cc) : 0;
+            const int ax = !bin ? 0 : (v0 > v1) ? sky(L, v0 * 6 + r, v1 * 6 + cc) : sky(L, v1 * 6 + r, v0 * 6 + cc);
+            double h0 = lower ? L.Hs[a0] : 0.0, h1 = (bin && lower) ? L.Hs[a1] : 0.0, hx = bin ? L.Hs[ax] : 0.0;
+            h0 += wr * rec[r] * rec[cc];
+            if (bin) {
+                h1 += wr * rec[6 + r] * rec[6 + cc];
+                if (v0 > v1) hx += wr * rec[r] * rec[6 + cc];
+                else         hx += wr * rec[6 + r] * rec[cc];
             }
+            if (lower) L.Hs[a0] = h0;
+            if (bin && lower) L.Hs[a1] = h1;
+            if (bin) L.Hs[ax] = hx;
         } else if (lane < 42) {
             L.b[v0 * 6 + lane - 36] += rec[lane - 36] * om;
         } else if (lane < 48 && v1 >= 0) {
             L.b[v1 * 6 + lane - 42] += rec[6 + lane - 42] * om;
         }
     }
+    int nv = np > 0 ? L.p_idx[0] : 0;
     for (int e = 0; e < np; ++e) {
-        const int v = L.p_idx[e];
+        const int v = nv;
+        if (e + 1 < np) nv = L.p_idx[e + 1];
         const double* rec = L.prec + e * PREC;
         if (lane < 36) {
             if (r >= cc) {
@@ -417,9 +432,10 @@ __device__ __forceinline__ void build_system(const WindowArgs& a, const Lds& L, 
             L.b[v * 6 + rr] += s;
         }
     }
+    int nvi = ns > 0 ? L.s_idx[0] : 0, nvj = ns > 0 ? L.s_idx[1] : 0;
     for (int e = 0; e < ns; ++e) {
-        const int32_t* idx = L.s_idx + e * 4;
-        const int vi = idx[0], vj = idx[1];
+        const int vi = nvi, vj = nvj;
+        if (e + 1 < ns) { nvi = L.s_idx[4 * e + 4]; nvj = L.s_idx[4 * e + 5]; }
         const double* rec = L.srec + e * SREC;
         const double *J0 = rec, *J1 = rec + 36, *WJ0 = rec + 72, *WJ1 = rec + 108, *om = rec + 144;
         if (lane < 36) {
@@ -430,9 +446,13 @@ __device__ __forceinline__ void build_system(const WindowArgs& a, const Lds& L, 
                 sjj += J1[i * 6 + r] * WJ1[i * 6 + cc];
                 sx += (vi > vj) ? J0[i * 6 + r] * WJ1[i * 6 + cc] : J1[i * 6 + r] * WJ0[i * 6 + cc];  // rows of the later pose
             }
-            if (r >= cc) { L.Hs[sky(L, vi * 6 + r, vi * 6 + cc)] += sii; L.Hs[sky(L, vj * 6 + r, vj * 6 + cc)] += sjj; }
-            if (vi > vj) L.Hs[sky(L, vi * 6 + r, vj * 6 + cc)] += sx;
-            else         L.Hs[sky(L, vj * 6 + r, vi * 6 + cc)] += sx;
+            const bool lower = r >= cc;
+            const int ai = lower ? sky(L, vi * 6 + r, vi * 6 + cc) : 0, aj = lower ? sky(L, vj * 6 + r, vj * 6 + cc) : 0;
+            const int ax = (vi > vj) ? sky(L, vi * 6 + r, vj * 6 + cc) : sky(L, vj * 6 + r, vi * 6 + cc);
+            double hi = lower ? L.Hs[ai] : 0.0, hj = lower ? L.Hs[aj] : 0.0, hx = L.Hs[ax];  // three distinct blocks: one round trip
+            hi += sii; hj += sjj; hx += sx;
+            if (lower) { L.Hs[ai] = hi; L.Hs[aj] = hj; }
+            L.Hs[ax] = hx;
         } else if (lane < 48) {
             const bool second = lane >= 42;
             const int rr = second ? lane - 42 : lane - 36;
@@ -646,9 +666,16 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
     L.rrec = p; p += c.nr_max * RREC;
     L.prec = p; p += c.np_max * PREC;
     L.srec = p; p += c.ns_max * SREC;
-    L.fb = reinterpret_cast<int*>(p); p += (c.nv_max + 1) / 2;
-    L.last = reinterpret_cast<int*>(p); p += (c.nv_max + 1) / 2;
-    L.boff = reinterpret_cast<int*>(p); p += (n_max + 2) / 2;
+    if (GLOBAL_A) {
+        // the three small index tables stay in LDS even when everything else is in the HBM workspace: every address in
+        // the sweep and in the edge fold starts with a lookup in them, and an HBM round trip there is pure latency
+        int* t = reinterpret_cast<int*>(lds);
+        L.fb = t; L.last = t + c.nv_max; L.boff = t + 2 * c.nv_max;
+    } else {
+        L.fb = reinterpret_cast<int*>(p); p += (c.nv_max + 1) / 2;
+        L.last = reinterpret_cast<int*>(p); p += (c.nv_max + 1) / 2;
+        L.boff = reinterpret_cast<int*>(p); p += (n_max + 2) / 2;
+    }
     double* gpose = a.poses + (size_t)inst * c.nv_max * 12;
     for (int i = lane; i < nv * 12; i += 64) L.pose[i] = gpose[i];
     if (GLOBAL_A) {
@@ -771,7 +798,7 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
 }  // namespace
 
 size_t window_lds_bytes(const WindowCaps& c, bool global_a) {
-    if (global_a) return 0;  // (the 6x6 exchange block is static LDS)
+    if (global_a) return (3 * (size_t)c.nv_max + 2) * sizeof(int);  // fb, last, boff (+ the static 6x6 exchange block)
     const size_t tables = (size_t)c.nr_max * 6 + (size_t)c.np_max * 18 + (c.np_max + 1) / 2 + (size_t)c.ns_max * 50;
     return (window_instance_doubles(c) + tables) * sizeof(double);
 }
