@@ -156,7 +156,9 @@ int loc_snapshot_timing_end(loc_snapshot* s, int32_t* n_launches, double* total_
 typedef struct loc_window loc_window;
 typedef struct loc_window_caps {
     int32_t nv_max, nr_max, np_max, ns_max;
-    int32_t bw_max; /* widest pose-to-pose coupling |vi - vj| of any binary edge, in pose slots; < 0 = nv_max - 1 (dense) */
+    int32_t bw_max; /* widest pose-to-pose coupling |vi - vj| of any binary edge, in pose slots; < 0 = nv_max - 1 (dense).
+                     * Pass the true bound: it sizes the per-instance storage, and small windows then fit twice as many
+                     * instances per CU (measured: 4096 ten-pose chains 3.3 ms with -1, 1.8 ms with 1). */
 } loc_window_caps;
 
 int loc_window_create(loc_window** out, int32_t device, int64_t batch, const loc_window_caps* caps,
