@@ -150,6 +150,7 @@ struct Lds {
     double *Hs, *Ls;  // skyline H (lower) and its Cholesky factor (LDS, or an HBM workspace slice for large windows)
     double *diagL, *b, *x, *yrow, *pose, *bak, *rrec, *prec, *srec;
     int *fb, *last, *boff;  // per block row: first / last connected block, offset of the block row's storage
+    int *ioff, *ilist;      // per pose: its incident edges in fold order (CSR), entry = kind << 28 | role << 27 | edge
     double* blk; // 6x6 scratch: the diagonal block being factored
 #ifdef LOCAMD_WINDOW_TIMING
     long long* tim;  // diagnostic build: cycles in (a) segments, (b) block exchange+factor, (c) row finish, back-substitution
@@ -337,16 +338,30 @@ __host__ __device__ inline size_t sky_nnz_bound(int nv, int bw) {
     return s;
 }
 
+// entries of the per-pose incidence lists: every edge once per moving endpoint
+__host__ __device__ inline size_t window_incidences(const WindowCaps& c) {
+    return 2 * (size_t)c.nr_max + (size_t)c.np_max + 2 * (size_t)c.ns_max;
+}
 // doubles of one instance's arrays (skyline pair, dense vectors, poses, edge records, index tables) — the layout the
 // kernel carves, in LDS or in the HBM workspace
 __host__ __device__ inline size_t window_instance_doubles(const WindowCaps& c) {
     const size_t n_max = 6 * (size_t)c.nv_max;
     return 2 * sky_nnz_bound(c.nv_max, c.bw_max) + 4 * n_max + 2 * (size_t)c.nv_max * 12 + (size_t)c.nr_max * RREC + (size_t)c.np_max * PREC +
-           (size_t)c.ns_max * SREC + 2 * (((size_t)c.nv_max + 1) / 2) + (n_max + 2) / 2;
+           (size_t)c.ns_max * SREC + 2 * (((size_t)c.nv_max + 1) / 2) + (n_max + 2) / 2 + ((size_t)c.nv_max + 2) / 2 +
+           (window_incidences(c) + 1) / 2;
 }
 
-// Once per solve (the topology does not change between iterations): fb[], last[], boff[].
-__device__ __forceinline__ void compute_skyline(const Lds& L, int lane, int n, int nr, int ns) {
+// address of H/L entry (row, col), col <= row, col inside row's envelope
+__device__ __forceinline__ int sky(const Lds& L, int row, int col) {
+    const int v = row / 6;
+    return L.boff[v] + 6 * (col - 6 * L.fb[v]) + (row - 6 * v);
+}
+
+constexpr int INC_KIND_SHIFT = 28, INC_ROLE_SHIFT = 27, INC_EDGE_MASK = (1 << 27) - 1;
+
+// Once per solve (the topology does not change between iterations): fb[], last[], boff[], the incidence lists, and
+// whether two binary edges couple the same pair of poses (returned; uniform).
+__device__ __forceinline__ bool compute_skyline(const Lds& L, int lane, int n, int nr, int np, int ns) {
     const int nv = n / 6;
     if (lane == 0) {
         for (int v = 0; v < nv; ++v) { L.fb[v] = v; L.last[v] = v; }
@@ -364,15 +379,45 @@ __device__ __forceinline__ void compute_skyline(const Lds& L, int lane, int n, i
         int off = 0;
         for (int v = 0; v < nv; ++v) { L.boff[v] = off; off += 36 * (v - L.fb[v] + 1); }
         L.boff[nv] = off;
+        // incidence lists in the order the fold visits the edges: ranges, priors, SE3 (stable counting sort by pose)
+        for (int v = 0; v <= nv; ++v) L.ioff[v] = 0;
+        for (int e = 0; e < nr; ++e) { ++L.ioff[L.r_idx[2 * e] + 1]; if (L.r_idx[2 * e + 1] >= 0) ++L.ioff[L.r_idx[2 * e + 1] + 1]; }
+        for (int e = 0; e < np; ++e) ++L.ioff[L.p_idx[e] + 1];
+        for (int e = 0; e < ns; ++e) { ++L.ioff[L.s_idx[4 * e] + 1]; ++L.ioff[L.s_idx[4 * e + 1] + 1]; }
+        for (int v = 0; v < nv; ++v) L.ioff[v + 1] += L.ioff[v];
+        // (last[] doubles as the write cursor while the lists are filled; it is rebuilt right after)
+        for (int v = 0; v < nv; ++v) L.last[v] = L.ioff[v];
+        for (int e = 0; e < nr; ++e) {
+            const int v0 = L.r_idx[2 * e], v1 = L.r_idx[2 * e + 1];
+            L.ilist[L.last[v0]++] = e;
+            if (v1 >= 0) L.ilist[L.last[v1]++] = (1 << INC_ROLE_SHIFT) | e;
+        }
+        for (int e = 0; e < np; ++e) L.ilist[L.last[L.p_idx[e]]++] = (1 << INC_KIND_SHIFT) | e;
+        for (int e = 0; e < ns; ++e) {
+            L.ilist[L.last[L.s_idx[4 * e]]++] = (2 << INC_KIND_SHIFT) | e;
+            L.ilist[L.last[L.s_idx[4 * e + 1]]++] = (2 << INC_KIND_SHIFT) | (1 << INC_ROLE_SHIFT) | e;
+        }
+        for (int v = 0; v < nv; ++v) L.last[v] = v;
+        for (int v = 0; v < nv; ++v) for (int J = L.fb[v]; J <= v; ++J) L.last[J] = max(L.last[J], v);
     }
     __syncthreads();
+    // Two binary edges on the same pair of poses?  Every binary edge stamps its number on the first entry of its
+    // off-diagonal block (H is not in use yet); whoever does not read its own stamp back shares the block.
+    bool clash = false;
+    for (int t = lane; t < nr + ns; t += 64) {
+        const bool is_r = t < nr;
+        const int va = is_r ? L.r_idx[2 * t] : L.s_idx[4 * (t - nr)], vb = is_r ? L.r_idx[2 * t + 1] : L.s_idx[4 * (t - nr) + 1];
+        if (vb >= 0) L.Hs[sky(L, 6 * max(va, vb), 6 * min(va, vb))] = (double)(t + 1);
+    }
+    __syncthreads();
+    for (int t = lane; t < nr + ns; t += 64) {
+        const bool is_r = t < nr;
+        const int va = is_r ? L.r_idx[2 * t] : L.s_idx[4 * (t - nr)], vb = is_r ? L.r_idx[2 * t + 1] : L.s_idx[4 * (t - nr) + 1];
+        if (vb >= 0 && L.Hs[sky(L, 6 * max(va, vb), 6 * min(va, vb))] != (double)(t + 1)) clash = true;
+    }
+    __syncthreads();
+    return __any(clash);
 }
-// address of H/L entry (row, col), col <= row, col inside row's envelope
-__device__ __forceinline__ int sky(const Lds& L, int row, int col) {
-    const int v = row / 6;
-    return L.boff[v] + 6 * (col - 6 * L.fb[v]) + (row - 6 * v);
-}
-
 // Fold the edge records into H (skyline lower triangle) and b, one edge after the other (fixed order: bit-reproducible).
 __device__ __forceinline__ void build_system(const WindowArgs& a, const Lds& L, int inst, int lane, int n, int nr, int np, int ns) {
     (void)a; (void)inst;
@@ -461,6 +506,90 @@ __device__ __forceinline__ void build_system(const WindowArgs& a, const Lds& L, 
 #pragma unroll
             for (int i = 0; i < 6; ++i) s += J[i * 6 + rr] * om[i];
             L.b[(second ? vj : vi) * 6 + rr] += s;
+        }
+    }
+    __syncthreads();
+}
+
+// The same H and b, entry for entry and addition for addition, but gathered instead of scattered: task (pose v, entry)
+// walks v's incidence list (fold order) and sums that entry of the diagonal block / of b in a register, one store at the
+// end; every off-diagonal block belongs to exactly one edge (the caller checked: no two binary edges on one pair of
+// poses) and is written, not accumulated.  No read-modify-write chains through memory, all tasks independent: what was
+// one dependent memory round trip per edge becomes a few pipelined loads per list entry across 64 lanes.
+__device__ __forceinline__ void build_system_gather(const Lds& L, int lane, int n, int nr, int ns) {
+    const int nv = n / 6;
+    const int nnz = L.boff[nv];
+    for (int i = lane; i < nnz; i += 64) L.Hs[i] = 0.0;
+    __syncthreads();
+    for (int task = lane; task < nv * 27; task += 64) {
+        const int v = task / 27, k = task - 27 * v;  // k < 21: lower-triangle entry (r, cc) of the diagonal block; else b[k - 21]
+        int r = 0;
+        while ((r + 1) * (r + 2) / 2 <= k && r < 5) ++r;
+        const int cc = k - r * (r + 1) / 2;
+        const bool is_b = k >= 21;
+        const int rb = k - 21;
+        double acc = 0.0;
+        const int p1 = L.ioff[v + 1];
+        for (int p = L.ioff[v]; p < p1; ++p) {
+            const int code = L.ilist[p];
+            const int kind = code >> INC_KIND_SHIFT, role = (code >> INC_ROLE_SHIFT) & 1, e = code & INC_EDGE_MASK;
+            if (kind == 0) {
+                const double* rec = L.rrec + e * RREC;
+                const double* J = rec + 6 * role;
+                if (is_b) acc += J[rb] * rec[13];
+                else acc += rec[12] * J[r] * J[cc];
+            } else if (kind == 1) {
+                const double* rec = L.prec + e * PREC;
+                double t = 0.0;
+                if (is_b) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) t += rec[i * 6 + rb] * rec[42 + i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) t += rec[i * 6 + r] * rec[36 + i] * rec[i * 6 + cc];
+                }
+                acc += t;
+            } else {
+                const double* rec = L.srec + e * SREC;
+                const double* J = rec + 36 * role;
+                double t = 0.0;
+                if (is_b) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) t += J[i * 6 + rb] * rec[144 + i];
+                } else {
+                    const double* WJ = rec + 72 + 36 * role;
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) t += J[i * 6 + r] * WJ[i * 6 + cc];
+                }
+                acc += t;
+            }
+        }
+        if (is_b) L.b[v * 6 + rb] = acc;
+        else L.Hs[sky(L, v * 6 + r, v * 6 + cc)] = acc;
+    }
+    for (int task = lane; task < (nr + ns) * 36; task += 64) {
+        const int t = task / 36, q = task - 36 * t;
+        const int r = q / 6, cc = q - 6 * r;
+        if (t < nr) {
+            const int v0 = L.r_idx[2 * t], v1 = L.r_idx[2 * t + 1];
+            if (v1 < 0) continue;
+            const double* rec = L.rrec + t * RREC;
+            const double wr = rec[12];
+            double h = 0.0;
+            if (v0 > v1) { h += wr * rec[r] * rec[6 + cc]; L.Hs[sky(L, v0 * 6 + r, v1 * 6 + cc)] = h; }
+            else         { h += wr * rec[6 + r] * rec[cc]; L.Hs[sky(L, v1 * 6 + r, v0 * 6 + cc)] = h; }
+        } else {
+            const int e = t - nr;
+            const int vi = L.s_idx[4 * e], vj = L.s_idx[4 * e + 1];
+            const double* rec = L.srec + e * SREC;
+            const double *J0 = rec, *J1 = rec + 36, *WJ0 = rec + 72, *WJ1 = rec + 108;
+            double sx = 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) sx += (vi > vj) ? J0[i * 6 + r] * WJ1[i * 6 + cc] : J1[i * 6 + r] * WJ0[i * 6 + cc];  // rows of the later pose
+            double h = 0.0;
+            h += sx;
+            if (vi > vj) L.Hs[sky(L, vi * 6 + r, vj * 6 + cc)] = h;
+            else         L.Hs[sky(L, vj * 6 + r, vi * 6 + cc)] = h;
         }
     }
     __syncthreads();
@@ -670,12 +799,15 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
         // the three small index tables stay in LDS even when everything else is in the HBM workspace: every address in
         // the sweep and in the edge fold starts with a lookup in them, and an HBM round trip there is pure latency
         int* t = reinterpret_cast<int*>(lds);
-        L.fb = t; L.last = t + c.nv_max; L.boff = t + 2 * c.nv_max;
+        L.fb = t; L.last = t + c.nv_max; L.boff = t + 2 * c.nv_max; L.ioff = t + 3 * c.nv_max + 1;
+        p += 2 * ((c.nv_max + 1) / 2) + (n_max + 2) / 2 + (c.nv_max + 2) / 2;  // (their workspace slots stay unused)
     } else {
         L.fb = reinterpret_cast<int*>(p); p += (c.nv_max + 1) / 2;
         L.last = reinterpret_cast<int*>(p); p += (c.nv_max + 1) / 2;
         L.boff = reinterpret_cast<int*>(p); p += (n_max + 2) / 2;
+        L.ioff = reinterpret_cast<int*>(p); p += (c.nv_max + 2) / 2;
     }
+    L.ilist = reinterpret_cast<int*>(p); p += (window_incidences(c) + 1) / 2;
     double* gpose = a.poses + (size_t)inst * c.nv_max * 12;
     for (int i = lane; i < nv * 12; i += 64) L.pose[i] = gpose[i];
     if (GLOBAL_A) {
@@ -698,7 +830,7 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
         for (int i = lane; i < ns * 48; i += 64) st_sval[i] = a.s_val[(size_t)inst * c.ns_max * 48 + i];
     }
     __syncthreads();
-    compute_skyline(L, lane, n, nr, ns);
+    const bool serial_fold = compute_skyline(L, lane, n, nr, np, ns);
 
     constexpr double tau = 1e-5, good_lo = 1.0 / 3.0, good_hi = 2.0 / 3.0;
     constexpr int max_trials = 10;
@@ -721,7 +853,8 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
         evaluate_edges<true>(a, L, inst, lane, nr, np, ns, cur_chi, plain);  // computeActiveErrors + linearize
         last_plain = plain;
         __syncthreads();
-        build_system(a, L, inst, lane, n, nr, np, ns);
+        if (serial_fold) build_system(a, L, inst, lane, n, nr, np, ns);
+        else build_system_gather(L, lane, n, nr, ns);
         LOCAMD_T1(t_bd);
         if (it == 0) {  // computeLambdaInit
             double md = 0.0;
@@ -798,7 +931,7 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
 }  // namespace
 
 size_t window_lds_bytes(const WindowCaps& c, bool global_a) {
-    if (global_a) return (3 * (size_t)c.nv_max + 2) * sizeof(int);  // fb, last, boff (+ the static 6x6 exchange block)
+    if (global_a) return (4 * (size_t)c.nv_max + 4) * sizeof(int);  // fb, last, boff, ioff (+ the static 6x6 exchange block)
     const size_t tables = (size_t)c.nr_max * 6 + (size_t)c.np_max * 18 + (c.np_max + 1) / 2 + (size_t)c.ns_max * 50;
     return (window_instance_doubles(c) + tables) * sizeof(double);
 }
