@@ -165,3 +165,45 @@ def test_window_rejects_bad_indices(gpu):
     with pytest.raises(la.LocalizationAmdError):
         solver.solve(wb)
     solver.close()
+
+
+def test_two_edges_on_one_pair_of_poses_take_the_serial_fold(gpu):
+    """A smoothness range AND an EdgeSE3 (and, in half the instances, a second range) between the same two poses — what the
+    reference produces when a twist edge and the key-frame pose edge meet (localization.cpp:276-281, 446-450).  Their
+    off-diagonal block then has more than one contributor: the kernel detects it and folds edge by edge; the result
+    matches the oracle like every other graph."""
+    import localization_amd as la
+    from oracle import oracle as O
+    rng = np.random.default_rng(11)
+    B, T = 32, 6
+    wb = la.WindowBatch(B, T, 3 * T, 0, T)
+    want_t = np.zeros((B, T, 3))
+    for i in range(B):
+        truth_t = np.cumsum(rng.normal(0, 0.05, (T, 3)), axis=0) + np.array([0.3, -0.4, 1.1])
+        truth_R = Rotation.from_rotvec(np.cumsum(rng.normal(0, 0.03, (T, 3)), axis=0))
+        est_t = truth_t + rng.normal(0, 0.05, (T, 3)); est_R = (truth_R * Rotation.from_rotvec(rng.normal(0, 0.02, (T, 3)))).as_matrix()
+        g = O.Graph()
+        for m, a in enumerate(ANCH): g.add_vertex(m, a, fixed=True)
+        for k in range(T):
+            g.add_vertex(100 + k, est_t[k], est_R[k]); wb.add_pose(i, est_t[k], est_R[k])
+        for k in range(T):
+            a = int(rng.integers(0, 4)); d = float(np.float32(np.linalg.norm(truth_t[k] - ANCH[a]) + rng.normal(0, 0.03)))
+            g.add_range_edge(100 + k, a, d, 1 / 0.055 ** 2); wb.add_range(i, k, a, d, 1 / 0.055 ** 2, anchor=True)
+            if k:
+                info_s = 1.0 / (5.0 / 32 / 3) ** 2
+                g.add_range_edge(100 + k - 1, 100 + k, 0.0, info_s); wb.add_range(i, k - 1, k, 0.0, info_s)
+                if i % 2:   # a measured peer-to-peer range on the same pair as well
+                    dd = float(np.linalg.norm(truth_t[k] - truth_t[k - 1]) + rng.normal(0, 0.01))
+                    g.add_range_edge(100 + k, 100 + k - 1, dd, 1 / 0.03 ** 2); wb.add_range(i, k, k - 1, dd, 1 / 0.03 ** 2)
+                Zt = truth_R[k - 1].inv().apply(truth_t[k] - truth_t[k - 1]) + rng.normal(0, 0.01, 3)
+                ZR = (truth_R[k - 1].inv() * truth_R[k] * Rotation.from_rotvec(rng.normal(0, 0.01, 3))).as_matrix()
+                info = np.eye(6) * 2e3
+                g.add_se3_edge(100 + k - 1, 100 + k, Zt, ZR, info, robust=True); wb.add_se3(i, k - 1, k, Zt, ZR, info, True)
+        g.optimize(10, O.JAC_ANALYTIC)
+        for k in range(T):
+            want_t[i, k] = g.estimate(100 + k)[1]
+    solver = la.WindowSolver(ANCH, B, *wb.caps, maximum_iteration=10, bw_max=1)
+    solver.solve(wb)
+    solver.close()
+    d = np.abs(wb.poses[:, :, 9:] - want_t)
+    assert np.isfinite(wb.poses).all() and d.max() < 1e-7 and np.median(d) < 1e-9, (d.max(), np.median(d))
