@@ -24,7 +24,7 @@ struct WindowCaps {
 //   s_idx   int32 [B][ns_max][4]    vi, vj, robust, pad
 //   s_val   double[B][ns_max][48]   Z^-1 as R(9), t(3); information 6x6 row-major (36)
 //   result  double[B][8]            chi2 (all edges, last evaluated), robust chi2, lambda, outer iterations,
-//                                   LM trials, terminated, 0, 0
+//                                   LM trials, terminated, number of binary edges that share their pair of poses with another edge, 0
 struct WindowArgs {
     const int32_t* counts;
     double* poses;

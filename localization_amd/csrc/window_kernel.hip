@@ -151,6 +151,7 @@ struct Lds {
     double *diagL, *b, *x, *yrow, *pose, *bak, *rrec, *prec, *srec;
     int *fb, *last, *boff;  // per block row: first / last connected block, offset of the block row's storage
     int *ioff, *ilist;      // per pose: its incident edges in fold order (CSR), entry = kind << 28 | role << 27 | edge
+    int *shared;            // [0] = count, then the binary edges (range e, or nr + SE3 e) whose pair of poses has another edge, in fold order
     double* blk; // 6x6 scratch: the diagonal block being factored
 #ifdef LOCAMD_WINDOW_TIMING
     long long* tim;  // diagnostic build: cycles in (a) segments, (b) block exchange+factor, (c) row finish, back-substitution
@@ -348,7 +349,7 @@ __host__ __device__ inline size_t window_instance_doubles(const WindowCaps& c) {
     const size_t n_max = 6 * (size_t)c.nv_max;
     return 2 * sky_nnz_bound(c.nv_max, c.bw_max) + 4 * n_max + 2 * (size_t)c.nv_max * 12 + (size_t)c.nr_max * RREC + (size_t)c.np_max * PREC +
            (size_t)c.ns_max * SREC + 2 * (((size_t)c.nv_max + 1) / 2) + (n_max + 2) / 2 + ((size_t)c.nv_max + 2) / 2 +
-           (window_incidences(c) + 1) / 2;
+           (window_incidences(c) + 1) / 2 + ((size_t)c.nr_max + (size_t)c.ns_max + 2) / 2;
 }
 
 // address of H/L entry (row, col), col <= row, col inside row's envelope
@@ -360,8 +361,8 @@ __device__ __forceinline__ int sky(const Lds& L, int row, int col) {
 constexpr int INC_KIND_SHIFT = 28, INC_ROLE_SHIFT = 27, INC_EDGE_MASK = (1 << 27) - 1;
 
 // Once per solve (the topology does not change between iterations): fb[], last[], boff[], the incidence lists, and
-// whether two binary edges couple the same pair of poses (returned; uniform).
-__device__ __forceinline__ bool compute_skyline(const Lds& L, int lane, int n, int nr, int np, int ns) {
+// the list of binary edges that share their pair of poses with another edge.
+__device__ __forceinline__ void compute_skyline(const Lds& L, int lane, int n, int nr, int np, int ns) {
     const int nv = n / 6;
     if (lane == 0) {
         for (int v = 0; v < nv; ++v) { L.fb[v] = v; L.last[v] = v; }
@@ -401,122 +402,38 @@ __device__ __forceinline__ bool compute_skyline(const Lds& L, int lane, int n, i
         for (int v = 0; v < nv; ++v) for (int J = L.fb[v]; J <= v; ++J) L.last[J] = max(L.last[J], v);
     }
     __syncthreads();
-    // Two binary edges on the same pair of poses?  Every binary edge stamps its number on the first entry of its
-    // off-diagonal block (H is not in use yet); whoever does not read its own stamp back shares the block.
-    bool clash = false;
-    for (int t = lane; t < nr + ns; t += 64) {
+    // Binary edges that share their pair of poses with another one: every binary edge stamps its number on the first
+    // entry of its off-diagonal block (H is not in use yet); whoever does not read its own stamp back overwrites it with
+    // -1, and after that everybody on a shared pair reads -1.  Lane 0 lists those edges in fold order.
+    auto block_entry = [&](int t) {
         const bool is_r = t < nr;
         const int va = is_r ? L.r_idx[2 * t] : L.s_idx[4 * (t - nr)], vb = is_r ? L.r_idx[2 * t + 1] : L.s_idx[4 * (t - nr) + 1];
-        if (vb >= 0) L.Hs[sky(L, 6 * max(va, vb), 6 * min(va, vb))] = (double)(t + 1);
-    }
+        return vb >= 0 ? sky(L, 6 * max(va, vb), 6 * min(va, vb)) : -1;
+    };
+    for (int t = lane; t < nr + ns; t += 64) { const int a0 = block_entry(t); if (a0 >= 0) L.Hs[a0] = (double)(t + 1); }
     __syncthreads();
-    for (int t = lane; t < nr + ns; t += 64) {
-        const bool is_r = t < nr;
-        const int va = is_r ? L.r_idx[2 * t] : L.s_idx[4 * (t - nr)], vb = is_r ? L.r_idx[2 * t + 1] : L.s_idx[4 * (t - nr) + 1];
-        if (vb >= 0 && L.Hs[sky(L, 6 * max(va, vb), 6 * min(va, vb))] != (double)(t + 1)) clash = true;
-    }
+    for (int t = lane; t < nr + ns; t += 64) { const int a0 = block_entry(t); if (a0 >= 0 && L.Hs[a0] != (double)(t + 1)) L.Hs[a0] = -1.0; }
     __syncthreads();
-    return __any(clash);
-}
-// Fold the edge records into H (skyline lower triangle) and b, one edge after the other (fixed order: bit-reproducible).
-__device__ __forceinline__ void build_system(const WindowArgs& a, const Lds& L, int inst, int lane, int n, int nr, int np, int ns) {
-    (void)a; (void)inst;
-    const int nnz = L.boff[n / 6];
-    for (int i = lane; i < nnz; i += 64) L.Hs[i] = 0.0;
-    for (int i = lane; i < n; i += 64) L.b[i] = 0.0;
-    __syncthreads();
-    const int r = lane / 6, cc = lane % 6;  // lanes 0..35: one entry of a 6x6 block
-    // (the endpoints of edge e + 1 are fetched while edge e is folded: with the tables in HBM the fold of one edge is
-    //  otherwise two dependent round trips, indices then H entries; the compiler may not hoist the load over the stores)
-    int nv0 = nr > 0 ? L.r_idx[0] : 0, nv1 = nr > 0 ? L.r_idx[1] : 0;
-    for (int e = 0; e < nr; ++e) {
-        const int v0 = nv0, v1 = nv1;
-        if (e + 1 < nr) { nv0 = L.r_idx[2 * e + 2]; nv1 = L.r_idx[2 * e + 3]; }
-        const double* rec = L.rrec + e * RREC;
-        const double wr = rec[12], om = rec[13];
-        if (lane < 36) {
-            // the (up to) three blocks an edge touches are distinct: read all three entries, then add, then store — one
-            // memory round trip per edge instead of three dependent read-modify-writes
-            const bool lower = r >= cc, bin = v1 >= 0;
-            const int a0 = lower ? sky(L, v0 * 6 + r, v0 * 6 + cc) : 0;
-            const int a1 = (bin && lower) ? sky(L, v1 * 6 + r, v1 * 6 + cc) : 0;
-            const int ax = !bin ? 0 : (v0 > v1) ? sky(L, v0 * 6 + r, v1 * 6 + cc) : sky(L, v1 * 6 + r, v0 * 6 + cc);
-            double h0 = lower ? L.Hs[a0] : 0.0, h1 = (bin && lower) ? L.Hs[a1] : 0.0, hx = bin ? L.Hs[ax] : 0.0;
-            h0 += wr * rec[r] * rec[cc];
-            if (bin) {
-                h1 += wr * rec[6 + r] * rec[6 + cc];
-                if (v0 > v1) hx += wr * rec[r] * rec[6 + cc];
-                else         hx += wr * rec[6 + r] * rec[cc];
-            }
-            if (lower) L.Hs[a0] = h0;
-            if (bin && lower) L.Hs[a1] = h1;
-            if (bin) L.Hs[ax] = hx;
-        } else if (lane < 42) {
-            L.b[v0 * 6 + lane - 36] += rec[lane - 36] * om;
-        } else if (lane < 48 && v1 >= 0) {
-            L.b[v1 * 6 + lane - 42] += rec[6 + lane - 42] * om;
+    if (lane == 0) {
+        int cnt = 0;
+        for (int t = 0; t < nr + ns; ++t) {
+            const int a0 = block_entry(t);
+            if (a0 < 0) continue;
+            const double stamp = L.Hs[a0];
+            if (stamp == -1.0) { L.shared[1 + cnt++] = (1 << INC_KIND_SHIFT) | t; L.Hs[a0] = -2.0; }  // first edge of its pair
+            else if (stamp == -2.0) L.shared[1 + cnt++] = t;
         }
-    }
-    int nv = np > 0 ? L.p_idx[0] : 0;
-    for (int e = 0; e < np; ++e) {
-        const int v = nv;
-        if (e + 1 < np) nv = L.p_idx[e + 1];
-        const double* rec = L.prec + e * PREC;
-        if (lane < 36) {
-            if (r >= cc) {
-                double s = 0.0;
-#pragma unroll
-                for (int i = 0; i < 6; ++i) s += rec[i * 6 + r] * rec[36 + i] * rec[i * 6 + cc];
-                L.Hs[sky(L, v * 6 + r, v * 6 + cc)] += s;
-            }
-        } else if (lane < 42) {
-            const int rr = lane - 36;
-            double s = 0.0;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) s += rec[i * 6 + rr] * rec[42 + i];
-            L.b[v * 6 + rr] += s;
-        }
-    }
-    int nvi = ns > 0 ? L.s_idx[0] : 0, nvj = ns > 0 ? L.s_idx[1] : 0;
-    for (int e = 0; e < ns; ++e) {
-        const int vi = nvi, vj = nvj;
-        if (e + 1 < ns) { nvi = L.s_idx[4 * e + 4]; nvj = L.s_idx[4 * e + 5]; }
-        const double* rec = L.srec + e * SREC;
-        const double *J0 = rec, *J1 = rec + 36, *WJ0 = rec + 72, *WJ1 = rec + 108, *om = rec + 144;
-        if (lane < 36) {
-            double sii = 0.0, sjj = 0.0, sx = 0.0;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                sii += J0[i * 6 + r] * WJ0[i * 6 + cc];
-                sjj += J1[i * 6 + r] * WJ1[i * 6 + cc];
-                sx += (vi > vj) ? J0[i * 6 + r] * WJ1[i * 6 + cc] : J1[i * 6 + r] * WJ0[i * 6 + cc];  // rows of the later pose
-            }
-            const bool lower = r >= cc;
-            const int ai = lower ? sky(L, vi * 6 + r, vi * 6 + cc) : 0, aj = lower ? sky(L, vj * 6 + r, vj * 6 + cc) : 0;
-            const int ax = (vi > vj) ? sky(L, vi * 6 + r, vj * 6 + cc) : sky(L, vj * 6 + r, vi * 6 + cc);
-            double hi = lower ? L.Hs[ai] : 0.0, hj = lower ? L.Hs[aj] : 0.0, hx = L.Hs[ax];  // three distinct blocks: one round trip
-            hi += sii; hj += sjj; hx += sx;
-            if (lower) { L.Hs[ai] = hi; L.Hs[aj] = hj; }
-            L.Hs[ax] = hx;
-        } else if (lane < 48) {
-            const bool second = lane >= 42;
-            const int rr = second ? lane - 42 : lane - 36;
-            const double* J = second ? J1 : J0;
-            double s = 0.0;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) s += J[i * 6 + rr] * om[i];
-            L.b[(second ? vj : vi) * 6 + rr] += s;
-        }
+        L.shared[0] = cnt;
     }
     __syncthreads();
 }
-
-// The same H and b, entry for entry and addition for addition, but gathered instead of scattered: task (pose v, entry)
-// walks v's incidence list (fold order) and sums that entry of the diagonal block / of b in a register, one store at the
-// end; every off-diagonal block belongs to exactly one edge (the caller checked: no two binary edges on one pair of
-// poses) and is written, not accumulated.  No read-modify-write chains through memory, all tasks independent: what was
-// one dependent memory round trip per edge becomes a few pipelined loads per list entry across 64 lanes.
-__device__ __forceinline__ void build_system_gather(const Lds& L, int lane, int n, int nr, int ns) {
+// Fold the edge records into H (skyline lower triangle) and b: H_vv = sum J_v^T (rho' Omega) J_v etc., every entry summed
+// over its edges in one fixed order (ranges, priors, SE3; bit-reproducible, no atomics).  It is a gather: task
+// (pose v, entry) walks v's incidence list and sums that entry of the diagonal block / of b in a register, one store at
+// the end; an off-diagonal block that belongs to one edge is written by it; the few pairs of poses with several edges
+// (a key-frame pose edge landing on the previous pose next to the smoothness edge) are accumulated edge by edge at the
+// end.  No read-modify-write chains through memory for the bulk, all tasks independent.
+__device__ __forceinline__ void build_system(const Lds& L, int lane, int n, int nr, int ns) {
     const int nv = n / 6;
     const int nnz = L.boff[nv];
     for (int i = lane; i < nnz; i += 64) L.Hs[i] = 0.0;
@@ -567,29 +484,44 @@ __device__ __forceinline__ void build_system_gather(const Lds& L, int lane, int 
         if (is_b) L.b[v * 6 + rb] = acc;
         else L.Hs[sky(L, v * 6 + r, v * 6 + cc)] = acc;
     }
-    for (int task = lane; task < (nr + ns) * 36; task += 64) {
-        const int t = task / 36, q = task - 36 * t;
-        const int r = q / 6, cc = q - 6 * r;
+    // off-diagonal blocks: one task per (binary edge, entry); the value of entry (r, cc) of edge t
+    auto offdiag = [&](int t, int r, int cc, int& addr) {
+        double h = 0.0;
         if (t < nr) {
             const int v0 = L.r_idx[2 * t], v1 = L.r_idx[2 * t + 1];
-            if (v1 < 0) continue;
             const double* rec = L.rrec + t * RREC;
             const double wr = rec[12];
-            double h = 0.0;
-            if (v0 > v1) { h += wr * rec[r] * rec[6 + cc]; L.Hs[sky(L, v0 * 6 + r, v1 * 6 + cc)] = h; }
-            else         { h += wr * rec[6 + r] * rec[cc]; L.Hs[sky(L, v1 * 6 + r, v0 * 6 + cc)] = h; }
+            if (v0 > v1) { h = wr * rec[r] * rec[6 + cc]; addr = sky(L, v0 * 6 + r, v1 * 6 + cc); }
+            else         { h = wr * rec[6 + r] * rec[cc]; addr = sky(L, v1 * 6 + r, v0 * 6 + cc); }
         } else {
             const int e = t - nr;
             const int vi = L.s_idx[4 * e], vj = L.s_idx[4 * e + 1];
             const double* rec = L.srec + e * SREC;
             const double *J0 = rec, *J1 = rec + 36, *WJ0 = rec + 72, *WJ1 = rec + 108;
-            double sx = 0.0;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) sx += (vi > vj) ? J0[i * 6 + r] * WJ1[i * 6 + cc] : J1[i * 6 + r] * WJ0[i * 6 + cc];  // rows of the later pose
-            double h = 0.0;
-            h += sx;
-            if (vi > vj) L.Hs[sky(L, vi * 6 + r, vj * 6 + cc)] = h;
-            else         L.Hs[sky(L, vj * 6 + r, vi * 6 + cc)] = h;
+            for (int i = 0; i < 6; ++i) h += (vi > vj) ? J0[i * 6 + r] * WJ1[i * 6 + cc] : J1[i * 6 + r] * WJ0[i * 6 + cc];  // rows of the later pose
+            addr = (vi > vj) ? sky(L, vi * 6 + r, vj * 6 + cc) : sky(L, vj * 6 + r, vi * 6 + cc);
+        }
+        return h;
+    };
+    for (int task = lane; task < (nr + ns) * 36; task += 64) {
+        const int t = task / 36, q = task - 36 * t;
+        if (t < nr && L.r_idx[2 * t + 1] < 0) continue;  // a range to a fixed anchor has no off-diagonal block
+        int addr;
+        const double h = offdiag(t, q / 6, q - 6 * (q / 6), addr);
+        L.Hs[addr] = h;   // (for a pair with several edges this is overwritten below)
+    }
+    __syncthreads();
+    // pairs of poses with several edges: their blocks are accumulated edge by edge, in fold order
+    const int n_shared = L.shared[0];
+    for (int i = 1; i <= n_shared; ++i) {
+        const int code = L.shared[i];
+        const int t = code & INC_EDGE_MASK;
+        const bool first = (code >> INC_KIND_SHIFT) != 0;
+        if (lane < 36) {
+            int addr;
+            const double h = offdiag(t, lane / 6, lane % 6, addr);
+            L.Hs[addr] = first ? h : L.Hs[addr] + h;
         }
     }
     __syncthreads();
@@ -808,6 +740,7 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
         L.ioff = reinterpret_cast<int*>(p); p += (c.nv_max + 2) / 2;
     }
     L.ilist = reinterpret_cast<int*>(p); p += (window_incidences(c) + 1) / 2;
+    L.shared = reinterpret_cast<int*>(p); p += (c.nr_max + c.ns_max + 2) / 2;
     double* gpose = a.poses + (size_t)inst * c.nv_max * 12;
     for (int i = lane; i < nv * 12; i += 64) L.pose[i] = gpose[i];
     if (GLOBAL_A) {
@@ -830,7 +763,7 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
         for (int i = lane; i < ns * 48; i += 64) st_sval[i] = a.s_val[(size_t)inst * c.ns_max * 48 + i];
     }
     __syncthreads();
-    const bool serial_fold = compute_skyline(L, lane, n, nr, np, ns);
+    compute_skyline(L, lane, n, nr, np, ns);
 
     constexpr double tau = 1e-5, good_lo = 1.0 / 3.0, good_hi = 2.0 / 3.0;
     constexpr int max_trials = 10;
@@ -853,8 +786,7 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
         evaluate_edges<true>(a, L, inst, lane, nr, np, ns, cur_chi, plain);  // computeActiveErrors + linearize
         last_plain = plain;
         __syncthreads();
-        if (serial_fold) build_system(a, L, inst, lane, n, nr, np, ns);
-        else build_system_gather(L, lane, n, nr, ns);
+        build_system(L, lane, n, nr, ns);
         LOCAMD_T1(t_bd);
         if (it == 0) {  // computeLambdaInit
             double md = 0.0;
@@ -920,7 +852,7 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
     if (lane == 0) {
         double* res = a.result + (size_t)inst * 8;
         res[0] = last_plain; res[1] = cur_chi; res[2] = lambda; res[3] = (double)it; res[4] = (double)trials;
-        res[5] = (double)terminated; res[6] = 0.0; res[7] = 0.0;
+        res[5] = (double)terminated; res[6] = (double)L.shared[0]; res[7] = 0.0;
 #ifdef LOCAMD_WINDOW_TIMING
         res[6] = (double)t_fs * 1e6 + (double)t_ev * 1e-3; res[7] = (double)t_bd * 1e6 + (double)(clock64() - t_start) * 1e-3;
         res[0] = (double)L.tim[0]; res[1] = (double)L.tim[1]; res[2] = (double)L.tim[2]; res[5] = (double)L.tim[3];

@@ -95,6 +95,9 @@ def test_window_matches_oracle(gpu, T, with_imu, with_pose_edges, lever):
     dt = np.abs(got_t - want_t)
     dR = np.abs(got_R - want_R)
     assert np.isfinite(got_t).all() and np.isfinite(got_R).all()
+    # result[6]: binary edges that share their pair of poses with another edge (their blocks are accumulated edge by edge).
+    # A key-frame pose edge onto the previous pose shares its pair with the smoothness edge; without pose edges: none.
+    assert ((res[:, 6] > 0) == (with_pose_edges and T > 1)).all()
     assert dt.max() < 1e-7 and np.median(dt) < 1e-9, (dt.max(), np.median(dt))
     assert dR.max() < 1e-7, dR.max()
     assert np.abs(res[:, 0] - want_chi).max() <= 1e-6 * max(1.0, np.abs(want_chi).max())
@@ -167,11 +170,11 @@ def test_window_rejects_bad_indices(gpu):
     solver.close()
 
 
-def test_two_edges_on_one_pair_of_poses_take_the_serial_fold(gpu):
+def test_several_edges_on_one_pair_of_poses(gpu):
     """A smoothness range AND an EdgeSE3 (and, in half the instances, a second range) between the same two poses — what the
     reference produces when a twist edge and the key-frame pose edge meet (localization.cpp:276-281, 446-450).  Their
-    off-diagonal block then has more than one contributor: the kernel detects it and folds edge by edge; the result
-    matches the oracle like every other graph."""
+    off-diagonal block then has more than one contributor: the kernel finds those pairs once per solve and accumulates
+    their blocks edge by edge; the result matches the oracle like every other graph."""
     import localization_amd as la
     from oracle import oracle as O
     rng = np.random.default_rng(11)
@@ -203,7 +206,8 @@ def test_two_edges_on_one_pair_of_poses_take_the_serial_fold(gpu):
         for k in range(T):
             want_t[i, k] = g.estimate(100 + k)[1]
     solver = la.WindowSolver(ANCH, B, *wb.caps, maximum_iteration=10, bw_max=1)
-    solver.solve(wb)
+    res = solver.solve(wb)
     solver.close()
+    assert (res[::2, 6] == 2 * (T - 1)).all() and (res[1::2, 6] == 3 * (T - 1)).all()   # every binary edge is on a shared pair
     d = np.abs(wb.poses[:, :, 9:] - want_t)
     assert np.isfinite(wb.poses).all() and d.max() < 1e-7 and np.median(d) < 1e-9, (d.max(), np.median(d))
