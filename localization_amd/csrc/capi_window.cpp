@@ -3,6 +3,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+
 #include <new>
 #include <string>
 #include <vector>
@@ -30,7 +32,10 @@ struct loc_window {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_ms = 0.0;
+    // small calls (a node's single window): all inputs travel as one page-locked block, all outputs as another
+    char *h_stage = nullptr, *d_stage = nullptr;
 };
+static constexpr size_t kStageBytes = 4u << 20;
 
 extern "C" {
 
@@ -54,6 +59,8 @@ int loc_window_destroy(loc_window* w) {
     (void)hipSetDevice(w->device);
     void* ptrs[] = {w->d_anchors, w->d_counts, w->d_ridx, w->d_pidx, w->d_sidx, w->d_poses, w->d_rval, w->d_pval, w->d_sval, w->d_result, w->d_workspace};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (w->h_stage) (void)hipHostFree(w->h_stage);
+    if (w->d_stage) (void)hipFree(w->d_stage);
     if (w->ev0) (void)hipEventDestroy(w->ev0);
     if (w->ev1) (void)hipEventDestroy(w->ev1);
     if (w->stream) (void)hipStreamDestroy(w->stream);
@@ -154,6 +161,46 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
     LOC_HIP(hipSetDevice(w->device));
     const size_t N = (size_t)n;
     hipStream_t st = w->stream;
+    {
+        // Single-block path: [poses | result | counts | r_val | p_val | s_val | r_idx | p_idx | s_idx], 16-byte aligned
+        // pieces, sized for this call's n.  One H2D copy, one launch, one D2H copy of [poses | result]: a node's solve is
+        // then ~0.2 ms of host/PCIe overhead around the kernel instead of a dozen small pageable copies.
+        auto al = [](size_t b) { return (b + 15) & ~(size_t)15; };
+        const size_t sz[9] = {al(N * c.nv_max * 12 * sizeof(double)), al(N * 8 * sizeof(double)), al(N * 4 * sizeof(int32_t)),
+                              al(N * c.nr_max * 5 * sizeof(double)), al(N * c.np_max * 18 * sizeof(double)), al(N * c.ns_max * 48 * sizeof(double)),
+                              al(N * c.nr_max * 2 * sizeof(int32_t)), al(N * c.np_max * sizeof(int32_t)), al(N * c.ns_max * 4 * sizeof(int32_t))};
+        size_t off[10]; off[0] = 0;
+        for (int i = 0; i < 9; ++i) off[i + 1] = off[i] + sz[i];
+        if (off[9] <= kStageBytes) {
+            if (!w->h_stage) LOC_HIP(hipHostMalloc((void**)&w->h_stage, kStageBytes, hipHostMallocDefault));
+            if (!w->d_stage) LOC_HIP(hipMalloc((void**)&w->d_stage, kStageBytes));
+            char* h = w->h_stage; char* d = w->d_stage;
+            std::memcpy(h + off[0], poses, N * c.nv_max * 12 * sizeof(double));
+            std::memcpy(h + off[2], counts, N * 4 * sizeof(int32_t));
+            if (c.nr_max) { std::memcpy(h + off[3], r_val, N * c.nr_max * 5 * sizeof(double)); std::memcpy(h + off[6], r_idx, N * c.nr_max * 2 * sizeof(int32_t)); }
+            if (c.np_max) { std::memcpy(h + off[4], p_val, N * c.np_max * 18 * sizeof(double)); std::memcpy(h + off[7], p_idx, N * c.np_max * sizeof(int32_t)); }
+            if (c.ns_max) { std::memcpy(h + off[5], s_val, N * c.ns_max * 48 * sizeof(double)); std::memcpy(h + off[8], s_idx, N * c.ns_max * 4 * sizeof(int32_t)); }
+            LOC_HIP(hipMemcpyAsync(d, h, off[9], hipMemcpyHostToDevice, st));
+            locamd::WindowArgs a;
+            a.poses = (double*)(d + off[0]); a.result = (double*)(d + off[1]); a.counts = (const int32_t*)(d + off[2]);
+            a.r_val = (const double*)(d + off[3]); a.p_val = (const double*)(d + off[4]); a.s_val = (const double*)(d + off[5]);
+            a.r_idx = (const int32_t*)(d + off[6]); a.p_idx = (const int32_t*)(d + off[7]); a.s_idx = (const int32_t*)(d + off[8]);
+            a.anchors = w->d_anchors; a.workspace = w->d_workspace;
+            a.n_anchors = w->n_anchors; a.B = (int)n; a.iterations = w->iterations; a.caps = c;
+            LOC_HIP(hipEventRecord(w->ev0, st));
+            hipError_t e = locamd::launch_window(a, st);
+            if (e != hipSuccess) return locamd_fail_hip(e, "launch_window");
+            LOC_HIP(hipEventRecord(w->ev1, st));
+            LOC_HIP(hipMemcpyAsync(h, d, off[2], hipMemcpyDeviceToHost, st));  // [poses | result]
+            LOC_HIP(hipStreamSynchronize(st));
+            std::memcpy(poses, h + off[0], N * c.nv_max * 12 * sizeof(double));
+            std::memcpy(result, h + off[1], N * 8 * sizeof(double));
+            float ms = 0;
+            LOC_HIP(hipEventElapsedTime(&ms, w->ev0, w->ev1));
+            w->last_ms = ms;
+            return LOC_OK;
+        }
+    }
     LOC_HIP(hipMemcpyAsync(w->d_counts, counts, N * 4 * sizeof(int32_t), hipMemcpyHostToDevice, st));
     LOC_HIP(hipMemcpyAsync(w->d_poses, poses, N * c.nv_max * 12 * sizeof(double), hipMemcpyHostToDevice, st));
     if (c.nr_max) {

@@ -120,7 +120,8 @@ struct loc_node {
     bool deferred = false, pending = false;
     loc_window* win = nullptr;            // cached single-instance solver (anchors are part of its device state)
     std::vector<double> win_anchors;
-    loc_window_caps caps{16, 64, 32, 32, -1};  // sized for the window in loc_node_create
+    loc_window_caps caps{16, 64, 32, 32, -1};  // LIMITS of what pack() accepts, set in loc_node_create
+    loc_window_caps win_caps{0, 0, 0, 0, 0};   // capacities of the cached handle: what the packed graphs needed so far
 
     RobotRing* robot(int id) { for (auto& r : robots) if (r.id == id) return &r; return nullptr; }
     void remove_vertex(int vid) {  // optimizer.removeVertex(v, false): the vertex and every edge touching it
@@ -197,10 +198,10 @@ int pack(const loc_node* n, Packed& P) {
     if ((int)slot.size() != k) return locamd_fail(LOC_ERR_INVALID, "internal: active vertex outside every robot ring");
     if (k > c.nv_max) return locamd_fail(LOC_ERR_UNSUPPORTED, "window has more active poses than the node was sized for");
     P.counts.assign(4, 0);
-    P.poses.assign((size_t)c.nv_max * 12, 0.0);
-    P.r_idx.assign((size_t)c.nr_max * 2, 0); P.r_val.assign((size_t)c.nr_max * 5, 0.0);
-    P.p_idx.assign((size_t)c.np_max, 0); P.p_val.assign((size_t)c.np_max * 18, 0.0);
-    P.s_idx.assign((size_t)c.ns_max * 4, 0); P.s_val.assign((size_t)c.ns_max * 48, 0.0);
+    P.poses.assign((size_t)k * 12, 0.0);
+    P.r_idx.assign(n->ranges.size() * 2, 0); P.r_val.assign(n->ranges.size() * 5, 0.0);
+    P.p_idx.assign(n->priors.size(), 0); P.p_val.assign(n->priors.size() * 18, 0.0);
+    P.s_idx.assign(n->se3s.size() * 4, 0); P.s_val.assign(n->se3s.size() * 48, 0.0);
     P.anchors.assign(std::max<size_t>(anchor_ix.size(), 1) * 3, 0.0);
     for (auto& kv : slot) {
         const Vertex& v = n->vertices.at(kv.first);
@@ -247,7 +248,35 @@ int pack(const loc_node* n, Packed& P) {
         ++ns;
     }
     P.counts[0] = (int32_t)slot.size(); P.counts[1] = nr; P.counts[2] = np; P.counts[3] = ns;
+    P.r_idx.resize((size_t)nr * 2); P.r_val.resize((size_t)nr * 5);   // (edges between fixed vertices were skipped)
+    P.p_idx.resize((size_t)np); P.p_val.resize((size_t)np * 18);
+    P.s_idx.resize((size_t)ns * 4); P.s_val.resize((size_t)ns * 48);
     return LOC_OK;
+}
+
+// Capacities a solver handle needs for this packed graph, never below `have` (handles only grow: a window that slides
+// keeps its shape, so after the warm-up the handle is created once).  Tight on purpose: the per-instance storage decides
+// whether the window lives in LDS and how many fit a CU.
+loc_window_caps grown_caps(const loc_window_caps& have, const Packed& P) {
+    auto up = [](int v, int m) { return (v + m - 1) / m * m; };
+    loc_window_caps c = have;
+    c.nv_max = std::max(have.nv_max, std::max(1, (int)P.counts[0]));
+    c.nr_max = std::max(have.nr_max, up(P.counts[1], 8));
+    c.np_max = std::max(have.np_max, up(P.counts[2], 4));
+    c.ns_max = std::max(have.ns_max, up(P.counts[3], 4));
+    c.bw_max = std::min(c.nv_max - 1, std::max(have.bw_max, std::max(1, P.band)));
+    if (c.bw_max < 0) c.bw_max = 0;
+    return c;
+}
+bool same_caps(const loc_window_caps& a, const loc_window_caps& b) {
+    return a.nv_max == b.nv_max && a.nr_max == b.nr_max && a.np_max == b.np_max && a.ns_max == b.ns_max && a.bw_max == b.bw_max;
+}
+// the solver reads whole [cap] rows
+void pad_to(Packed& P, const loc_window_caps& c) {
+    P.poses.resize((size_t)c.nv_max * 12, 0.0);
+    P.r_idx.resize((size_t)c.nr_max * 2, 0); P.r_val.resize((size_t)c.nr_max * 5, 0.0);
+    P.p_idx.resize((size_t)c.np_max, 0); P.p_val.resize((size_t)c.np_max * 18, 0.0);
+    P.s_idx.resize((size_t)c.ns_max * 4, 0); P.s_val.resize((size_t)c.ns_max * 48, 0.0);
 }
 
 void fill_output(loc_node* n, const double* res, loc_node_output* out) {
@@ -270,16 +299,19 @@ int solve_now(loc_node* n, loc_node_output* out) {
     if (rc != LOC_OK) return rc;
     double res[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (P.counts[0] > 0) {
-        // the anchor table is device state of the solver handle: keep one handle per node, rebuilt only when the set
-        // of fixed vertices seen by the window changes
-        const int want_bw = n->caps.nv_max <= 16 ? -1 : std::min(n->caps.nv_max - 1, std::max(8, P.band));
-        if (want_bw >= 0 && (n->caps.bw_max < 0 || want_bw > n->caps.bw_max)) {  // grow the band capacity (rare)
-            n->caps.bw_max = want_bw;
-            if (n->win) { loc_window_destroy(n->win); n->win = nullptr; }
-        }
-        if (!n->win || n->win_anchors != P.anchors) {
-            if (n->win) { loc_window_destroy(n->win); n->win = nullptr; }
-            rc = loc_window_create(&n->win, n->device, 1, &n->caps, (int32_t)(P.anchors.size() / 3), P.anchors.data(), n->cfg.maximum_iteration);
+        // one solver handle per node, re-created only while the window is still growing into its final shape
+        const loc_window_caps want = grown_caps(n->win_caps, P);
+        if (n->win && !same_caps(want, n->win_caps)) { loc_window_destroy(n->win); n->win = nullptr; }
+        n->win_caps = want;
+        pad_to(P, want);
+        if (!n->win) {
+            rc = loc_window_create(&n->win, n->device, 1, &n->win_caps, (int32_t)(P.anchors.size() / 3), P.anchors.data(), n->cfg.maximum_iteration);
+            if (rc != LOC_OK) return rc;
+            n->win_anchors = P.anchors;
+        } else if (n->win_anchors != P.anchors) {
+            // the fixed vertices the window sees (or just their order) change as the window slides: refresh the table,
+            // keep the handle — creating one costs milliseconds of hipMalloc / stream / event set-up per solve
+            rc = loc_window_set_anchors(n->win, (int32_t)(P.anchors.size() / 3), P.anchors.data());
             if (rc != LOC_OK) return rc;
             n->win_anchors = P.anchors;
         }
@@ -349,6 +381,8 @@ int loc_node_create(loc_node** out, int32_t device, const loc_node_config* cfg, 
         n->caps.np_max = tv <= 16 ? 32 : tv;
         n->caps.ns_max = tv <= 16 ? 32 : tv;
         n->caps.bw_max = -1;
+        n->win_caps.nv_max = tv;                 // the window's final pose count is known; edges and band grow on demand
+        n->win_caps.nr_max = 2 * tv + 8;         // the two-edge range topology (localization.cpp:327-357)
     }
     for (int i = 0; i < n_nodes; ++i) {  // :92-108 and Robot::init, robot.cpp:31-58
         RobotRing r;
@@ -556,12 +590,13 @@ int loc_nodes_solve_batch(loc_node** nodes, int32_t n_nodes, loc_node_output* ou
         todo.push_back(i);
     }
     if (todo.empty()) return 0;
-    loc_window_caps caps = nodes[todo[0]]->caps;
-    {
-        int band = 0;
-        for (int i : todo) band = std::max(band, P[(size_t)i].band);
-        caps.bw_max = caps.nv_max <= 16 ? -1 : std::min(caps.nv_max - 1, std::max(8, band));
-    }
+    loc_node* first = nodes[todo[0]];
+    // one cached batch solver per thread: re-created only when the capacities or the batch size grow, or the device changes
+    struct BatchCache { loc_window* w = nullptr; loc_window_caps caps{0, 0, 0, 0, 0}; int device = -1; size_t B = 0; int iters = 0; };
+    static thread_local BatchCache cache;
+    const bool reusable = cache.w && cache.device == first->device && cache.iters == first->cfg.maximum_iteration;
+    loc_window_caps caps = reusable ? cache.caps : loc_window_caps{0, 0, 0, 0, 0};
+    for (int i : todo) caps = grown_caps(caps, P[(size_t)i]);
     const size_t B = todo.size();
     std::vector<int32_t> counts(B * 4), r_idx(B * caps.nr_max * 2), p_idx(B * caps.np_max), s_idx(B * caps.ns_max * 4);
     std::vector<double> poses(B * caps.nv_max * 12), r_val(B * caps.nr_max * 5), p_val(B * caps.np_max * 18),
@@ -580,12 +615,7 @@ int loc_nodes_solve_batch(loc_node** nodes, int32_t n_nodes, loc_node_output* ou
         std::copy(p.s_idx.begin(), p.s_idx.end(), s_idx.begin() + b * caps.ns_max * 4);
         std::copy(p.s_val.begin(), p.s_val.end(), s_val.begin() + b * caps.ns_max * 48);
     }
-    loc_node* first = nodes[todo[0]];
-    // one cached batch solver per thread: re-created only when the capacities, the device or the batch size grow
-    struct BatchCache { loc_window* w = nullptr; loc_window_caps caps{0, 0, 0, 0}; int device = -1; size_t B = 0; int iters = 0; };
-    static thread_local BatchCache cache;
-    if (!cache.w || cache.device != first->device || cache.B < B || cache.iters != first->cfg.maximum_iteration ||
-        std::memcmp(&cache.caps, &caps, sizeof(caps)) != 0) {
+    if (!reusable || cache.B < B || !same_caps(cache.caps, caps)) {
         if (cache.w) { loc_window_destroy(cache.w); cache.w = nullptr; }
         int rc0 = loc_window_create(&cache.w, first->device, (int64_t)B, &caps, (int32_t)(anchors.size() / 3), anchors.data(), first->cfg.maximum_iteration);
         if (rc0 != LOC_OK) return rc0;
