@@ -84,3 +84,24 @@ def test_config_loader_reads_reference_style_yaml(tmp_path):
     d = la.LocalizationConfig()               # reference defaults (localization.cpp:58-159)
     assert (d.maximum_iteration, d.minimum_optimize_error, d.maximum_velocity, d.distance_outlier) == (20, 1000.0, 1.0, 1.0)
     assert d.trajectory_length is None and d.frame_target == "estimation" and d.frame_source == "local_origin"
+
+
+def test_header_is_plain_c_and_a_c_program_links(tmp_path, built):
+    """The boundary is a C ABI: the header compiles as strict C99 (no C++ types leak through), and a C program links against
+    liblocalization_amd.so and runs its non-compute entry points on a machine without a GPU."""
+    import subprocess
+    src = tmp_path / "abi_c.c"
+    src.write_text('#include "localization_amd.h"\n'
+                   "int main(void) {\n"
+                   "  loc_snapshot_params p; loc_node_config c; loc_fusion_params f;\n"
+                   "  loc_snapshot_default_params(&p); loc_node_default_config(&c); loc_fusion_default_params(&f);\n"
+                   "  if (loc_abi_version() != LOC_ABI_VERSION) return 1;\n"
+                   "  if (p.maximum_iteration != 20 || c.maximum_iteration != 20) return 2;   /* reference default, localization.cpp:65 */\n"
+                   "  return 0;\n}\n")
+    inc = os.path.join(ROOT, "include")
+    libdir = os.path.join(ROOT, "localization_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)])
+    exe = tmp_path / "abi_c"
+    subprocess.check_call(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-llocalization_amd",
+                           "-Wl,-rpath," + libdir])
+    assert subprocess.call([str(exe)]) == 0
