@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define LOC_ABI_VERSION 1
+#define LOC_ABI_VERSION 2 /* 2: jacobian mode for every solver, resident window solves, loc_node_add_rl_range */
 
 typedef enum loc_status {
     LOC_OK = 0,
@@ -135,7 +135,8 @@ int loc_snapshot_timing_end(loc_snapshot* s, int32_t* n_launches, double* total_
  * with an antenna lever arm on endpoint 0 (localization.cpp:331-340, types_edge_se3range.cpp:105-114),
  * EdgeSE3Prior with diagonal information (IMU / lidar, localization.cpp:476-486, 513-525) and EdgeSE3
  * (pose / twist, localization.cpp:263-281, 588-602).  Range and SE3 edges carry RobustKernelCauchy(1) as in the
- * reference (range always; SE3 per the `robust` flag); priors do not.  Jacobians are analytic.
+ * reference (range always; SE3 per the `robust` flag); priors do not.  Range Jacobians: analytic by default, g2o's
+ * central differences (the reference's configuration, types_edge_se3range.h:45-74) with loc_window_set_jacobian.
  *
  * Host layouts (arrays of B instances, fixed capacities per instance):
  *   counts int32 [B][4]           nv, nr, np, ns  (poses, range edges, priors, SE3 edges actually used)
@@ -173,6 +174,26 @@ int loc_window_solve_host(loc_window* w, int64_t n_instances, const int32_t* cou
                           const int32_t* s_idx, const double* s_val, double* result);
 /* kernel time of the last loc_window_solve_host launch (HIP events on its stream), milliseconds */
 int loc_window_last_kernel_ms(loc_window* w, double* ms);
+/* LOC_JAC_ANALYTIC (default) or LOC_JAC_NUMERIC_G2O for the EdgeSE3Range factors of every later solve */
+int loc_window_set_jacobian(loc_window* w, int32_t jacobian);
+/* Windows of up to 64 poses are eliminated in a minimum-degree order the kernel computes per instance (what CHOLMOD's AMD
+ * ordering does for the reference, localization.h:82-84: a key-frame star then factors without fill); natural != 0 keeps
+ * the caller's pose order instead.  Larger windows always use the caller's order (loc_node_* packs them leaf-first). */
+int loc_window_set_ordering(loc_window* w, int32_t natural);
+/* Device-resident operation: upload n instances once (same host layouts as loc_window_solve_host), then run
+ * loc_window_solve_resident any number of times — each launch starts from the uploaded estimates, is asynchronous on
+ * hip_stream (NULL = the handle's own stream) and leaves poses / result on the device — and fetch them with
+ * loc_window_download (synchronises).  loc_window_timing_begin/_end bracket resident launches with HIP events on the
+ * stream they run on, like loc_snapshot_timing_*. */
+int loc_window_upload(loc_window* w, int64_t n_instances, const int32_t* counts, const double* poses,
+                      const int32_t* r_idx, const double* r_val, const int32_t* p_idx, const double* p_val,
+                      const int32_t* s_idx, const double* s_val);
+int loc_window_solve_resident(loc_window* w, void* hip_stream);
+int loc_window_download(loc_window* w, double* poses, double* result);
+void* loc_window_poses_device(loc_window* w);   /* double [B][nv_max][12] */
+void* loc_window_result_device(loc_window* w);  /* double [B][8] */
+int loc_window_timing_begin(loc_window* w, int32_t max_launches);
+int loc_window_timing_end(loc_window* w, int32_t* n_launches, double* total_ms, double* avg_ms);
 
 /* ================================================================================================
  * Node front-end — `class Localization` behind the ABI (one moving tag, its ring window, its anchors).
@@ -183,6 +204,8 @@ int loc_window_last_kernel_ms(loc_window* w, double* ms);
  *   loc_node_add_pose      Localization::addPoseEdge           localization.cpp:254-290
  *   loc_node_add_twist     Localization::addTwistEdge          localization.cpp:438-459, 560-605
  *   loc_node_add_lidar     Localization::addLidarEdge          localization.cpp:462-496
+ *   loc_node_add_rl_range  Localization::addRLRangeEdge        localization.cpp:378-436 (built only with -DRELATIVE_LOCALIZATION,
+ *                                                              CMakeLists.txt:137; message uwb_reloc::uwbTalkData)
  *   loc_node_solve         Localization::solve + publish       localization.cpp:164-251
  *   loc_node_get_path      Robot::vertices2path                robot.cpp:61-72
  * add_* return 1 when the call ran a solve (out is filled), 0 when it did not, < 0 on error.
@@ -199,6 +222,9 @@ typedef struct loc_node_config {
     double minimum_optimize_error;    /* optimizer/minimum_optimize_error (1000)  :68 */
     int32_t publish_range, publish_pose, publish_twist, publish_lidar, publish_imu; /* publish_flag/...  :146-158 */
     int32_t has_relative_range;       /* topic/relative_range present: every node moves  :94 */
+    int32_t jacobian;                 /* LOC_JAC_ANALYTIC (default) or LOC_JAC_NUMERIC_G2O = what the reference's EdgeSE3Range
+                                         inherits from g2o (types_edge_se3range.h:45-74) */
+    int32_t publish_relative_range;   /* publish_flag/relative_range  :158 */
 } loc_node_config;
 
 typedef struct loc_node_output {
@@ -224,14 +250,22 @@ int loc_node_add_pose(loc_node* n, double stamp, const double* pose_xyz_qxyzw, c
 int loc_node_add_twist(loc_node* n, double stamp, const double* twist_lin_ang6, const double* cov36,
                        const char* frame_id, loc_node_output* out);
 int loc_node_add_lidar(loc_node* n, double stamp, double z, const char* frame_id, loc_node_output* out);
+/* uwbTalkData: time_stamp, rqstrId, rspdrId, d, (rqstr_vx, rqstr_vy, rqstr_vz).  Peer range with the fixed sigma_d = 0.054 m, the
+ * responder's smoothness edge, and for a moving requester an EdgeSE3 from its previous pose with measurement
+ * translate(dt * v) and information diag(1/sigma_v^2 x3, 0 x3), no robust kernel; solves when publish_relative_range. */
+int loc_node_add_rl_range(loc_node* n, int32_t requester_id, int32_t responder_id, double stamp, double distance,
+                          const double* requester_velocity_xyz, loc_node_output* out);
 int loc_node_solve(loc_node* n, loc_node_output* out);
 int loc_node_get_path(loc_node* n, int32_t node_id, double* out_T_by_8, int32_t capacity_poses);
 int32_t loc_node_number_measurements(const loc_node* n);
 /* Fleet mode: with deferred on, add_* only mark the node "solve pending"; loc_nodes_solve_batch then solves every
- * pending node of the array in ONE launch (returns how many were solved). */
+ * pending node of the array in ONE launch per parameter group (returns how many were solved). */
 int loc_node_set_deferred(loc_node* n, int32_t on);
 int32_t loc_node_solve_pending(const loc_node* n);
 int loc_nodes_solve_batch(loc_node** nodes, int32_t n_nodes, loc_node_output* outs);
+/* loc_nodes_solve_batch groups the pending nodes by (device, maximum_iteration, jacobian) — one launch per group, every
+ * node solved with its own parameters — and keeps one batch solver per group cached for the calling thread; this frees them. */
+int loc_nodes_release_batch_cache(void);
 
 /* ================================================================================================
  * Batched fusion snapshot solver — BASELINE config 3 (8 anchors + IMU orientation prior, 6-DoF state).
@@ -253,6 +287,7 @@ typedef struct loc_fusion_params {
     int32_t gate_warmup_epochs;  /* default 1 */
     double antenna_offset[3];    /* /uwb/antennaOffset of the antenna every range uses (localization.cpp:111-123, 333) */
     int32_t block_threads;       /* 0 = 256 */
+    int32_t jacobian;            /* LOC_JAC_* for the range factors */
 } loc_fusion_params;
 
 void loc_fusion_default_params(loc_fusion_params* p);

@@ -27,6 +27,7 @@ public:
         int maximum_iteration = 20;
         bool publish_range = false, publish_pose = false, publish_twist = false, publish_lidar = false, publish_imu = false;
         bool relative_range_topic = false;
+        bool numeric_jacobian = false;        // true = g2o's central-difference range Jacobians, the reference's exact configuration
         std::vector<int> nodesId;            // /uwb/nodesId, last = the moving tag
         std::vector<double> nodesPos;        // /uwb/nodesPos
         std::vector<double> antennaOffset;   // /uwb/antennaOffset (may be empty)
@@ -41,6 +42,7 @@ public:
         c.minimum_optimize_error = p.minimum_optimize_error;
         c.publish_range = p.publish_range; c.publish_pose = p.publish_pose; c.publish_twist = p.publish_twist;
         c.publish_lidar = p.publish_lidar; c.publish_imu = p.publish_imu; c.has_relative_range = p.relative_range_topic;
+        c.jacobian = p.numeric_jacobian ? LOC_JAC_NUMERIC_G2O : LOC_JAC_ANALYTIC;
         std::vector<int32_t> ids(p.nodesId.begin(), p.nodesId.end());
         self_id_ = ids.empty() ? 0 : ids.back();
         const int rc = loc_node_create(&node_, p.device, &c, (int32_t)ids.size(), ids.data(), p.nodesPos.data(),

@@ -10,11 +10,11 @@ from ._lib import LocalizationAmdError, abi_version, device_count, lib, library_
 from .config import LocalizationConfig, load_config
 from .snapshot import SnapshotSolver, pack_ranges, unpack_ranges
 from .window import WindowBatch, WindowSolver
-from .node import LocalizationNode, solve_batch
+from .node import LocalizationNode, release_batch_cache, solve_batch
 from .fusion import FusionSolver
 from . import ate, bag
 
 __all__ = [
     "LocalizationAmdError", "abi_version", "device_count", "lib", "library_path",
-    "LocalizationConfig", "load_config", "SnapshotSolver", "pack_ranges", "unpack_ranges", "WindowBatch", "WindowSolver", "LocalizationNode", "solve_batch", "FusionSolver",
+    "LocalizationConfig", "load_config", "SnapshotSolver", "pack_ranges", "unpack_ranges", "WindowBatch", "WindowSolver", "LocalizationNode", "solve_batch", "release_batch_cache", "FusionSolver",
 ]

@@ -38,10 +38,13 @@ EXPORTED_SYMBOLS = [
     "loc_snapshot_solve_host_kmb", "loc_host_alloc", "loc_host_free",
     "loc_snapshot_timing_begin", "loc_snapshot_timing_end",
     "loc_window_create", "loc_window_destroy", "loc_window_set_anchors", "loc_window_lds_bytes", "loc_window_solve_host",
-    "loc_window_last_kernel_ms",
+    "loc_window_last_kernel_ms", "loc_window_set_jacobian", "loc_window_set_ordering", "loc_window_upload",
+    "loc_window_solve_resident", "loc_window_download", "loc_window_poses_device", "loc_window_result_device",
+    "loc_window_timing_begin", "loc_window_timing_end",
     "loc_node_default_config", "loc_node_create", "loc_node_destroy", "loc_node_add_range", "loc_node_add_imu",
-    "loc_node_add_pose", "loc_node_add_twist", "loc_node_add_lidar", "loc_node_solve", "loc_node_get_path",
+    "loc_node_add_pose", "loc_node_add_twist", "loc_node_add_lidar", "loc_node_add_rl_range", "loc_node_solve", "loc_node_get_path",
     "loc_node_number_measurements", "loc_node_set_deferred", "loc_node_solve_pending", "loc_nodes_solve_batch",
+    "loc_nodes_release_batch_cache",
     "loc_fusion_default_params", "loc_fusion_create", "loc_fusion_destroy", "loc_fusion_set_poses", "loc_fusion_get_poses",
     "loc_fusion_solve_device", "loc_fusion_solve_host", "loc_fusion_solve_host_kmb", "loc_fusion_last_kernel_ms",
 ]
@@ -88,6 +91,15 @@ def lib():
     L.loc_window_lds_bytes.argtypes = [vp]; L.loc_window_lds_bytes.restype = C.c_size_t
     L.loc_window_solve_host.argtypes = [vp, C.c_int64, ip, dp, ip, dp, ip, dp, ip, dp, dp]
     L.loc_window_last_kernel_ms.argtypes = [vp, dp]
+    L.loc_window_set_jacobian.argtypes = [vp, C.c_int32]
+    L.loc_window_set_ordering.argtypes = [vp, C.c_int32]
+    L.loc_window_upload.argtypes = [vp, C.c_int64, ip, dp, ip, dp, ip, dp, ip, dp]
+    L.loc_window_solve_resident.argtypes = [vp, vp]
+    L.loc_window_download.argtypes = [vp, dp, dp]
+    L.loc_window_poses_device.argtypes = [vp]; L.loc_window_poses_device.restype = vp
+    L.loc_window_result_device.argtypes = [vp]; L.loc_window_result_device.restype = vp
+    L.loc_window_timing_begin.argtypes = [vp, C.c_int32]
+    L.loc_window_timing_end.argtypes = [vp, ip, dp, dp]
     _LIB = L
     return L
 

@@ -89,7 +89,8 @@ int loc_fusion_create(loc_fusion** out, int32_t device, int64_t batch, int32_t n
     loc_fusion_params prm;
     if (params) prm = *params; else loc_fusion_default_params(&prm);
     if (prm.block_threads == 0) prm.block_threads = 256;
-    if (prm.block_threads % 64 || prm.block_threads > 256 || prm.gate_warmup_epochs < 0) return locamd_fail(LOC_ERR_INVALID, "fusion params");
+    if (prm.block_threads % 64 || prm.block_threads > 256 || prm.gate_warmup_epochs < 0 ||
+        (prm.jacobian != LOC_JAC_ANALYTIC && prm.jacobian != LOC_JAC_NUMERIC_G2O)) return locamd_fail(LOC_ERR_INVALID, "fusion params");
     LOC_HIP(hipSetDevice(device));
     loc_fusion* f = new (std::nothrow) loc_fusion();
     if (!f) return locamd_fail(LOC_ERR_INVALID, "out of host memory");
@@ -140,6 +141,7 @@ int loc_fusion_solve_device(loc_fusion* f, int32_t epochs, const float* dist, co
     a.dist = dist; a.err = err; a.imu = imu; a.pose = f->d_pose; a.out_pose = out_pose; a.out_chi2 = out_chi2; a.out_trials = out_trials;
     a.anchors = f->d_anchors; a.offset = f->d_offset; a.B = f->B; a.K = epochs; a.iterations = f->prm.maximum_iteration;
     a.gate = f->prm.distance_outlier;
+    a.jacobian = f->prm.jacobian;
     const long long left = (long long)f->prm.gate_warmup_epochs - f->epochs_done;
     a.gate_from_epoch = left > 0 ? (int)(left > epochs ? epochs : left) : 0;
     LOC_HIP(hipEventRecord(f->ev0, st));

@@ -25,13 +25,19 @@ struct loc_window {
     locamd::WindowCaps caps{};
     int n_anchors = 0, anchors_cap = 0;
     int iterations = 10;
+    int jacobian = LOC_JAC_ANALYTIC, natural_order = 0;
     double* d_anchors = nullptr;
     int32_t *d_counts = nullptr, *d_ridx = nullptr, *d_pidx = nullptr, *d_sidx = nullptr;
     double *d_poses = nullptr, *d_rval = nullptr, *d_pval = nullptr, *d_sval = nullptr, *d_result = nullptr;
     double* d_workspace = nullptr;  // HBM copy of the (H, L) matrices when they do not fit LDS
+    double* d_poses_in = nullptr;   // resident mode: the uploaded initial estimates (every resident solve starts from them)
+    long long n_resident = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_ms = 0.0;
+    std::vector<hipEvent_t> ev;     // loc_window_timing_*: one pair per resident launch
+    int ev_used = 0;
+    bool timing = false;
     // small calls (a node's single window): all inputs travel as one page-locked block, all outputs as another
     char *h_stage = nullptr, *d_stage = nullptr;
 };
@@ -57,8 +63,9 @@ size_t loc_window_lds_bytes(const loc_window_caps* caps) {
 int loc_window_destroy(loc_window* w) {
     if (!w) return LOC_OK;
     (void)hipSetDevice(w->device);
-    void* ptrs[] = {w->d_anchors, w->d_counts, w->d_ridx, w->d_pidx, w->d_sidx, w->d_poses, w->d_rval, w->d_pval, w->d_sval, w->d_result, w->d_workspace};
+    void* ptrs[] = {w->d_anchors, w->d_counts, w->d_ridx, w->d_pidx, w->d_sidx, w->d_poses, w->d_rval, w->d_pval, w->d_sval, w->d_result, w->d_workspace, w->d_poses_in};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (hipEvent_t e : w->ev) (void)hipEventDestroy(e);
     if (w->h_stage) (void)hipHostFree(w->h_stage);
     if (w->d_stage) (void)hipFree(w->d_stage);
     if (w->ev0) (void)hipEventDestroy(w->ev0);
@@ -126,15 +133,15 @@ int loc_window_set_anchors(loc_window* w, int32_t n_anchors, const double* ancho
     return LOC_OK;
 }
 
-int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, double* poses, const int32_t* r_idx,
-                          const double* r_val, const int32_t* p_idx, const double* p_val, const int32_t* s_idx,
-                          const double* s_val, double* result) {
-    if (!w || !counts || !poses || !result) return locamd_fail(LOC_ERR_INVALID, "window solve arguments");
+// host-side shape check: a bad index would fault the GPU
+static int validate_instances(const loc_window* w, int64_t n, const int32_t* counts, const double* poses, const int32_t* r_idx,
+                              const double* r_val, const int32_t* p_idx, const double* p_val, const int32_t* s_idx,
+                              const double* s_val) {
+    if (!w || !counts || !poses) return locamd_fail(LOC_ERR_INVALID, "window solve arguments");
     if (n <= 0 || n > w->B) return locamd_fail(LOC_ERR_INVALID, "n_instances");
     const locamd::WindowCaps& c = w->caps;
     if ((c.nr_max && (!r_idx || !r_val)) || (c.np_max && (!p_idx || !p_val)) || (c.ns_max && (!s_idx || !s_val)))
         return locamd_fail(LOC_ERR_INVALID, "missing edge arrays");
-    // host-side shape check: a bad index would fault the GPU
     for (int64_t i = 0; i < n; ++i) {
         const int32_t* cn = counts + i * 4;
         if (cn[0] < 0 || cn[0] > c.nv_max || cn[1] < 0 || cn[1] > c.nr_max || cn[2] < 0 || cn[2] > c.np_max || cn[3] < 0 || cn[3] > c.ns_max)
@@ -158,6 +165,29 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
                 return locamd_fail(LOC_ERR_INVALID, "SE3 edge couples poses further apart than bw_max");
         }
     }
+    return LOC_OK;
+}
+
+int loc_window_set_jacobian(loc_window* w, int32_t jacobian) {
+    if (!w || (jacobian != LOC_JAC_ANALYTIC && jacobian != LOC_JAC_NUMERIC_G2O)) return locamd_fail(LOC_ERR_INVALID, "jacobian mode");
+    w->jacobian = jacobian;
+    return LOC_OK;
+}
+int loc_window_set_ordering(loc_window* w, int32_t natural) {
+    if (!w) return locamd_fail(LOC_ERR_INVALID, "null");
+    w->natural_order = natural != 0;
+    return LOC_OK;
+}
+
+int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, double* poses, const int32_t* r_idx,
+                          const double* r_val, const int32_t* p_idx, const double* p_val, const int32_t* s_idx,
+                          const double* s_val, double* result) {
+    if (!result) return locamd_fail(LOC_ERR_INVALID, "window solve arguments");
+    {
+        const int rc = validate_instances(w, n, counts, poses, r_idx, r_val, p_idx, p_val, s_idx, s_val);
+        if (rc != LOC_OK) return rc;
+    }
+    const locamd::WindowCaps& c = w->caps;
     LOC_HIP(hipSetDevice(w->device));
     const size_t N = (size_t)n;
     hipStream_t st = w->stream;
@@ -182,7 +212,7 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
             if (c.ns_max) { std::memcpy(h + off[5], s_val, N * c.ns_max * 48 * sizeof(double)); std::memcpy(h + off[8], s_idx, N * c.ns_max * 4 * sizeof(int32_t)); }
             LOC_HIP(hipMemcpyAsync(d, h, off[9], hipMemcpyHostToDevice, st));
             locamd::WindowArgs a;
-            a.poses = (double*)(d + off[0]); a.result = (double*)(d + off[1]); a.counts = (const int32_t*)(d + off[2]);
+            a.poses = (double*)(d + off[0]); a.poses_in = a.poses; a.jacobian = w->jacobian; a.natural_order = w->natural_order; a.result = (double*)(d + off[1]); a.counts = (const int32_t*)(d + off[2]);
             a.r_val = (const double*)(d + off[3]); a.p_val = (const double*)(d + off[4]); a.s_val = (const double*)(d + off[5]);
             a.r_idx = (const int32_t*)(d + off[6]); a.p_idx = (const int32_t*)(d + off[7]); a.s_idx = (const int32_t*)(d + off[8]);
             a.anchors = w->d_anchors; a.workspace = w->d_workspace;
@@ -216,7 +246,7 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
         LOC_HIP(hipMemcpyAsync(w->d_sval, s_val, N * c.ns_max * 48 * sizeof(double), hipMemcpyHostToDevice, st));
     }
     locamd::WindowArgs a;
-    a.counts = w->d_counts; a.poses = w->d_poses; a.r_idx = w->d_ridx; a.r_val = w->d_rval; a.p_idx = w->d_pidx;
+    a.counts = w->d_counts; a.poses = w->d_poses; a.poses_in = a.poses; a.jacobian = w->jacobian; a.natural_order = w->natural_order; a.r_idx = w->d_ridx; a.r_val = w->d_rval; a.p_idx = w->d_pidx;
     a.p_val = w->d_pval; a.s_idx = w->d_sidx; a.s_val = w->d_sval; a.anchors = w->d_anchors; a.result = w->d_result;
     a.workspace = w->d_workspace;
     a.n_anchors = w->n_anchors; a.B = (int)n; a.iterations = w->iterations; a.caps = c;
@@ -230,6 +260,98 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
     float ms = 0;
     LOC_HIP(hipEventElapsedTime(&ms, w->ev0, w->ev1));
     w->last_ms = ms;
+    return LOC_OK;
+}
+
+// ---- device-resident operation --------------------------------------------------------------------------------------
+int loc_window_upload(loc_window* w, int64_t n, const int32_t* counts, const double* poses, const int32_t* r_idx,
+                      const double* r_val, const int32_t* p_idx, const double* p_val, const int32_t* s_idx,
+                      const double* s_val) {
+    {
+        const int rc = validate_instances(w, n, counts, poses, r_idx, r_val, p_idx, p_val, s_idx, s_val);
+        if (rc != LOC_OK) return rc;
+    }
+    const locamd::WindowCaps& c = w->caps;
+    LOC_HIP(hipSetDevice(w->device));
+    const size_t N = (size_t)n;
+    if (!w->d_poses_in) LOC_HIP(hipMalloc((void**)&w->d_poses_in, (size_t)w->B * c.nv_max * 12 * sizeof(double)));
+    LOC_HIP(hipMemcpy(w->d_counts, counts, N * 4 * sizeof(int32_t), hipMemcpyHostToDevice));
+    LOC_HIP(hipMemcpy(w->d_poses_in, poses, N * c.nv_max * 12 * sizeof(double), hipMemcpyHostToDevice));
+    if (c.nr_max) {
+        LOC_HIP(hipMemcpy(w->d_ridx, r_idx, N * c.nr_max * 2 * sizeof(int32_t), hipMemcpyHostToDevice));
+        LOC_HIP(hipMemcpy(w->d_rval, r_val, N * c.nr_max * 5 * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (c.np_max) {
+        LOC_HIP(hipMemcpy(w->d_pidx, p_idx, N * c.np_max * sizeof(int32_t), hipMemcpyHostToDevice));
+        LOC_HIP(hipMemcpy(w->d_pval, p_val, N * c.np_max * 18 * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (c.ns_max) {
+        LOC_HIP(hipMemcpy(w->d_sidx, s_idx, N * c.ns_max * 4 * sizeof(int32_t), hipMemcpyHostToDevice));
+        LOC_HIP(hipMemcpy(w->d_sval, s_val, N * c.ns_max * 48 * sizeof(double), hipMemcpyHostToDevice));
+    }
+    w->n_resident = n;
+    return LOC_OK;
+}
+
+int loc_window_solve_resident(loc_window* w, void* hip_stream) {
+    if (!w || w->n_resident <= 0) return locamd_fail(LOC_ERR_INVALID, "nothing uploaded");
+    LOC_HIP(hipSetDevice(w->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : w->stream;
+    locamd::WindowArgs a;
+    a.counts = w->d_counts; a.poses_in = w->d_poses_in; a.poses = w->d_poses; a.r_idx = w->d_ridx; a.r_val = w->d_rval; a.p_idx = w->d_pidx;
+    a.p_val = w->d_pval; a.s_idx = w->d_sidx; a.s_val = w->d_sval; a.anchors = w->d_anchors; a.result = w->d_result;
+    a.workspace = w->d_workspace;
+    a.n_anchors = w->n_anchors; a.B = (int)w->n_resident; a.iterations = w->iterations; a.jacobian = w->jacobian;
+    a.natural_order = w->natural_order; a.caps = w->caps;
+    const bool timed = w->timing && (size_t)(w->ev_used + 2) <= w->ev.size();
+    if (timed) LOC_HIP(hipEventRecord(w->ev[w->ev_used], st));
+    hipError_t e = locamd::launch_window(a, st);
+    if (e != hipSuccess) return locamd_fail_hip(e, "launch_window");
+    if (timed) { LOC_HIP(hipEventRecord(w->ev[w->ev_used + 1], st)); w->ev_used += 2; }
+    return LOC_OK;
+}
+
+int loc_window_download(loc_window* w, double* poses, double* result) {
+    if (!w || w->n_resident <= 0) return locamd_fail(LOC_ERR_INVALID, "nothing uploaded");
+    LOC_HIP(hipSetDevice(w->device));
+    LOC_HIP(hipDeviceSynchronize());
+    const size_t N = (size_t)w->n_resident;
+    if (poses) LOC_HIP(hipMemcpy(poses, w->d_poses, N * w->caps.nv_max * 12 * sizeof(double), hipMemcpyDeviceToHost));
+    if (result) LOC_HIP(hipMemcpy(result, w->d_result, N * 8 * sizeof(double), hipMemcpyDeviceToHost));
+    return LOC_OK;
+}
+
+void* loc_window_poses_device(loc_window* w) { return w ? (void*)w->d_poses : nullptr; }
+void* loc_window_result_device(loc_window* w) { return w ? (void*)w->d_result : nullptr; }
+
+int loc_window_timing_begin(loc_window* w, int32_t max_launches) {
+    if (!w || max_launches <= 0) return locamd_fail(LOC_ERR_INVALID, "timing_begin");
+    LOC_HIP(hipSetDevice(w->device));
+    while ((int)w->ev.size() < 2 * max_launches) {
+        hipEvent_t ev;
+        LOC_HIP(hipEventCreate(&ev));
+        w->ev.push_back(ev);
+    }
+    w->ev_used = 0;
+    w->timing = true;
+    return LOC_OK;
+}
+int loc_window_timing_end(loc_window* w, int32_t* n_launches, double* total_ms, double* avg_ms) {
+    if (!w) return locamd_fail(LOC_ERR_INVALID, "timing_end");
+    LOC_HIP(hipSetDevice(w->device));
+    w->timing = false;
+    double tot = 0;
+    const int n = w->ev_used / 2;
+    for (int i = 0; i < n; ++i) {
+        LOC_HIP(hipEventSynchronize(w->ev[2 * i + 1]));
+        float ms = 0;
+        LOC_HIP(hipEventElapsedTime(&ms, w->ev[2 * i], w->ev[2 * i + 1]));
+        tot += ms;
+    }
+    if (n_launches) *n_launches = n;
+    if (total_ms) *total_ms = tot;
+    if (avg_ms) *avg_ms = n ? tot / n : 0.0;
+    w->ev_used = 0;
     return LOC_OK;
 }
 

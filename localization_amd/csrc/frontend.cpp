@@ -120,7 +120,8 @@ struct loc_node {
     bool deferred = false, pending = false;
     loc_window* win = nullptr;            // cached single-instance solver (anchors are part of its device state)
     std::vector<double> win_anchors;
-    loc_window_caps caps{16, 64, 32, 32, -1};  // LIMITS of what pack() accepts, set in loc_node_create
+    loc_window_caps caps{16, 0, 0, 0, -1};     // LIMIT of what pack() accepts: nv_max = the most active poses (set in loc_node_create);
+                                               // the edge counts have no limit (the reference has none): the handle grows on demand
     loc_window_caps win_caps{0, 0, 0, 0, 0};   // capacities of the cached handle: what the packed graphs needed so far
 
     RobotRing* robot(int id) { for (auto& r : robots) if (r.id == id) return &r; return nullptr; }
@@ -197,6 +198,31 @@ int pack(const loc_node* n, Packed& P) {
     }
     if ((int)slot.size() != k) return locamd_fail(LOC_ERR_INVALID, "internal: active vertex outside every robot ring");
     if (k > c.nv_max) return locamd_fail(LOC_ERR_UNSUPPORTED, "window has more active poses than the node was sized for");
+    {
+        // Oldest-first or newest-first?  Windows of more than 64 poses are factored in envelope (skyline) form in exactly
+        // this order, so take the direction with the cheaper envelope: a key-frame star (addPoseEdge: every pose hangs on
+        // an OLDER key pose) packed newest-first has its leaves before their key and factors without any fill, packed
+        // oldest-first every row reaches back to its key.  (Smaller windows are re-ordered by the kernel anyway.)
+        std::vector<int> first((size_t)k), lastn((size_t)k);
+        for (int v = 0; v < k; ++v) first[(size_t)v] = lastn[(size_t)v] = v;
+        auto couple = [&](int a, int b) {
+            if (n->vertices.at(a).fixed || n->vertices.at(b).fixed) return;
+            const int sa = slot.at(a), sb = slot.at(b), lo = std::min(sa, sb), hi = std::max(sa, sb);
+            first[(size_t)hi] = std::min(first[(size_t)hi], lo);
+            lastn[(size_t)lo] = std::max(lastn[(size_t)lo], hi);
+        };
+        for (const auto& e : n->ranges) if (active2(e.v0, e.v1)) couple(e.v0, e.v1);
+        for (const auto& e : n->se3s) if (active2(e.vi, e.vj)) couple(e.vi, e.vj);
+        double fwd = 0, rev = 0;
+        for (int v = 0; v < k; ++v) {
+            const double wf = v - first[(size_t)v] + 1, wr = lastn[(size_t)v] - v + 1;
+            fwd += wf * wf; rev += wr * wr;
+        }
+        if (rev < fwd) {
+            for (auto& kv : slot) kv.second = k - 1 - kv.second;
+            std::reverse(P.slot_vid.begin(), P.slot_vid.end());
+        }
+    }
     P.counts.assign(4, 0);
     P.poses.assign((size_t)k * 12, 0.0);
     P.r_idx.assign(n->ranges.size() * 2, 0); P.r_val.assign(n->ranges.size() * 5, 0.0);
@@ -212,7 +238,6 @@ int pack(const loc_node* n, Packed& P) {
     int nr = 0, np = 0, ns = 0;
     for (const auto& e : n->ranges) {
         if (!active2(e.v0, e.v1)) continue;
-        if (nr >= c.nr_max) return locamd_fail(LOC_ERR_UNSUPPORTED, "more range edges in the window than the node was sized for");
         int a = e.v0, b = e.v1;
         double off[3] = {e.off[0], e.off[1], e.off[2]};
         if (n->vertices.at(a).fixed) {  // the kernel wants endpoint 0 moving; the residual is symmetric
@@ -228,7 +253,6 @@ int pack(const loc_node* n, Packed& P) {
     }
     for (const auto& e : n->priors) {
         if (n->vertices.at(e.v).fixed) continue;
-        if (np >= c.np_max) return locamd_fail(LOC_ERR_UNSUPPORTED, "more prior edges in the window than the node was sized for");
         P.p_idx[np] = slot.at(e.v);
         double* v = &P.p_val[(size_t)np * 18];
         std::memcpy(v, e.zinv.R, sizeof(double) * 9); std::memcpy(v + 9, e.zinv.t, sizeof(double) * 3);
@@ -238,7 +262,6 @@ int pack(const loc_node* n, Packed& P) {
     for (const auto& e : n->se3s) {
         if (!active2(e.vi, e.vj)) continue;
         if (n->vertices.at(e.vi).fixed || n->vertices.at(e.vj).fixed) return locamd_fail(LOC_ERR_UNSUPPORTED, "SE3 edge to a fixed vertex");
-        if (ns >= c.ns_max) return locamd_fail(LOC_ERR_UNSUPPORTED, "more SE3 edges in the window than the node was sized for");
         int32_t* ix = &P.s_idx[(size_t)ns * 4];
         ix[0] = slot.at(e.vi); ix[1] = slot.at(e.vj); ix[2] = e.robust ? 1 : 0; ix[3] = 0;
         P.band = std::max(P.band, std::abs(ix[0] - ix[1]));
@@ -307,6 +330,8 @@ int solve_now(loc_node* n, loc_node_output* out) {
         if (!n->win) {
             rc = loc_window_create(&n->win, n->device, 1, &n->win_caps, (int32_t)(P.anchors.size() / 3), P.anchors.data(), n->cfg.maximum_iteration);
             if (rc != LOC_OK) return rc;
+            rc = loc_window_set_jacobian(n->win, n->cfg.jacobian);
+            if (rc != LOC_OK) return rc;
             n->win_anchors = P.anchors;
         } else if (n->win_anchors != P.anchors) {
             // the fixed vertices the window sees (or just their order) change as the window slides: refresh the table,
@@ -355,6 +380,7 @@ void loc_node_default_config(loc_node_config* c) {
     c->distance_outlier = 1.0;           // :78
     c->maximum_iteration = 20;           // :65
     c->minimum_optimize_error = 1000.0;  // :68
+    c->jacobian = LOC_JAC_ANALYTIC;
 }
 
 int loc_node_create(loc_node** out, int32_t device, const loc_node_config* cfg, int32_t n_nodes, const int32_t* ids,
@@ -363,6 +389,7 @@ int loc_node_create(loc_node** out, int32_t device, const loc_node_config* cfg, 
     *out = nullptr;
     if (!cfg || n_nodes <= 0 || !ids || !pos_xyz) return locamd_fail(LOC_ERR_INVALID, "node arguments");
     if (cfg->trajectory_length <= 0) return locamd_fail(LOC_ERR_INVALID, "robot/trajectory_length must be set");
+    if (cfg->jacobian != LOC_JAC_ANALYTIC && cfg->jacobian != LOC_JAC_NUMERIC_G2O) return locamd_fail(LOC_ERR_INVALID, "jacobian mode");
     if (loc_device_count() <= 0) return locamd_fail(LOC_ERR_NO_DEVICE, "no HIP device visible: localization_amd has no CPU fallback");
     if (cfg->trajectory_length > 1024 || (cfg->has_relative_range && cfg->trajectory_length * n_nodes > 1024))
         return locamd_fail(LOC_ERR_UNSUPPORTED, "windows of more than 1024 moving poses are not supported by this kernel version");
@@ -371,15 +398,11 @@ int loc_node_create(loc_node** out, int32_t device, const loc_node_config* cfg, 
     n->cfg = *cfg;
     n->device = device;
     n->self_id = ids[n_nodes - 1];  // nodesId.back(), localization.cpp:89
-    {   // capacities for this window: every pose can carry a range + a smoothness edge, one prior, one SE3 edge.
-        // Band: poses are packed in ascending vertex id = ring-slot order, so consecutive poses are neighbours except
-        // across the ring's wrap point (oldest <-> newest slot), and key-frame pose factors reach back at most T - 1:
-        // dense up to 16 poses; beyond that a band is requested and grown on demand (pack() measures what it needs).
+    {   // The only limit is the kernel's: active poses per window.  Edge capacities of the solver handle grow with what the
+        // packed graphs need (grown_caps): two priors per vertex (IMU + lidar, cfg/uwb_imu_lidar.yaml), any number of
+        // ranges piling onto one pose vertex (the else-branch at localization.cpp:348) — the reference has no such limits.
         const int tv = cfg->has_relative_range ? cfg->trajectory_length * n_nodes : cfg->trajectory_length;
-        n->caps.nv_max = tv <= 16 ? 16 : tv;
-        n->caps.nr_max = tv <= 16 ? 64 : 2 * tv + 8;
-        n->caps.np_max = tv <= 16 ? 32 : tv;
-        n->caps.ns_max = tv <= 16 ? 32 : tv;
+        n->caps.nv_max = tv;
         n->caps.bw_max = -1;
         n->win_caps.nv_max = tv;                 // the window's final pose count is known; edges and band grow on demand
         n->win_caps.nr_max = 2 * tv + 8;         // the two-edge range topology (localization.cpp:327-357)
@@ -424,6 +447,8 @@ int loc_node_add_range(loc_node* n, int32_t requester_id, int32_t responder_id, 
     RobotRing* rq = n->robot(requester_id);
     RobotRing* rs = n->robot(responder_id);
     if (!rq || !rs) return locamd_fail(LOC_ERR_UNKNOWN_NODE, "node id not in nodesId");
+    // (everything that can fail is checked before the graph is touched: an error return leaves the node as it was)
+    if (antenna > 0 && (size_t)antenna * 3 > n->antenna.size()) return locamd_fail(LOC_ERR_INVALID, "antenna index beyond /uwb/antennaOffset");
     ++n->number_measurements;  // :303
     const Iso& xq = n->vertices.at(rq->last_vertex()).est;
     const Iso& xr = n->vertices.at(rs->last_vertex()).est;
@@ -444,10 +469,7 @@ int loc_node_add_range(loc_node* n, int32_t requester_id, int32_t responder_id, 
     if (last_frame.find(h.frame_id) != std::string::npos || last_frame.find("none") != std::string::npos) {  // :327
         const int vertex_requester = n->new_vertex(*rq, ST_RANGE, h);
         const double* off = nullptr;
-        if (antenna > 0) {  // :333-334
-            if ((size_t)antenna * 3 > n->antenna.size()) return locamd_fail(LOC_ERR_INVALID, "antenna index beyond /uwb/antennaOffset");
-            off = &n->antenna[(size_t)(antenna - 1) * 3];
-        }
+        if (antenna > 0) off = &n->antenna[(size_t)(antenna - 1) * 3];  // :333-334
         add_range_edge(n, vertex_requester, vertex_responder, (double)distance, distance_cov, off);   // :331-336
         add_range_edge(n, vertex_last_requester, vertex_requester, 0.0, cov_requester, nullptr);      // :338-340
     } else {
@@ -458,6 +480,39 @@ int loc_node_add_range(loc_node* n, int32_t requester_id, int32_t responder_id, 
         add_range_edge(n, vertex_last_responder, vertex_responder, 0.0, cov_responder, nullptr);
     }
     return maybe_solve(n, n->cfg.publish_range && n->number_measurements > n->cfg.trajectory_length, out);  // :371-375
+}
+
+// Localization::addRLRangeEdge, localization.cpp:378-436 (in the reference only with -DRELATIVE_LOCALIZATION, CMakeLists.txt:137)
+int loc_node_add_rl_range(loc_node* n, int32_t requester_id, int32_t responder_id, double stamp, double distance,
+                          const double* vel, loc_node_output* out) {
+    if (!n || !vel) return locamd_fail(LOC_ERR_INVALID, "null");
+    if (out) std::memset(out, 0, sizeof(*out));
+    RobotRing* rq = n->robot(requester_id);
+    RobotRing* rs = n->robot(responder_id);
+    if (!rq || !rs) return locamd_fail(LOC_ERR_UNKNOWN_NODE, "node id not in nodesId");
+    if (rq == rs) return locamd_fail(LOC_ERR_INVALID, "requester and responder are the same node");
+    Header h; h.stamp = stamp; h.frame_id = "uwb";  // :380-382
+    const double dt_requester = stamp - rq->header[rq->index].stamp;  // :384
+    const double dt_responder = stamp - rs->header[rs->index].stamp;  // :385
+    const double distance_cov = std::pow(0.054, 2);                                         // :387
+    const double cov_requester = std::pow(n->cfg.maximum_velocity * dt_requester / 3, 2);   // :388
+    const double cov_responder = std::pow(n->cfg.maximum_velocity * dt_responder / 3, 2);   // :389
+    const int vertex_last_requester = rq->last_vertex();
+    const int vertex_last_responder = rs->last_vertex();
+    const int vertex_requester = n->new_vertex(*rq, ST_RANGE, h);  // :394
+    const int vertex_responder = n->new_vertex(*rs, ST_RANGE, h);  // :395
+    add_range_edge(n, vertex_requester, vertex_responder, distance, distance_cov, nullptr);  // :397-398
+    if (!rs->is_static) add_range_edge(n, vertex_last_responder, vertex_responder, 0.0, cov_responder, nullptr);  // :400-405
+    if (!rq->is_static && vertex_last_requester != vertex_requester) {  // :408-428 (T = 1 would make it a self-loop)
+        Se3Edge e{};
+        e.vi = vertex_last_requester; e.vj = vertex_requester; e.robust = false;   // no robust kernel is set
+        Iso z = iso_identity();
+        z.t[0] = dt_requester * vel[0]; z.t[1] = dt_requester * vel[1]; z.t[2] = dt_requester * vel[2];  // measurement.translate(dt v)
+        e.zinv = iso_inverse(z);
+        e.info[0] = e.info[7] = e.info[14] = 1.0 / cov_requester;  // translation only
+        n->se3s.push_back(e);
+    }
+    return maybe_solve(n, n->cfg.publish_relative_range != 0, out);  // :430-434
 }
 
 // Localization::addImuEdge, localization.cpp:499-535
@@ -576,26 +631,27 @@ int loc_node_get_path(loc_node* n, int32_t node_id, double* out, int32_t capacit
     return r->T;
 }
 
-// Many nodes, one launch: packs every node that has a solve pending (deferred mode) into one batch.
-int loc_nodes_solve_batch(loc_node** nodes, int32_t n_nodes, loc_node_output* outs) {
-    if (!nodes || n_nodes <= 0) return locamd_fail(LOC_ERR_INVALID, "nodes");
-    std::vector<Packed> P((size_t)n_nodes);
-    std::vector<int> todo;
-    for (int i = 0; i < n_nodes; ++i) {
-        if (!nodes[i]) return locamd_fail(LOC_ERR_INVALID, "null node");
-        if (outs) std::memset(&outs[i], 0, sizeof(loc_node_output));
-        if (!nodes[i]->pending) continue;
-        int rc = pack(nodes[i], P[(size_t)i]);
-        if (rc != LOC_OK) return rc;
-        todo.push_back(i);
-    }
-    if (todo.empty()) return 0;
+}  // extern "C"
+
+// Many nodes, one launch per group: every node that has a solve pending (deferred mode) is packed into a batch with the
+// other pending nodes of the same (device, maximum_iteration, jacobian) — what one kernel launch can serve.
+namespace {
+// cached batch solvers of the calling thread, one per group key: re-created only when the capacities or the batch size
+// grow.  loc_nodes_release_batch_cache() frees them.
+struct BatchCache { loc_window* w = nullptr; loc_window_caps caps{0, 0, 0, 0, 0}; int device = -1; size_t B = 0; int iters = 0; int jac = 0; };
+thread_local std::vector<BatchCache> g_batch_caches;
+
+int solve_group(loc_node** nodes, const std::vector<int>& todo, std::vector<Packed>& P, loc_node_output* outs) {
     loc_node* first = nodes[todo[0]];
-    // one cached batch solver per thread: re-created only when the capacities or the batch size grow, or the device changes
-    struct BatchCache { loc_window* w = nullptr; loc_window_caps caps{0, 0, 0, 0, 0}; int device = -1; size_t B = 0; int iters = 0; };
-    static thread_local BatchCache cache;
-    const bool reusable = cache.w && cache.device == first->device && cache.iters == first->cfg.maximum_iteration;
-    loc_window_caps caps = reusable ? cache.caps : loc_window_caps{0, 0, 0, 0, 0};
+    BatchCache* cache = nullptr;
+    for (auto& bc : g_batch_caches)
+        if (bc.device == first->device && bc.iters == first->cfg.maximum_iteration && bc.jac == first->cfg.jacobian) cache = &bc;
+    if (!cache) {
+        g_batch_caches.emplace_back();
+        cache = &g_batch_caches.back();
+        cache->device = first->device; cache->iters = first->cfg.maximum_iteration; cache->jac = first->cfg.jacobian;
+    }
+    loc_window_caps caps = cache->caps;
     for (int i : todo) caps = grown_caps(caps, P[(size_t)i]);
     const size_t B = todo.size();
     std::vector<int32_t> counts(B * 4), r_idx(B * caps.nr_max * 2), p_idx(B * caps.np_max), s_idx(B * caps.ns_max * 4);
@@ -615,16 +671,18 @@ int loc_nodes_solve_batch(loc_node** nodes, int32_t n_nodes, loc_node_output* ou
         std::copy(p.s_idx.begin(), p.s_idx.end(), s_idx.begin() + b * caps.ns_max * 4);
         std::copy(p.s_val.begin(), p.s_val.end(), s_val.begin() + b * caps.ns_max * 48);
     }
-    if (!reusable || cache.B < B || !same_caps(cache.caps, caps)) {
-        if (cache.w) { loc_window_destroy(cache.w); cache.w = nullptr; }
-        int rc0 = loc_window_create(&cache.w, first->device, (int64_t)B, &caps, (int32_t)(anchors.size() / 3), anchors.data(), first->cfg.maximum_iteration);
+    if (!cache->w || cache->B < B || !same_caps(cache->caps, caps)) {
+        if (cache->w) { loc_window_destroy(cache->w); cache->w = nullptr; cache->B = 0; }
+        int rc0 = loc_window_create(&cache->w, first->device, (int64_t)B, &caps, (int32_t)(anchors.size() / 3), anchors.data(), first->cfg.maximum_iteration);
         if (rc0 != LOC_OK) return rc0;
-        cache.caps = caps; cache.device = first->device; cache.B = B; cache.iters = first->cfg.maximum_iteration;
+        rc0 = loc_window_set_jacobian(cache->w, first->cfg.jacobian);
+        if (rc0 != LOC_OK) return rc0;
+        cache->caps = caps; cache->B = B;
     } else {
-        int rc0 = loc_window_set_anchors(cache.w, (int32_t)(anchors.size() / 3), anchors.data());
+        int rc0 = loc_window_set_anchors(cache->w, (int32_t)(anchors.size() / 3), anchors.data());
         if (rc0 != LOC_OK) return rc0;
     }
-    int rc = loc_window_solve_host(cache.w, (int64_t)B, counts.data(), poses.data(), r_idx.data(), r_val.data(), p_idx.data(), p_val.data(),
+    int rc = loc_window_solve_host(cache->w, (int64_t)B, counts.data(), poses.data(), r_idx.data(), r_val.data(), p_idx.data(), p_val.data(),
                                    s_idx.data(), s_val.data(), res.data());
     if (rc != LOC_OK) return rc;
     for (size_t b = 0; b < B; ++b) {
@@ -639,6 +697,49 @@ int loc_nodes_solve_batch(loc_node** nodes, int32_t n_nodes, loc_node_output* ou
         if (outs) fill_output(n, &res[b * 8], &outs[todo[b]]);
     }
     return (int)B;
+}
+}  // namespace
+
+extern "C" {
+
+int loc_nodes_solve_batch(loc_node** nodes, int32_t n_nodes, loc_node_output* outs) {
+    if (!nodes || n_nodes <= 0) return locamd_fail(LOC_ERR_INVALID, "nodes");
+    std::vector<Packed> P((size_t)n_nodes);
+    std::vector<int> todo;
+    for (int i = 0; i < n_nodes; ++i) {
+        if (!nodes[i]) return locamd_fail(LOC_ERR_INVALID, "null node");
+        if (outs) std::memset(&outs[i], 0, sizeof(loc_node_output));
+        if (!nodes[i]->pending) continue;
+        int rc = pack(nodes[i], P[(size_t)i]);
+        if (rc != LOC_OK) return rc;
+        todo.push_back(i);
+    }
+    // a heterogeneous fleet: one launch per (device, maximum_iteration, jacobian), each node solved with ITS parameters
+    int solved = 0;
+    std::vector<char> done(todo.size(), 0);
+    for (size_t a = 0; a < todo.size(); ++a) {
+        if (done[a]) continue;
+        const loc_node* na = nodes[todo[a]];
+        std::vector<int> group;
+        for (size_t b = a; b < todo.size(); ++b) {
+            const loc_node* nb = nodes[todo[b]];
+            if (!done[b] && nb->device == na->device && nb->cfg.maximum_iteration == na->cfg.maximum_iteration && nb->cfg.jacobian == na->cfg.jacobian) {
+                group.push_back(todo[b]);
+                done[b] = 1;
+            }
+        }
+        const int rc = solve_group(nodes, group, P, outs);
+        if (rc < 0) return rc;
+        solved += rc;
+    }
+    return solved;
+}
+
+// Frees the calling thread's cached batch solvers (device buffers, streams, events).
+int loc_nodes_release_batch_cache(void) {
+    for (auto& bc : g_batch_caches) if (bc.w) loc_window_destroy(bc.w);
+    g_batch_caches.clear();
+    return LOC_OK;
 }
 
 }  // extern "C"

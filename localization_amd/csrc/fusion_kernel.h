@@ -20,6 +20,7 @@ struct FusionArgs {
     int iterations;
     double gate;
     int gate_from_epoch;
+    int jacobian;          // 0: analytic range Jacobians, 1: g2o's central differences (delta = 1e-9)
 };
 
 hipError_t launch_fusion(const FusionArgs& a, int block_threads, hipStream_t stream);

@@ -16,6 +16,7 @@
 // 16-byte LDS-DMA pieces); pose state double [7][B] (t, q xyzw); outputs pose [K][7][B], chi2 [K][B], trials [K][B].
 #include "fusion_kernel.h"
 #include "device_math.h"
+#include "numeric_jacobian.h"
 
 #include <float.h>
 #include <math.h>
@@ -70,8 +71,11 @@ __device__ __forceinline__ void quat_to_mat(double w, double x, double y, double
 }
 
 // Residuals, weights, 6x6 normal equations and chi sums at pose X.
-//   ranges: e = d - ||R o + t - a||;  J = [ -(R^T u)^T , (R^T u x 2o)^T ]           (analytic)
+//   ranges: e = d - ||R o + t - a||;  J = [ -(R^T u)^T , (R^T u x 2o)^T ]           (analytic), or, JAC = 1,
+//           g2o's central differences through X * fromVectorMQT(+-1e-9 e_d) (the reference's mode: the twelve perturbed
+//           antenna points are shared by the tag's ranges)
 //   prior : e = vec(q(Rm^T R)), J_rot = w I + [q]x, information pinfo (rotation rows only)
+template <int JAC>
 __device__ __forceinline__ Sys6 evaluate6(const Pose& X, const double (&ax)[M8], const double (&ay)[M8], const double (&az)[M8],
                                           const double (&d)[M8], double (&w)[M8], const double (&Rm)[9], const double (&pinfo)[3],
                                           const double ox, const double oy, const double oz, const bool gate_now, const double gate) {
@@ -88,6 +92,18 @@ __device__ __forceinline__ Sys6 evaluate6(const Pose& X, const double (&ax)[M8],
     const double p0y = R[3] * ox + R[4] * oy + R[5] * oz + X.t[1];
     const double p0z = R[6] * ox + R[7] * oy + R[8] * oz + X.t[2];
     const double o2x = 2.0 * ox, o2y = 2.0 * oy, o2z = 2.0 * oz;
+    double P0[3], Pp[6][3], Pm[6][3];
+    if (JAC == 1) {
+        constexpr double delta = 1e-9;
+        const double off[3] = {ox, oy, oz};
+        perturbed_point_plain<0>(R, X.t, off, 0.0, P0);  // dl = 0: X * identity, same operation order
+        perturbed_point_plain<0>(R, X.t, off, delta, Pp[0]); perturbed_point_plain<0>(R, X.t, off, -delta, Pm[0]);
+        perturbed_point_plain<1>(R, X.t, off, delta, Pp[1]); perturbed_point_plain<1>(R, X.t, off, -delta, Pm[1]);
+        perturbed_point_plain<2>(R, X.t, off, delta, Pp[2]); perturbed_point_plain<2>(R, X.t, off, -delta, Pm[2]);
+        perturbed_point_plain<3>(R, X.t, off, delta, Pp[3]); perturbed_point_plain<3>(R, X.t, off, -delta, Pm[3]);
+        perturbed_point_plain<4>(R, X.t, off, delta, Pp[4]); perturbed_point_plain<4>(R, X.t, off, -delta, Pm[4]);
+        perturbed_point_plain<5>(R, X.t, off, delta, Pp[5]); perturbed_point_plain<5>(R, X.t, off, -delta, Pm[5]);
+    }
 #pragma unroll
     for (int j = 0; j < M8; ++j) {
         if (gate_now) {  // |‖t - a‖ - d| > gate on the vertex origin, without a square root
@@ -96,19 +112,26 @@ __device__ __forceinline__ Sys6 evaluate6(const Pose& X, const double (&ax)[M8],
             const double hi = d[j] + gate, lo = d[j] - gate;
             if (g2 > hi * hi || (lo > 0.0 && g2 < lo * lo)) w[j] = 0.0;
         }
-        const double ux = p0x - ax[j], uy = p0y - ay[j], uz = p0z - az[j];
-        const double n2 = fmax(ux * ux + uy * uy + uz * uz, 1e-300);
-        double n, inv;
-        sqrt_and_rsqrt(n2, n, inv);
-        const double e = d[j] - n;
-        const double vx = ux * inv, vy = uy * inv, vz = uz * inv;  // unit vector u
-        // uR = R^T u
-        const double rx = R[0] * vx + R[3] * vy + R[6] * vz;
-        const double ry = R[1] * vx + R[4] * vy + R[7] * vz;
-        const double rz = R[2] * vx + R[5] * vy + R[8] * vz;
-        double J[6];
-        J[0] = -rx; J[1] = -ry; J[2] = -rz;
-        J[3] = ry * o2z - rz * o2y; J[4] = rz * o2x - rx * o2z; J[5] = rx * o2y - ry * o2x;  // 2 (uR x o)
+        double e, J[6];
+        if (JAC == 0) {
+            const double ux = p0x - ax[j], uy = p0y - ay[j], uz = p0z - az[j];
+            const double n2 = fmax(ux * ux + uy * uy + uz * uz, 1e-300);
+            double n, inv;
+            sqrt_and_rsqrt(n2, n, inv);
+            e = d[j] - n;
+            const double vx = ux * inv, vy = uy * inv, vz = uz * inv;  // unit vector u
+            // uR = R^T u
+            const double rx = R[0] * vx + R[3] * vy + R[6] * vz;
+            const double ry = R[1] * vx + R[4] * vy + R[7] * vz;
+            const double rz = R[2] * vx + R[5] * vy + R[8] * vz;
+            J[0] = -rx; J[1] = -ry; J[2] = -rz;
+            J[3] = ry * o2z - rz * o2y; J[4] = rz * o2x - rx * o2z; J[5] = rx * o2y - ry * o2x;  // 2 (uR x o)
+        } else {
+            e = d[j] - norm_to_plain(P0, ax[j], ay[j], az[j]);
+#pragma unroll
+            for (int dd = 0; dd < 6; ++dd)
+                J[dd] = central_difference_plain(d[j], norm_to_plain(Pp[dd], ax[j], ay[j], az[j]), norm_to_plain(Pm[dd], ax[j], ay[j], az[j]));
+        }
         const double we = w[j] * e;
         const double chi = e * we;
         const double aux = 1.0 + chi;
@@ -222,6 +245,7 @@ constexpr int NEXT_DOUBLES = 28;
 constexpr int RAW_PIECES = 8;
 constexpr int FUSION_LDS_BYTES = NEXT_DOUBLES * 256 * 8 + RAW_PIECES * 256 * 16;
 
+template <int JAC>
 __global__ void __launch_bounds__(256) fusion_lm_kernel(const FusionArgs a) {
     __shared__ __attribute__((aligned(16))) char lds_bytes[FUSION_LDS_BYTES];
     double* const s_next = reinterpret_cast<double*>(lds_bytes);                      // [28][256]
@@ -374,7 +398,7 @@ __global__ void __launch_bounds__(256) fusion_lm_kernel(const FusionArgs a) {
         }
         const Pose T = oplus(X, x);
         const bool gate_now = active && init && (a.gate > 0.0) && (k >= a.gate_from_epoch);
-        const Sys6 tr = evaluate6(T, ax, ay, az, d, w, Rm, pinfo, ox, oy, oz, gate_now, a.gate);
+        const Sys6 tr = evaluate6<JAC>(T, ax, ay, az, d, w, Rm, pinfo, ox, oy, oz, gate_now, a.gate);
 
         bool finished = false;
         if (active) {
@@ -476,7 +500,8 @@ hipError_t launch_fusion(const FusionArgs& a, int block_threads, hipStream_t str
     if (block_threads % 64 || block_threads > 256) return hipErrorInvalidValue;
     const long long blocks = (a.B + block_threads - 1) / block_threads;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(fusion_lm_kernel, dim3((unsigned)blocks), dim3((unsigned)block_threads), 0, stream, a);
+    if (a.jacobian) hipLaunchKernelGGL(fusion_lm_kernel<1>, dim3((unsigned)blocks), dim3((unsigned)block_threads), 0, stream, a);
+    else hipLaunchKernelGGL(fusion_lm_kernel<0>, dim3((unsigned)blocks), dim3((unsigned)block_threads), 0, stream, a);
     return hipGetLastError();
 }
 

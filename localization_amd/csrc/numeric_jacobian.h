@@ -1,0 +1,69 @@
+// g2o's numeric Jacobian of EdgeSE3Range, shared by the window and fusion kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+namespace locamd {
+namespace {
+
+// ---- g2o's numeric Jacobian of EdgeSE3Range (BaseBinaryEdge::linearizeOplus) ---------------------------
+// The reference has no linearizeOplus for EdgeSE3Range (types_edge_se3range.h:45-74), so g2o differentiates
+// computeError() (types_edge_se3range.cpp:105-114) by central differences, delta = 1e-9, through VertexSE3::oplus
+// (X <- X * fromVectorMQT(+-delta e_d)).  The few operations of that evaluation are kept un-contracted and on the IEEE
+// sqrt, in the operation order of a plain CPU build, so the difference quotient (which multiplies every last-bit
+// difference by 5e8) sees the same roundings.
+#pragma clang fp contract(off)
+__device__ __forceinline__ double range_error_plain(const double* R, const double* t, const double* off, const double* q1, double meas) {
+    const double px = R[0] * off[0] + R[1] * off[1] + R[2] * off[2];
+    const double py = R[3] * off[0] + R[4] * off[1] + R[5] * off[2];
+    const double pz = R[6] * off[0] + R[7] * off[1] + R[8] * off[2];
+    const double dx = (px + t[0]) - q1[0], dy = (py + t[1]) - q1[1], dz = (pz + t[2]) - q1[2];
+    return meas - sqrt(dx * dx + dy * dy + dz * dz);
+}
+// X * fromVectorMQT(dl e_D): (R Rinc, R tinc + t)
+template <int D>
+__device__ __forceinline__ void oplus_axis_plain(const double* R, const double* t, double dl, double* Ro, double* to) {
+    double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    v[D] = dl;
+    double Ri[9];
+    const double w = 1.0 - (v[3] * v[3] + v[4] * v[4] + v[5] * v[5]);
+    if (w < 0) { Ri[0] = 1; Ri[1] = 0; Ri[2] = 0; Ri[3] = 0; Ri[4] = 1; Ri[5] = 0; Ri[6] = 0; Ri[7] = 0; Ri[8] = 1; }
+    else {
+        const double qw = sqrt(w), qx = v[3], qy = v[4], qz = v[5];
+        const double tx = 2 * qx, ty = 2 * qy, tz = 2 * qz;
+        const double twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, txy = ty * qx, txz = tz * qx, tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+        Ri[0] = 1 - (tyy + tzz); Ri[1] = txy - twz; Ri[2] = txz + twy;
+        Ri[3] = txy + twz; Ri[4] = 1 - (txx + tzz); Ri[5] = tyz - twx;
+        Ri[6] = txz - twy; Ri[7] = tyz + twx; Ri[8] = 1 - (txx + tyy);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Ro[i * 3 + j] = R[i * 3 + 0] * Ri[0 * 3 + j] + R[i * 3 + 1] * Ri[1 * 3 + j] + R[i * 3 + 2] * Ri[2 * 3 + j];
+        to[i] = (R[i * 3 + 0] * v[0] + R[i * 3 + 1] * v[1] + R[i * 3 + 2] * v[2]) + t[i];
+    }
+}
+// the lever-arm point (X * fromVectorMQT(dl e_D)) * o = R' o + t'
+template <int D>
+__device__ __forceinline__ void perturbed_point_plain(const double* R, const double* t, const double* off, double dl, double* P) {
+    double Ro[9], to[3];
+    oplus_axis_plain<D>(R, t, dl, Ro, to);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) P[i] = (Ro[i * 3 + 0] * off[0] + Ro[i * 3 + 1] * off[1] + Ro[i * 3 + 2] * off[2]) + to[i];
+}
+__device__ __forceinline__ double norm_to_plain(const double* P, double ax, double ay, double az) {
+    const double dx = P[0] - ax, dy = P[1] - ay, dz = P[2] - az;
+    return sqrt(dx * dx + dy * dy + dz * dz);
+}
+// J = ((meas - n+) - (meas - n-)) / (2 delta), g2o's operation order
+__device__ __forceinline__ double central_difference_plain(double meas, double np, double nm) {
+    constexpr double delta = 1e-9;
+    constexpr double scalar = 1.0 / (2 * delta);
+    double bak = meas - np;
+    bak -= meas - nm;
+    return scalar * bak;
+}
+#pragma clang fp contract(fast)
+
+}  // namespace
+}  // namespace locamd

@@ -24,10 +24,12 @@ struct WindowCaps {
 //   s_idx   int32 [B][ns_max][4]    vi, vj, robust, pad
 //   s_val   double[B][ns_max][48]   Z^-1 as R(9), t(3); information 6x6 row-major (36)
 //   result  double[B][8]            chi2 (all edges, last evaluated), robust chi2, lambda, outer iterations,
-//                                   LM trials, terminated, number of binary edges that share their pair of poses with another edge, 0
+//                                   LM trials, terminated, number of binary edges that share their pair of poses with another edge,
+//                                   (nv_max <= 64) elimination-tree levels * 65536 + blocks of the factor
 struct WindowArgs {
     const int32_t* counts;
-    double* poses;
+    const double* poses_in;  // initial estimates (may alias `poses`: every instance reads its poses before it writes them)
+    double* poses;           // optimised estimates
     const int32_t* r_idx; const double* r_val;
     const int32_t* p_idx; const double* p_val;
     const int32_t* s_idx; const double* s_val;
@@ -37,6 +39,8 @@ struct WindowArgs {
     int n_anchors;
     int B;
     int iterations;
+    int jacobian;       // 0: analytic range Jacobians, 1: g2o's central differences (delta = 1e-9)
+    int natural_order;  // != 0: windows of <= 64 poses are eliminated in the caller's pose order (diagnostics / tests)
     WindowCaps caps;
 };
 

@@ -11,24 +11,30 @@
 //             EdgeSE3       e = toVectorMQT(Z^-1 Xi^-1 Xj), 6x6 information, Cauchy  [localization.cpp:263-281, 588-602]
 //   solve     initializeOptimization + optimize(maximum_iteration), g2o LM          [localization.cpp:164-170]
 //             then optimizer.chi2()                                                 [localization.cpp:197]
-// (g2o semantics: SURVEY.md Appendix A.  Jacobians are analytic here; the reference's numeric range Jacobian is the
-//  same derivative up to 1e-7 relative noise.)
+// (g2o semantics: SURVEY.md Appendix A.)
 //
-// MI355X mapping: ONE WAVE PER INSTANCE, everything in LDS.
-//   * edge evaluation: lane e evaluates edge e (error, Jacobian blocks, robust weight) into an LDS record;
-//   * normal equations: edges are folded into H one after the other (fixed order => bit-reproducible, no atomics),
-//     the 64 lanes covering the 6x6 block entries;  H (n = 6 * poses <= 96) lives in the UPPER triangle of one
-//     n x ld LDS matrix (ld odd: conflict-free column walks), its Cholesky factor goes into the strict LOWER triangle,
-//     so a rejected LM trial needs no copy of H;
-//   * left-looking Cholesky with lanes over rows, column-oriented triangular solves, lane-per-pose oplus;
-//   * all LM control flow is wave-uniform (sums are xor-butterflies: every lane holds the same bits).
-// This is the latency-oriented first version of the window path (one 64-lane wave per 60..96-unknown system);
-// DESIGN.md lists what the throughput version changes.
+// MI355X mapping: ONE WAVE PER INSTANCE.
+//   * edge evaluation: lane e evaluates edge e (error, Jacobian blocks, robust weight) into a record; range Jacobians are
+//     analytic, or g2o's central differences (delta = 1e-9, what the reference inherits) when WindowArgs::jacobian says so;
+//   * normal equations: a gather over per-pose incidence lists (fixed order => bit-reproducible, no atomics);
+//   * windows of up to 64 poses (SPARSE path): the wave first orders the poses by multiple-minimum-degree on 64-bit
+//     adjacency masks (lane = pose; what CHOLMOD's AMD ordering does for the reference, localization.h:82-84), derives the
+//     exact block structure of the Cholesky factor and its elimination-tree levels, and then factors LEVEL BY LEVEL: all
+//     block columns of a level are independent, their rows are spread over the 64 lanes (6x6 blocks, the right-hand side
+//     rides along as one more row), two barriers per level.  BASELINE config 5's key-frame tree is 6 levels instead of
+//     64 sequential block columns and has no fill; a chain is eaten from both ends;
+//   * larger windows (SKYLINE path): H and its factor in envelope form in the caller's pose order, one block column
+//     after the other;
+//   * small windows keep everything in LDS, larger ones in a per-instance slice of an HBM workspace (index tables in LDS);
+//   * all LM control flow is wave-uniform (sums are DPP reductions: every lane holds the same bits).
 #include "window_kernel.h"
 #include "device_math.h"
+#include "numeric_jacobian.h"
 
 #include <float.h>
 #include <math.h>
+
+#include <atomic>
 
 namespace locamd {
 
@@ -146,23 +152,70 @@ __device__ __forceinline__ void quat_right_jac(const double* q, double sgn, doub
     J[5 * ldj + 3] = -y; J[5 * ldj + 4] = x;  J[5 * ldj + 5] = w;
 }
 
+typedef unsigned long long u64;
+
 struct Lds {
-    double *Hs, *Ls;  // skyline H (lower) and its Cholesky factor (LDS, or an HBM workspace slice for large windows)
+    double *Hs, *Ls;  // block-sparse H (lower) and its Cholesky factor (LDS, or an HBM workspace slice for large windows)
     double *diagL, *b, *x, *yrow, *pose, *bak, *rrec, *prec, *srec;
-    int *fb, *last, *boff;  // per block row: first / last connected block, offset of the block row's storage
+    int *boff;              // per block row: offset of its storage (boff[nv] = stored entries)
+    int *fb, *last;         // SKYLINE path: first / last connected block of a block row / column
+    // SPARSE path (nv <= 64), everything in elimination-order labels:
+    u64 *rowmask, *colmask; //   rowmask[i]: block columns K <= i with L(i,K) != 0 (bit i set); colmask[J]: block rows i > J with L(i,J) != 0
+    u64 *scr;               //   nv_max words of scratch for the ordering
+    int *perm;              //   caller's pose slot -> elimination position
+    int *lvl_col, *lvl_blk; //   per elimination-tree level: first entry in colorder / otask (nlev + 1 entries)
+    int *colorder;          //   block columns sorted by level
+    int *otask;             //   off-diagonal blocks (i << 8 | J) sorted by the level of J
+    int nlev;
     int *ioff, *ilist;      // per pose: its incident edges in fold order (CSR), entry = kind << 28 | role << 27 | edge
     int *shared;            // [0] = count, then the binary edges (range e, or nr + SE3 e) whose pair of poses has another edge, in fold order
-    double* blk; // 6x6 scratch: the diagonal block being factored
+    double* blk; // 6x6 scratch: the diagonal block being factored (SKYLINE path)
 #ifdef LOCAMD_WINDOW_TIMING
     long long* tim;  // diagnostic build: cycles in (a) segments, (b) block exchange+factor, (c) row finish, back-substitution
 #endif
-    // this instance's edge tables, staged from HBM once per launch
-    const int32_t *r_idx, *p_idx, *s_idx;
+    // this instance's edge tables (staged from HBM once per launch; the SPARSE path relabels the indices in place)
+    int32_t *r_idx, *p_idx, *s_idx;
     const double *r_val, *p_val, *s_val;
 };
 
+// Diagnostic build (-DLOCAMD_WINDOW_TIMING, tests/perf/probe_window_phases.py): cycles per phase, accumulated by lane 0 in
+// LDS and written INSTEAD of the result record — 0 set-up (ordering, structure, incidence), 1 linearise, 2 build,
+// 3 factor phase 1 (SKYLINE: the whole sweep), 4 factor phase 2, 5 back-substitution, 6 update + trial evaluation, 7 total.
+#ifdef LOCAMD_WINDOW_TIMING
+#define LOCAMD_TIC() const long long locamd_t0 = clock64()
+#define LOCAMD_TOC(slot) do { if (lane == 0) L.tim[slot] += clock64() - locamd_t0; } while (0)
+#else
+#define LOCAMD_TIC() do {} while (0)
+#define LOCAMD_TOC(slot) do {} while (0)
+#endif
+
+#pragma clang fp contract(off)
+// one column of the numeric Jacobian of endpoint `which` (0: the pose carrying the lever arm, 1: the other pose)
+template <int D>
+__device__ __forceinline__ double range_jac_numeric(const double* X0, const double* off, const double* X1, const double* q1, int which, double meas) {
+    constexpr double delta = 1e-9;
+    constexpr double scalar = 1.0 / (2 * delta);
+    double Rp[9], tp[3], Rm[9], tm[3];
+    double ep, em;
+    if (which == 0) {
+        oplus_axis_plain<D>(X0, X0 + 9, delta, Rp, tp);
+        oplus_axis_plain<D>(X0, X0 + 9, -delta, Rm, tm);
+        ep = range_error_plain(Rp, tp, off, q1, meas);
+        em = range_error_plain(Rm, tm, off, q1, meas);
+    } else {
+        oplus_axis_plain<D>(X1, X1 + 9, delta, Rp, tp);   // endpoint 1 has no lever arm: its point is its translation
+        oplus_axis_plain<D>(X1, X1 + 9, -delta, Rm, tm);
+        ep = range_error_plain(X0, X0 + 9, off, tp, meas);
+        em = range_error_plain(X0, X0 + 9, off, tm, meas);
+    }
+    double bak = ep;
+    bak -= em;
+    return scalar * bak;
+}
+#pragma clang fp contract(fast)
+
 // Evaluate every edge at the current poses: errors + chi sums always, Jacobian/weight records when FULL.
-template <bool FULL>
+template <bool FULL, int JAC>
 __device__ __forceinline__ void evaluate_edges(const WindowArgs& a, const Lds& L, int inst, int lane, int nr, int np, int ns,
                                double& robust_chi, double& plain_chi) {
     (void)inst;
@@ -182,27 +235,42 @@ __device__ __forceinline__ void evaluate_edges(const WindowArgs& a, const Lds& L
         else { const double* an = a.anchors + (size_t)(-1 - v1) * 3; p1[0] = an[0]; p1[1] = an[1]; p1[2] = an[2]; }
         double u[3] = {p0[0] - p1[0], p0[1] - p1[1], p0[2] - p1[2]};
         const double n = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
-        const double err = meas - n;
+        const double err = JAC == 0 ? meas - n : range_error_plain(X0, X0 + 9, off, p1, meas);
         const double chi = err * (info * err);
         const double aux = 1.0 + chi;
         rsum += log(aux);
         csum += chi;
         if (FULL) {
             double* rec = L.rrec + e * RREC;
-            const double inv = n > 0.0 ? 1.0 / n : 0.0;  // coincident endpoints: J = 0
-            u[0] *= inv; u[1] *= inv; u[2] *= inv;
-            double uR[3];
-            mat_tvec(X0, u, uR);  // (u^T R0)^T
-            rec[0] = -uR[0]; rec[1] = -uR[1]; rec[2] = -uR[2];
-            // dp0/dv = -2 R0 [o]x  =>  de/dv0 = 2 (uR x o)
-            rec[3] = 2.0 * (uR[1] * off[2] - uR[2] * off[1]);
-            rec[4] = 2.0 * (uR[2] * off[0] - uR[0] * off[2]);
-            rec[5] = 2.0 * (uR[0] * off[1] - uR[1] * off[0]);
-            if (v1 >= 0) {
-                double uR1[3];
-                mat_tvec(L.pose + v1 * 12, u, uR1);
-                rec[6] = uR1[0]; rec[7] = uR1[1]; rec[8] = uR1[2];
-            } else { rec[6] = 0; rec[7] = 0; rec[8] = 0; }
+            if (JAC == 0) {
+                const double inv = n > 0.0 ? 1.0 / n : 0.0;  // coincident endpoints: J = 0
+                u[0] *= inv; u[1] *= inv; u[2] *= inv;
+                double uR[3];
+                mat_tvec(X0, u, uR);  // (u^T R0)^T
+                rec[0] = -uR[0]; rec[1] = -uR[1]; rec[2] = -uR[2];
+                // dp0/dv = -2 R0 [o]x  =>  de/dv0 = 2 (uR x o)
+                rec[3] = 2.0 * (uR[1] * off[2] - uR[2] * off[1]);
+                rec[4] = 2.0 * (uR[2] * off[0] - uR[0] * off[2]);
+                rec[5] = 2.0 * (uR[0] * off[1] - uR[1] * off[0]);
+                if (v1 >= 0) {
+                    double uR1[3];
+                    mat_tvec(L.pose + v1 * 12, u, uR1);
+                    rec[6] = uR1[0]; rec[7] = uR1[1]; rec[8] = uR1[2];
+                } else { rec[6] = 0; rec[7] = 0; rec[8] = 0; }
+            } else {
+                const double* X1 = v1 >= 0 ? L.pose + v1 * 12 : X0;
+                rec[0] = range_jac_numeric<0>(X0, off, X1, p1, 0, meas);
+                rec[1] = range_jac_numeric<1>(X0, off, X1, p1, 0, meas);
+                rec[2] = range_jac_numeric<2>(X0, off, X1, p1, 0, meas);
+                rec[3] = range_jac_numeric<3>(X0, off, X1, p1, 0, meas);
+                rec[4] = range_jac_numeric<4>(X0, off, X1, p1, 0, meas);
+                rec[5] = range_jac_numeric<5>(X0, off, X1, p1, 0, meas);
+                if (v1 >= 0) {  // (rotating endpoint 1 does not move its point: those three columns are exactly 0)
+                    rec[6] = range_jac_numeric<0>(X0, off, X1, p1, 1, meas);
+                    rec[7] = range_jac_numeric<1>(X0, off, X1, p1, 1, meas);
+                    rec[8] = range_jac_numeric<2>(X0, off, X1, p1, 1, meas);
+                } else { rec[6] = 0; rec[7] = 0; rec[8] = 0; }
+            }
             rec[9] = 0; rec[10] = 0; rec[11] = 0;
             const double wr = info / aux;  // rho' * Omega
             rec[12] = wr;
@@ -325,45 +393,76 @@ __device__ __forceinline__ void evaluate_edges(const WindowArgs& a, const Lds& L
     plain_chi = wave_sum(csum);
 }
 
-// ---- skyline storage ---------------------------------------------------------------------------------------------
-// H (lower triangle) and its Cholesky factor live in SKYLINE form: the six rows of pose block v keep columns
-// [6 fb[v], 6 v + 5], fb[v] = the leftmost block v is connected to (itself if none).  Cholesky fill-in never leaves that
-// envelope, so storage and work are O(n * band^2) instead of O(n^2) / O(n^3): a 500-pose chain (cfg/uwb_pose.yaml) is
-// 3000 rows of ~12 entries.  A block row is stored COLUMN-MAJOR (6 rows x its columns): entry (6 v + r, col) sits at
-// boff[v] + 6 (col - 6 fb[v]) + r, so the six lanes working on one block row read one contiguous 48-byte piece per column
-// and a 6-column step of the sweep touches 288 contiguous bytes per block row (it was six separate row segments);
-// the back-substitution's per-column reads are contiguous across lanes.  boff[nv] = stored entries.
+// ---- storage ---------------------------------------------------------------------------------------------------------
+// H (lower triangle) and its Cholesky factor are stored by 6x6 blocks, the blocks of a block row one after the other in
+// column order, each block COLUMN-MAJOR: entry (6 i + r, 6 K + c) sits at off(i, K) + 6 c + r.  Which blocks a row has:
+//   SKYLINE (nv_max > 64): columns fb[i]..i, fb[i] = the leftmost block i is connected to; Cholesky never leaves that
+//     envelope, so storage and work are O(n band^2): a 500-pose chain (cfg/uwb_pose.yaml) is 3000 rows of ~12 entries;
+//   SPARSE  (nv_max <= 64): exactly the blocks of the factor's structure under the in-kernel elimination order (rowmask).
+// Capacity in both cases: the envelope bound of the caller's bw_max (the exact structure of the natural order lies inside
+// it; an elimination order that would need more falls back to the natural one).
 __host__ __device__ inline size_t sky_nnz_bound(int nv, int bw) {
     size_t s = 0;
     for (int v = 0; v < nv; ++v) s += 36 * ((size_t)(v < bw ? v : bw) + 1);
     return s;
 }
+__host__ __device__ inline bool window_sparse_path(const WindowCaps& c) { return c.nv_max <= 64; }
 
 // entries of the per-pose incidence lists: every edge once per moving endpoint
 __host__ __device__ inline size_t window_incidences(const WindowCaps& c) {
     return 2 * (size_t)c.nr_max + (size_t)c.np_max + 2 * (size_t)c.ns_max;
 }
-// doubles of one instance's arrays (skyline pair, dense vectors, poses, edge records, index tables) — the layout the
-// kernel carves, in LDS or in the HBM workspace
+__host__ __device__ inline size_t ints_as_doubles(size_t n) { return (n + 1) / 2; }
+// doubles of one instance's MAIN arrays (block-sparse pair, dense vectors, poses, edge records, incidence lists, a
+// writable copy of the edge index tables) — the layout the kernel carves, in LDS or in the HBM workspace
 __host__ __device__ inline size_t window_instance_doubles(const WindowCaps& c) {
     const size_t n_max = 6 * (size_t)c.nv_max;
     return 2 * sky_nnz_bound(c.nv_max, c.bw_max) + 4 * n_max + 2 * (size_t)c.nv_max * 12 + (size_t)c.nr_max * RREC + (size_t)c.np_max * PREC +
-           (size_t)c.ns_max * SREC + 2 * (((size_t)c.nv_max + 1) / 2) + (n_max + 2) / 2 + ((size_t)c.nv_max + 2) / 2 +
-           (window_incidences(c) + 1) / 2 + ((size_t)c.nr_max + (size_t)c.ns_max + 2) / 2;
+           (size_t)c.ns_max * SREC + ints_as_doubles(window_incidences(c)) + ints_as_doubles((size_t)c.nr_max + c.ns_max + 1) +
+           ints_as_doubles(2 * (size_t)c.nr_max) + ints_as_doubles((size_t)c.np_max) + ints_as_doubles(4 * (size_t)c.ns_max);
+}
+// bytes of the small index tables that always live in LDS
+__host__ __device__ inline size_t window_table_bytes(const WindowCaps& c) {
+    const size_t nv = (size_t)c.nv_max;
+    if (!window_sparse_path(c)) return (4 * nv + 2) * sizeof(int);  // fb, last, boff[nv + 1], ioff[nv + 1]
+    const size_t nb_max = sky_nnz_bound(c.nv_max, c.bw_max) / 36;
+    return 3 * nv * sizeof(u64) + (6 * nv + 4 + nb_max) * sizeof(int);  // rowmask, colmask, scr; perm, boff, ioff, lvl_col, lvl_blk, colorder, otask
 }
 
-// address of H/L entry (row, col), col <= row, col inside row's envelope
+// offset of block (i, K), K <= i, in the storage of H / L
+template <bool SP>
+__device__ __forceinline__ int blk_off(const Lds& L, int i, int K) {
+    if (SP) return L.boff[i] + 36 * __popcll(L.rowmask[i] & ((1ull << K) - 1));
+    return L.boff[i] + 36 * (K - L.fb[i]);
+}
+// address of H/L entry (row, col), col <= row, inside row's structure
+template <bool SP>
 __device__ __forceinline__ int sky(const Lds& L, int row, int col) {
-    const int v = row / 6;
-    return L.boff[v] + 6 * (col - 6 * L.fb[v]) + (row - 6 * v);
+    const int i = row / 6, K = col / 6;
+    return blk_off<SP>(L, i, K) + 6 * (col - 6 * K) + (row - 6 * i);
 }
 
 constexpr int INC_KIND_SHIFT = 28, INC_ROLE_SHIFT = 27, INC_EDGE_MASK = (1 << 27) - 1;
 
-// Once per solve (the topology does not change between iterations): fb[], last[], boff[], the incidence lists, and
-// the list of binary edges that share their pair of poses with another edge.
-__device__ __forceinline__ void compute_skyline(const Lds& L, int lane, int n, int nr, int np, int ns) {
-    const int nv = n / 6;
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int m = 32; m; m >>= 1) v = min(v, __shfl_xor(v, m, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int m = 32; m; m >>= 1) v = max(v, __shfl_xor(v, m, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_excl_scan_i(int v, int lane) {
+    int s = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(s, d, 64); if (lane >= d) s += t; }
+    return s - v;
+}
+
+// SKYLINE path, once per solve: fb[], last[], boff[] in the caller's pose order.
+__device__ __forceinline__ void compute_skyline(const Lds& L, int lane, int nv, int nr, int ns) {
     if (lane == 0) {
         for (int v = 0; v < nv; ++v) { L.fb[v] = v; L.last[v] = v; }
         for (int e = 0; e < nr; ++e) {
@@ -380,26 +479,141 @@ __device__ __forceinline__ void compute_skyline(const Lds& L, int lane, int n, i
         int off = 0;
         for (int v = 0; v < nv; ++v) { L.boff[v] = off; off += 36 * (v - L.fb[v] + 1); }
         L.boff[nv] = off;
+    }
+    __syncthreads();
+}
+
+// SPARSE path, once per solve (nv <= 64, lane = pose): elimination order, structure of the factor, levels, task lists.
+//   1. adjacency masks of the poses (binary edges), caller's labels;
+//   2. multiple minimum degree: per round every pose of minimum degree that has no lower-numbered minimum-degree
+//      neighbour is eliminated (an independent set, so the poses of a round do not interact); their remaining neighbours
+//      become cliques.  `natural`: one pose per round in the caller's order instead (the fallback whose structure is
+//      guaranteed to fit the envelope capacity);
+//   3. relabel by elimination position; rowmask / colmask of the factor; block offsets; elimination-tree levels
+//      (level(J) = 1 + max level of the columns in row J); columns and off-diagonal blocks sorted by level.
+// Returns the number of blocks of the factor (the caller checks it against the capacity).
+__device__ __forceinline__ int compute_sparse(Lds& L, int lane, int nv, int nv_max, int nb_max, int nr, int ns, bool natural) {
+    if (lane < nv) L.scr[lane] = 0;
+    __syncthreads();
+    for (int e = lane; e < nr; e += 64) {
+        const int v0 = L.r_idx[2 * e], v1 = L.r_idx[2 * e + 1];
+        if (v1 >= 0) { atomicOr(&L.scr[v0], 1ull << v1); atomicOr(&L.scr[v1], 1ull << v0); }
+    }
+    for (int e = lane; e < ns; e += 64) {
+        const int v0 = L.s_idx[4 * e], v1 = L.s_idx[4 * e + 1];
+        atomicOr(&L.scr[v0], 1ull << v1); atomicOr(&L.scr[v1], 1ull << v0);
+    }
+    __syncthreads();
+    const u64 me = 1ull << lane, below = me - 1;
+    u64 a = lane < nv ? (L.scr[lane] & ~me) : 0;
+    u64 remaining = nv >= 64 ? ~0ull : (1ull << nv) - 1;
+    int pos = 0, mypos = 0;
+    u64 mystruct = 0;
+    while (remaining) {
+        const bool alive = (remaining & me) != 0;
+        u64 S;
+        if (natural) {
+            S = remaining & (~remaining + 1);
+        } else {
+            const int deg = alive ? __popcll(a & remaining) : 1000;
+            const int mind = wave_min_i(deg);
+            const u64 cand = __ballot(deg == mind);
+            S = __ballot(alive && deg == mind && (a & cand & below) == 0);
+        }
+        const bool sel = (S & me) != 0;
+        if (sel) { mypos = pos + __popcll(S & below); mystruct = a & remaining; }
+        __syncthreads();
+        if (sel) L.scr[lane] = mystruct;
+        __syncthreads();
+        if (alive && !sel) {
+            u64 m = a & S;
+            while (m) { const int v = __ffsll((long long)m) - 1; m &= m - 1; a |= L.scr[v]; }
+            a &= ~me;
+        }
+        remaining &= ~S;
+        pos += __popcll(S);
+    }
+    __syncthreads();
+    if (lane < nv) L.perm[lane] = mypos;
+    __syncthreads();
+    {
+        u64 cm = 0, m = mystruct;
+        while (m) { const int u = __ffsll((long long)m) - 1; m &= m - 1; cm |= 1ull << L.perm[u]; }
+        if (lane < nv) L.colmask[mypos] = cm;
+    }
+    __syncthreads();
+    // from here on lane = elimination position
+    const u64 mycol = lane < nv ? L.colmask[lane] : 0;
+    u64 rm = lane < nv ? me : 0;
+    for (int J = 0; J < nv; ++J) rm |= ((L.colmask[J] >> lane) & 1ull) << J;
+    if (lane >= nv) rm = 0;
+    if (lane < nv) L.rowmask[lane] = rm;
+    const int cnt = __popcll(rm);
+    const int off = wave_excl_scan_i(cnt, lane);
+    const int nb = __shfl(off + cnt, 63, 64);
+    if (lane < nv) L.boff[lane] = 36 * off;
+    if (lane == 0) L.boff[nv] = 36 * nb;
+    if (nb > nb_max) return nb;  // (uniform) does not fit the capacity: the caller falls back to the natural order
+    int lev = 0;
+    for (int J = 0; J < nv; ++J) {
+        const int lJ = __shfl(lev, J, 64);
+        if (((rm >> J) & 1ull) && J != lane) lev = max(lev, lJ + 1);
+    }
+    const int nlev = wave_max_i(lane < nv ? lev : 0) + 1;
+    int rank = 0, base = 0;
+    for (int l = 0; l < nlev; ++l) {
+        const u64 bl = __ballot(lane < nv && lev == l);
+        if (lane == 0) L.lvl_col[l] = base;
+        if (lane < nv && lev == l) rank = base + __popcll(bl & below);
+        base += __popcll(bl);
+    }
+    if (lane == 0) L.lvl_col[nlev] = base;
+    if (lane < nv) L.colorder[rank] = lane;
+    // off-diagonal blocks of the columns, in level order
+    int* tmp = reinterpret_cast<int*>(L.scr);  // 2 nv_max ints
+    const int nbc = __popcll(mycol);
+    __syncthreads();
+    if (lane < nv) tmp[rank] = nbc;
+    __syncthreads();
+    const int c_r = lane < nv ? tmp[lane] : 0;
+    const int st = wave_excl_scan_i(c_r, lane);
+    if (lane < nv) tmp[nv_max + lane] = st;
+    __syncthreads();
+    const int blkbase = lane < nv ? tmp[nv_max + rank] : 0;
+    for (int l = lane; l < nlev; l += 64) L.lvl_blk[l] = tmp[nv_max + L.lvl_col[l]];
+    if (lane == 0) L.lvl_blk[nlev] = nb - nv;
+    {
+        u64 m = mycol;
+        int k = 0;
+        while (m) { const int i = __ffsll((long long)m) - 1; m &= m - 1; L.otask[blkbase + k++] = (i << 8) | lane; }
+    }
+    L.nlev = nlev;
+    __syncthreads();
+    return nb;
+}
+
+// Once per solve (the topology does not change between iterations): the incidence lists, and the list of binary edges
+// that share their pair of poses with another edge.
+template <bool SP>
+__device__ __forceinline__ void compute_incidence(const Lds& L, int lane, int nv, int nr, int np, int ns, int* cursor) {
+    if (lane == 0) {
         // incidence lists in the order the fold visits the edges: ranges, priors, SE3 (stable counting sort by pose)
         for (int v = 0; v <= nv; ++v) L.ioff[v] = 0;
         for (int e = 0; e < nr; ++e) { ++L.ioff[L.r_idx[2 * e] + 1]; if (L.r_idx[2 * e + 1] >= 0) ++L.ioff[L.r_idx[2 * e + 1] + 1]; }
         for (int e = 0; e < np; ++e) ++L.ioff[L.p_idx[e] + 1];
         for (int e = 0; e < ns; ++e) { ++L.ioff[L.s_idx[4 * e] + 1]; ++L.ioff[L.s_idx[4 * e + 1] + 1]; }
         for (int v = 0; v < nv; ++v) L.ioff[v + 1] += L.ioff[v];
-        // (last[] doubles as the write cursor while the lists are filled; it is rebuilt right after)
-        for (int v = 0; v < nv; ++v) L.last[v] = L.ioff[v];
+        for (int v = 0; v < nv; ++v) cursor[v] = L.ioff[v];
         for (int e = 0; e < nr; ++e) {
             const int v0 = L.r_idx[2 * e], v1 = L.r_idx[2 * e + 1];
-            L.ilist[L.last[v0]++] = e;
-            if (v1 >= 0) L.ilist[L.last[v1]++] = (1 << INC_ROLE_SHIFT) | e;
+            L.ilist[cursor[v0]++] = e;
+            if (v1 >= 0) L.ilist[cursor[v1]++] = (1 << INC_ROLE_SHIFT) | e;
         }
-        for (int e = 0; e < np; ++e) L.ilist[L.last[L.p_idx[e]]++] = (1 << INC_KIND_SHIFT) | e;
+        for (int e = 0; e < np; ++e) L.ilist[cursor[L.p_idx[e]]++] = (1 << INC_KIND_SHIFT) | e;
         for (int e = 0; e < ns; ++e) {
-            L.ilist[L.last[L.s_idx[4 * e]]++] = (2 << INC_KIND_SHIFT) | e;
-            L.ilist[L.last[L.s_idx[4 * e + 1]]++] = (2 << INC_KIND_SHIFT) | (1 << INC_ROLE_SHIFT) | e;
+            L.ilist[cursor[L.s_idx[4 * e]]++] = (2 << INC_KIND_SHIFT) | e;
+            L.ilist[cursor[L.s_idx[4 * e + 1]]++] = (2 << INC_KIND_SHIFT) | (1 << INC_ROLE_SHIFT) | e;
         }
-        for (int v = 0; v < nv; ++v) L.last[v] = v;
-        for (int v = 0; v < nv; ++v) for (int J = L.fb[v]; J <= v; ++J) L.last[J] = max(L.last[J], v);
     }
     __syncthreads();
     // Binary edges that share their pair of poses with another one: every binary edge stamps its number on the first
@@ -408,7 +622,7 @@ __device__ __forceinline__ void compute_skyline(const Lds& L, int lane, int n, i
     auto block_entry = [&](int t) {
         const bool is_r = t < nr;
         const int va = is_r ? L.r_idx[2 * t] : L.s_idx[4 * (t - nr)], vb = is_r ? L.r_idx[2 * t + 1] : L.s_idx[4 * (t - nr) + 1];
-        return vb >= 0 ? sky(L, 6 * max(va, vb), 6 * min(va, vb)) : -1;
+        return vb >= 0 ? sky<SP>(L, 6 * max(va, vb), 6 * min(va, vb)) : -1;
     };
     for (int t = lane; t < nr + ns; t += 64) { const int a0 = block_entry(t); if (a0 >= 0) L.Hs[a0] = (double)(t + 1); }
     __syncthreads();
@@ -427,12 +641,14 @@ __device__ __forceinline__ void compute_skyline(const Lds& L, int lane, int n, i
     }
     __syncthreads();
 }
+
 // Fold the edge records into H (skyline lower triangle) and b: H_vv = sum J_v^T (rho' Omega) J_v etc., every entry summed
 // over its edges in one fixed order (ranges, priors, SE3; bit-reproducible, no atomics).  It is a gather: task
 // (pose v, entry) walks v's incidence list and sums that entry of the diagonal block / of b in a register, one store at
 // the end; an off-diagonal block that belongs to one edge is written by it; the few pairs of poses with several edges
 // (a key-frame pose edge landing on the previous pose next to the smoothness edge) are accumulated edge by edge at the
 // end.  No read-modify-write chains through memory for the bulk, all tasks independent.
+template <bool SP>
 __device__ __forceinline__ void build_system(const Lds& L, int lane, int n, int nr, int ns) {
     const int nv = n / 6;
     const int nnz = L.boff[nv];
@@ -482,7 +698,7 @@ __device__ __forceinline__ void build_system(const Lds& L, int lane, int n, int 
             }
         }
         if (is_b) L.b[v * 6 + rb] = acc;
-        else L.Hs[sky(L, v * 6 + r, v * 6 + cc)] = acc;
+        else L.Hs[sky<SP>(L, v * 6 + r, v * 6 + cc)] = acc;
     }
     // off-diagonal blocks: one task per (binary edge, entry); the value of entry (r, cc) of edge t
     auto offdiag = [&](int t, int r, int cc, int& addr) {
@@ -491,8 +707,8 @@ __device__ __forceinline__ void build_system(const Lds& L, int lane, int n, int 
             const int v0 = L.r_idx[2 * t], v1 = L.r_idx[2 * t + 1];
             const double* rec = L.rrec + t * RREC;
             const double wr = rec[12];
-            if (v0 > v1) { h = wr * rec[r] * rec[6 + cc]; addr = sky(L, v0 * 6 + r, v1 * 6 + cc); }
-            else         { h = wr * rec[6 + r] * rec[cc]; addr = sky(L, v1 * 6 + r, v0 * 6 + cc); }
+            if (v0 > v1) { h = wr * rec[r] * rec[6 + cc]; addr = sky<SP>(L, v0 * 6 + r, v1 * 6 + cc); }
+            else         { h = wr * rec[6 + r] * rec[cc]; addr = sky<SP>(L, v1 * 6 + r, v0 * 6 + cc); }
         } else {
             const int e = t - nr;
             const int vi = L.s_idx[4 * e], vj = L.s_idx[4 * e + 1];
@@ -500,7 +716,7 @@ __device__ __forceinline__ void build_system(const Lds& L, int lane, int n, int 
             const double *J0 = rec, *J1 = rec + 36, *WJ0 = rec + 72, *WJ1 = rec + 108;
 #pragma unroll
             for (int i = 0; i < 6; ++i) h += (vi > vj) ? J0[i * 6 + r] * WJ1[i * 6 + cc] : J1[i * 6 + r] * WJ0[i * 6 + cc];  // rows of the later pose
-            addr = (vi > vj) ? sky(L, vi * 6 + r, vj * 6 + cc) : sky(L, vj * 6 + r, vi * 6 + cc);
+            addr = (vi > vj) ? sky<SP>(L, vi * 6 + r, vj * 6 + cc) : sky<SP>(L, vj * 6 + r, vi * 6 + cc);
         }
         return h;
     };
@@ -527,7 +743,7 @@ __device__ __forceinline__ void build_system(const Lds& L, int lane, int n, int 
     __syncthreads();
 }
 
-// (H + lambda I) x = b in one sweep over 6x6 block columns (poses are 6-DoF blocks, n = 6 nv):
+// SKYLINE path: (H + lambda I) x = b in one sweep over 6x6 block columns (poses are 6-DoF blocks, n = 6 nv):
 //   per block column J the ACTIVE rows are those of blocks J..last[J] whose envelope reaches J, plus the right-hand side
 //   (it rides along as one more row of the factor: forward substitution is one more Cholesky row).  In chunks of 64:
 //   (a) every lane forms the 6-entry segment S_i = H[i][J] - sum_K L[i][K] L[J][K]^T of its row (K over the band),
@@ -544,9 +760,6 @@ __device__ __forceinline__ bool factor_and_solve(const Lds& L, int lane, int n, 
         const int total = nrows + 1;
         double G[6][6], ig[6];
         for (int base = 0; base < total; base += 64) {
-#ifdef LOCAMD_WINDOW_TIMING
-            long long ts0 = clock64();
-#endif
             const int idx = base + lane;
             const bool is_rhs = idx == nrows;
             const int row = is_rhs ? n : c0 + idx;
@@ -585,9 +798,6 @@ __device__ __forceinline__ bool factor_and_solve(const Lds& L, int lane, int n, 
                     }
                 }
             }
-#ifdef LOCAMD_WINDOW_TIMING
-            long long ts1 = clock64();
-#endif
             if (base == 0) {
                 // (b) publish the diagonal block (rows idx 0..5), factor it everywhere
                 if (idx < 6) {
@@ -617,9 +827,6 @@ __device__ __forceinline__ bool factor_and_solve(const Lds& L, int lane, int n, 
                 }
                 if (!ok) return false;  // uniform: every lane factored the same block
             }
-#ifdef LOCAMD_WINDOW_TIMING
-            long long ts2 = clock64();
-#endif
             // (c) finish the rows
             if (part && (is_rhs || idx >= 6)) {
                 double x[6];
@@ -644,15 +851,10 @@ __device__ __forceinline__ bool factor_and_solve(const Lds& L, int lane, int n, 
                     }
                 }
             }
-#ifdef LOCAMD_WINDOW_TIMING
-            if (lane == 0) { const long long ts3 = clock64(); L.tim[0] += ts1 - ts0; L.tim[1] += ts2 - ts1; L.tim[2] += ts3 - ts2; }
-#endif
         }
         __syncthreads();
     }
-#ifdef LOCAMD_WINDOW_TIMING
-    const long long tb0 = clock64();
-#endif
+    LOCAMD_TIC();
     // back substitution, block rows from the bottom; y (= row n of the factor) is updated in place in LDS
     for (int J = nvb - 1; J >= 0; --J) {
         const int c0 = 6 * J;
@@ -686,15 +888,228 @@ __device__ __forceinline__ bool factor_and_solve(const Lds& L, int lane, int n, 
         }
         __syncthreads();
     }
-#ifdef LOCAMD_WINDOW_TIMING
-    if (lane == 0) L.tim[3] += clock64() - tb0;
-#endif
+    LOCAMD_TOC(5);
     return true;
 }
 
-// GLOBAL_A: the skyline arrays (H and its factor) live in an HBM workspace slice instead of LDS (large windows);
-// a workgroup is one wave on one CU, whose L1 is coherent for its own stores after the workgroup barrier.
-template <bool GLOBAL_A>
+// SPARSE path: (H + lambda I) x = b, level by level over the elimination tree.  Per level (its block columns J are
+// mutually independent):
+//   phase 1  the six rows of every diagonal block form S_JJ = H_JJ + lambda I - sum_K L_JK L_JK^T and publish it RAW into
+//            the upper triangle (+ diagonal) of L's (J, J) block — the Cholesky factor G_J of that block only needs the
+//            strict lower triangle (its inverse pivots go to diagL), so both fit the 36 slots;
+//   phase 2  one lane per row of every block of the level's columns (diagonal rows, off-diagonal rows, and the right-hand
+//            side as one more row per column): factor G_J from the raw block in registers (redundantly: no broadcast of
+//            the factor), then  diagonal rows store their row of G_J;  the others form their 6-entry segment
+//            S = H_iJ - sum_{K in row i and row J} L_iK L_JK^T  and finish it with the 6x6 triangular solve.
+//   Back-substitution walks the levels downwards, one lane per column (a gather over the column's blocks).
+__device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, double lambda) {
+    for (int l = 0; l < L.nlev; ++l) {
+        const int c0 = L.lvl_col[l], ncol = L.lvl_col[l + 1] - c0;
+        const int b0 = L.lvl_blk[l], nblk = L.lvl_blk[l + 1] - b0;
+        LOCAMD_TIC();
+        for (int base = 0; base < 6 * ncol; base += 64) {
+            const int idx = base + lane;
+            if (idx < 6 * ncol) {
+                const int J = L.colorder[c0 + idx / 6], r = idx % 6;
+                const int rowJ = L.boff[J], dJ = L.boff[J + 1] - 36;  // the diagonal block is the last one of its row
+                double S[6];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) S[c] = c <= r ? L.Hs[dJ + 6 * c + r] : 0.0;
+                const int nK = (dJ - rowJ) / 36;
+                for (int kb = 0; kb < nK; ++kb) {
+                    const double* blk = L.Ls + rowJ + 36 * kb;
+                    double li[6];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) li[k] = blk[6 * k + r];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) acc = __builtin_fma(li[k], blk[6 * k + c], acc);
+                        S[c] -= acc;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    if (c == r) S[c] += lambda;
+                    if (c <= r) L.Ls[dJ + 6 * r + c] = S[c];  // entry (r, c) in the transposed slot
+                }
+            }
+        }
+        __syncthreads();
+        LOCAMD_TOC(3);
+        const int ntask = 7 * ncol + 6 * nblk;
+        bool ok = true;
+        const long long locamd_t1 = clock64();
+        (void)locamd_t1;
+        for (int base = 0; base < ntask; base += 64) {
+            const int idx = base + lane;
+            if (idx < ntask) {
+                int kind, i, J, r;  // 0: row r of the diagonal block of J; 1: row r of block (i, J); 2: right-hand side of column J
+                if (idx < 6 * ncol) { kind = 0; J = L.colorder[c0 + idx / 6]; i = J; r = idx % 6; }
+                else if (idx < 6 * (ncol + nblk)) {
+                    const int t = idx - 6 * ncol;
+                    const int code = L.otask[b0 + t / 6];
+                    kind = 1; i = code >> 8; J = code & 255; r = t % 6;
+                } else { kind = 2; J = L.colorder[c0 + idx - 6 * (ncol + nblk)]; i = J; r = 0; }
+                const int rowJ = L.boff[J], dJ = L.boff[J + 1] - 36;
+                // the row's own segment first (its loads overlap the factorisation below)
+                double S[6];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) S[c] = 0.0;
+                int bi = 0;
+                if (kind == 1) {
+                    const u64 rmi = L.rowmask[i], rmJ = L.rowmask[J], belowJ = (1ull << J) - 1;
+                    const int rowi = L.boff[i];
+                    bi = rowi + 36 * __popcll(rmi & belowJ);
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) S[c] = L.Hs[bi + 6 * c + r];
+                    u64 m = rmi & rmJ & belowJ;
+                    while (m) {
+                        const int K = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const u64 belowK = (1ull << K) - 1;
+                        const double* bki = L.Ls + rowi + 36 * __popcll(rmi & belowK);
+                        const double* bkj = L.Ls + rowJ + 36 * __popcll(rmJ & belowK);
+                        double li[6];
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) li[k] = bki[6 * k + r];
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) {
+                            double acc = 0.0;
+#pragma unroll
+                            for (int k = 0; k < 6; ++k) acc = __builtin_fma(li[k], bkj[6 * k + c], acc);
+                            S[c] -= acc;
+                        }
+                    }
+                } else if (kind == 2) {
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) S[c] = L.b[6 * J + c];
+                    u64 m = L.rowmask[J] & ((1ull << J) - 1);
+                    int kb = 0;
+                    while (m) {
+                        const int K = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const double* bkj = L.Ls + rowJ + 36 * kb++;
+                        double li[6];
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) li[k] = L.yrow[6 * K + k];
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) {
+                            double acc = 0.0;
+#pragma unroll
+                            for (int k = 0; k < 6; ++k) acc = __builtin_fma(li[k], bkj[6 * k + c], acc);
+                            S[c] -= acc;
+                        }
+                    }
+                }
+                // G_J from the raw diagonal block: entry (p, q), p >= q, at dJ + 6 p + q
+                double G[6][6], ig[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    double dj = L.Ls[dJ + 7 * j];
+#pragma unroll
+                    for (int k = 0; k < j; ++k) dj = __builtin_fma(-G[j][k], G[j][k], dj);
+                    ok = ok && (dj > 0.0) && (dj < DBL_MAX);
+                    double g, igj;
+                    sqrt_and_rsqrt(fmax(dj, 1e-300), g, igj);
+                    igj = __builtin_fma(igj, __builtin_fma(-g, igj, 1.0), igj);  // one Newton step: 1/g to ~1e-16
+                    G[j][j] = g;
+                    ig[j] = igj;
+#pragma unroll
+                    for (int i2 = j + 1; i2 < 6; ++i2) {
+                        double v = L.Ls[dJ + 6 * i2 + j];
+#pragma unroll
+                        for (int k = 0; k < j; ++k) v = __builtin_fma(-G[i2][k], G[j][k], v);
+                        G[i2][j] = v * ig[j];
+                    }
+                }
+                if (kind == 0) {
+                    // (static indices only: a runtime row index would push G into scratch memory)
+#pragma unroll
+                    for (int rr = 0; rr < 6; ++rr) {
+                        if (r == rr) {
+#pragma unroll
+                            for (int c = 0; c < rr; ++c) L.Ls[dJ + 6 * c + rr] = G[rr][c];
+                            L.diagL[6 * J + rr] = ig[rr];  // the INVERSE pivot: back-substitution multiplies
+                        }
+                    }
+                } else {
+                    double x[6];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {
+                        double v = S[c];
+#pragma unroll
+                        for (int k = 0; k < c; ++k) v = __builtin_fma(-x[k], G[c][k], v);
+                        x[c] = v * ig[c];
+                    }
+                    if (kind == 1) {
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) L.Ls[bi + 6 * c + r] = x[c];
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) L.yrow[6 * J + c] = x[c];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+#ifdef LOCAMD_WINDOW_TIMING
+        if (lane == 0) L.tim[4] += clock64() - locamd_t1;
+#endif
+        if (__ballot(!ok)) return false;
+    }
+    LOCAMD_TIC();
+    // back substitution: x_J = G_J^-T (y_J - sum_{i in column J} L_iJ^T x_i), levels downwards
+    for (int l = L.nlev - 1; l >= 0; --l) {
+        const int c0 = L.lvl_col[l], ncol = L.lvl_col[l + 1] - c0;
+        for (int base = 0; base < ncol; base += 64) {
+            const int idx = base + lane;
+            if (idx < ncol) {
+                const int J = L.colorder[c0 + idx];
+                const int dJ = L.boff[J + 1] - 36;
+                const u64 belowJ = (1ull << J) - 1;
+                double t[6];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) t[c] = L.yrow[6 * J + c];
+                u64 m = L.colmask[J];
+                while (m) {
+                    const int i = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const double* bk = L.Ls + L.boff[i] + 36 * __popcll(L.rowmask[i] & belowJ);
+                    double xi[6];
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) xi[r] = L.x[6 * i + r];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int r = 0; r < 6; ++r) acc = __builtin_fma(bk[6 * c + r], xi[r], acc);
+                        t[c] -= acc;
+                    }
+                }
+                double xs[6];
+#pragma unroll
+                for (int rr = 5; rr >= 0; --rr) {
+                    double v = t[rr];
+#pragma unroll
+                    for (int s2 = rr + 1; s2 < 6; ++s2) v = __builtin_fma(-L.Ls[dJ + 6 * rr + s2], xs[s2], v);
+                    xs[rr] = v * L.diagL[6 * J + rr];
+                }
+#pragma unroll
+                for (int c = 0; c < 6; ++c) L.x[6 * J + c] = xs[c];
+            }
+        }
+        __syncthreads();
+    }
+    LOCAMD_TOC(5);
+    return true;
+}
+
+// GLOBAL_A: the main arrays (H, its factor, vectors, poses, records) live in an HBM workspace slice instead of LDS (large
+// windows); a workgroup is one wave on one CU, whose L1 is coherent for its own stores after the workgroup barrier.
+// JAC: range-edge Jacobians analytic (0) or g2o's central differences (1).  SP: SPARSE path (nv_max <= 64) or SKYLINE.
+template <bool GLOBAL_A, int JAC, bool SP>
 __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int inst = blockIdx.x;
@@ -705,15 +1120,14 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
     const int n_max = 6 * c.nv_max;
     const size_t nnz_max = sky_nnz_bound(c.nv_max, c.bw_max);
     Lds L;
-    // Small windows: everything per-instance lives in LDS.  Large windows (GLOBAL_A): everything lives in this
-    // instance's slice of the HBM workspace (L1/L2-cached), edge tables are read where the caller put them; only the
-    // 6x6 exchange block stays in LDS.
     __shared__ double s_blk[36];
 #ifdef LOCAMD_WINDOW_TIMING
-    __shared__ long long s_tim[4];
-    if (lane < 4) s_tim[lane] = 0;
+    __shared__ long long s_tim[8];
+    if (lane < 8) s_tim[lane] = 0;
     L.tim = s_tim;
+    const long long t_start = clock64();
 #endif
+    // main arrays: LDS for small windows, this instance's slice of the HBM workspace (L1/L2-cached) for large ones
     double* p = GLOBAL_A ? a.workspace + (size_t)inst * window_instance_doubles(c) : lds;
     L.Hs = p; p += nnz_max;
     L.Ls = p; p += nnz_max;
@@ -727,70 +1141,104 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
     L.rrec = p; p += c.nr_max * RREC;
     L.prec = p; p += c.np_max * PREC;
     L.srec = p; p += c.ns_max * SREC;
-    if (GLOBAL_A) {
-        // the three small index tables stay in LDS even when everything else is in the HBM workspace: every address in
-        // the sweep and in the edge fold starts with a lookup in them, and an HBM round trip there is pure latency
-        int* t = reinterpret_cast<int*>(lds);
-        L.fb = t; L.last = t + c.nv_max; L.boff = t + 2 * c.nv_max; L.ioff = t + 3 * c.nv_max + 1;
-        p += 2 * ((c.nv_max + 1) / 2) + (n_max + 2) / 2 + (c.nv_max + 2) / 2;  // (their workspace slots stay unused)
-    } else {
-        L.fb = reinterpret_cast<int*>(p); p += (c.nv_max + 1) / 2;
-        L.last = reinterpret_cast<int*>(p); p += (c.nv_max + 1) / 2;
-        L.boff = reinterpret_cast<int*>(p); p += (n_max + 2) / 2;
-        L.ioff = reinterpret_cast<int*>(p); p += (c.nv_max + 2) / 2;
+    L.ilist = reinterpret_cast<int*>(p); p += ints_as_doubles(window_incidences(c));
+    L.shared = reinterpret_cast<int*>(p); p += ints_as_doubles((size_t)c.nr_max + c.ns_max + 1);
+    L.r_idx = reinterpret_cast<int32_t*>(p); p += ints_as_doubles(2 * (size_t)c.nr_max);
+    L.p_idx = reinterpret_cast<int32_t*>(p); p += ints_as_doubles((size_t)c.np_max);
+    L.s_idx = reinterpret_cast<int32_t*>(p); p += ints_as_doubles(4 * (size_t)c.ns_max);
+    // the small index tables stay in LDS even when everything else is in the HBM workspace: every address in the sweep and
+    // in the edge fold starts with a lookup in them, and an HBM round trip there is pure latency
+    {
+        double* t = GLOBAL_A ? lds : p;
+        if (SP) {
+            L.rowmask = reinterpret_cast<u64*>(t); L.colmask = L.rowmask + c.nv_max; L.scr = L.colmask + c.nv_max;
+            int* ti = reinterpret_cast<int*>(L.scr + c.nv_max);
+            L.perm = ti; ti += c.nv_max;
+            L.boff = ti; ti += c.nv_max + 1;
+            L.ioff = ti; ti += c.nv_max + 1;
+            L.lvl_col = ti; ti += c.nv_max + 1;
+            L.lvl_blk = ti; ti += c.nv_max + 1;
+            L.colorder = ti; ti += c.nv_max;
+            L.otask = ti;
+            L.fb = L.last = nullptr;
+        } else {
+            int* ti = reinterpret_cast<int*>(t);
+            L.fb = ti; L.last = ti + c.nv_max; L.boff = ti + 2 * c.nv_max; L.ioff = ti + 3 * c.nv_max + 1;
+            L.rowmask = L.colmask = L.scr = nullptr; L.perm = L.lvl_col = L.lvl_blk = L.colorder = L.otask = nullptr;
+        }
+        if (!GLOBAL_A) p += (window_table_bytes(c) + 7) / 8;
     }
-    L.ilist = reinterpret_cast<int*>(p); p += (window_incidences(c) + 1) / 2;
-    L.shared = reinterpret_cast<int*>(p); p += (c.nr_max + c.ns_max + 2) / 2;
-    double* gpose = a.poses + (size_t)inst * c.nv_max * 12;
-    for (int i = lane; i < nv * 12; i += 64) L.pose[i] = gpose[i];
+    L.nlev = 0;
+    // edge tables: the values are staged into LDS for small windows and read in place for large ones; the index tables
+    // always get a private writable copy (the SPARSE path relabels them)
+    for (int i = lane; i < nr * 2; i += 64) L.r_idx[i] = a.r_idx[(size_t)inst * c.nr_max * 2 + i];
+    for (int i = lane; i < np; i += 64) L.p_idx[i] = a.p_idx[(size_t)inst * c.np_max + i];
+    for (int i = lane; i < ns * 4; i += 64) L.s_idx[i] = a.s_idx[(size_t)inst * c.ns_max * 4 + i];
     if (GLOBAL_A) {
-        L.r_idx = a.r_idx + (size_t)inst * c.nr_max * 2; L.r_val = a.r_val + (size_t)inst * c.nr_max * 5;
-        L.p_idx = a.p_idx + (size_t)inst * c.np_max;     L.p_val = a.p_val + (size_t)inst * c.np_max * 18;
-        L.s_idx = a.s_idx + (size_t)inst * c.ns_max * 4; L.s_val = a.s_val + (size_t)inst * c.ns_max * 48;
+        L.r_val = a.r_val + (size_t)inst * c.nr_max * 5;
+        L.p_val = a.p_val + (size_t)inst * c.np_max * 18;
+        L.s_val = a.s_val + (size_t)inst * c.ns_max * 48;
     } else {
         double* st_rval = p; p += c.nr_max * 5;
         double* st_pval = p; p += c.np_max * 18;
-        double* st_sval = p; p += c.ns_max * 48;
-        int32_t* st_ridx = reinterpret_cast<int32_t*>(p); p += c.nr_max;        // nr_max * 2 ints
-        int32_t* st_pidx = reinterpret_cast<int32_t*>(p); p += (c.np_max + 1) / 2;
-        int32_t* st_sidx = reinterpret_cast<int32_t*>(p);                        // ns_max * 4 ints
-        L.r_idx = st_ridx; L.p_idx = st_pidx; L.s_idx = st_sidx; L.r_val = st_rval; L.p_val = st_pval; L.s_val = st_sval;
-        for (int i = lane; i < nr * 2; i += 64) st_ridx[i] = a.r_idx[(size_t)inst * c.nr_max * 2 + i];
+        double* st_sval = p;
+        L.r_val = st_rval; L.p_val = st_pval; L.s_val = st_sval;
         for (int i = lane; i < nr * 5; i += 64) st_rval[i] = a.r_val[(size_t)inst * c.nr_max * 5 + i];
-        for (int i = lane; i < np; i += 64) st_pidx[i] = a.p_idx[(size_t)inst * c.np_max + i];
         for (int i = lane; i < np * 18; i += 64) st_pval[i] = a.p_val[(size_t)inst * c.np_max * 18 + i];
-        for (int i = lane; i < ns * 4; i += 64) st_sidx[i] = a.s_idx[(size_t)inst * c.ns_max * 4 + i];
         for (int i = lane; i < ns * 48; i += 64) st_sval[i] = a.s_val[(size_t)inst * c.ns_max * 48 + i];
     }
     __syncthreads();
-    compute_skyline(L, lane, n, nr, np, ns);
+    const double* gpose_in = a.poses_in + (size_t)inst * c.nv_max * 12;
+    double* gpose = a.poses + (size_t)inst * c.nv_max * 12;
+    if (SP) {
+        const int nb_max = (int)(nnz_max / 36);
+        int nb = compute_sparse(L, lane, nv, c.nv_max, nb_max, nr, ns, a.natural_order != 0);
+        if (nb > nb_max) { __syncthreads(); nb = compute_sparse(L, lane, nv, c.nv_max, nb_max, nr, ns, true); }  // (the natural order cannot exceed the envelope capacity)
+        // relabel: pose slots -> elimination positions
+        for (int e = lane; e < nr; e += 64) {
+            L.r_idx[2 * e] = L.perm[L.r_idx[2 * e]];
+            const int v1 = L.r_idx[2 * e + 1];
+            if (v1 >= 0) L.r_idx[2 * e + 1] = L.perm[v1];
+        }
+        for (int e = lane; e < np; e += 64) L.p_idx[e] = L.perm[L.p_idx[e]];
+        for (int e = lane; e < ns; e += 64) { L.s_idx[4 * e] = L.perm[L.s_idx[4 * e]]; L.s_idx[4 * e + 1] = L.perm[L.s_idx[4 * e + 1]]; }
+        for (int i = lane; i < nv * 12; i += 64) L.pose[L.perm[i / 12] * 12 + i % 12] = gpose_in[i];
+    } else {
+        compute_skyline(L, lane, nv, nr, ns);
+        for (int i = lane; i < nv * 12; i += 64) L.pose[i] = gpose_in[i];
+    }
+    __syncthreads();
+    compute_incidence<SP>(L, lane, nv, nr, np, ns, reinterpret_cast<int*>(L.x));
 
     constexpr double tau = 1e-5, good_lo = 1.0 / 3.0, good_hi = 2.0 / 3.0;
     constexpr int max_trials = 10;
     double lambda = 0.0, ni = 2.0, cur_chi = 0.0, last_plain = 0.0;
-#ifdef LOCAMD_WINDOW_TIMING  // diagnostic build only: phase cycle counts into result[6], result[7]
-    long long t_fs = 0, t_ev = 0, t_bd = 0, tt0 = 0; const long long t_start = clock64();
-#define LOCAMD_T0() tt0 = clock64()
-#define LOCAMD_T1(acc) acc += clock64() - tt0
-#else
-#define LOCAMD_T0()
-#define LOCAMD_T1(acc)
+#ifdef LOCAMD_WINDOW_TIMING
+    if (lane == 0) L.tim[0] += clock64() - t_start;
 #endif
     int it = 0, trials = 0, terminated = 0;
     const bool empty = (nv <= 0) || (nr + np + ns <= 0);
 
+    for (int i = lane; i < n; i += 64) L.x[i] = 0.0;  // the solver's x of a fresh optimize() call
+    __syncthreads();
     bool ok = !empty;
     for (it = 0; it < a.iterations && ok; ++it) {
         double plain;
-        LOCAMD_T0();
-        evaluate_edges<true>(a, L, inst, lane, nr, np, ns, cur_chi, plain);  // computeActiveErrors + linearize
-        last_plain = plain;
-        __syncthreads();
-        build_system(L, lane, n, nr, ns);
-        LOCAMD_T1(t_bd);
+        {
+            LOCAMD_TIC();
+            evaluate_edges<true, JAC>(a, L, inst, lane, nr, np, ns, cur_chi, plain);  // computeActiveErrors + linearize
+            last_plain = plain;
+            __syncthreads();
+            LOCAMD_TOC(1);
+        }
+        {
+            LOCAMD_TIC();
+            build_system<SP>(L, lane, n, nr, ns);
+            LOCAMD_TOC(2);
+        }
         if (it == 0) {  // computeLambdaInit
             double md = 0.0;
-            for (int j = lane; j < n; j += 64) md = fmax(md, fabs(L.Hs[sky(L, j, j)]));
+            for (int j = lane; j < n; j += 64) md = fmax(md, fabs(L.Hs[sky<SP>(L, j, j)]));
             lambda = tau * wave_max(md);
             ni = 2.0;
         }
@@ -798,10 +1246,18 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
         int q = 0;
         do {
             for (int i = lane; i < nv * 12; i += 64) L.bak[i] = L.pose[i];  // push
-            LOCAMD_T0();
-            const bool ok2 = factor_and_solve(L, lane, n, lambda);
-            LOCAMD_T1(t_fs);
-            if (!ok2) { for (int i = lane; i < n; i += 64) L.x[i] = 0.0; __syncthreads(); }
+#ifdef LOCAMD_WINDOW_TIMING
+            const long long locamd_tf = clock64();
+#endif
+            const bool ok2 = SP ? factor_and_solve_sparse(L, lane, lambda) : factor_and_solve(L, lane, n, lambda);
+#ifdef LOCAMD_WINDOW_TIMING
+            if (!SP && lane == 0) L.tim[3] += clock64() - locamd_tf;  // SKYLINE: the whole sweep incl. back-substitution (slot 5)
+#endif
+            LOCAMD_TIC();
+            // A failed Cholesky (H + lambda I not positive definite): g2o's solver returns false WITHOUT touching x, and LM
+            // applies that stale x all the same (zero at the first solve of an optimize() call: x is cleared when the solve starts), scores
+            // the trial tempChi = max double and pops the step.  Mirrored as is: L.x is only written by a successful
+            // back-substitution.
             // update: X <- X * fromVectorMQT(dx), one pose per lane
             for (int v = lane; v < nv; v += 64) {
                 const double* dx = L.x + v * 6;
@@ -820,16 +1276,15 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
             __syncthreads();
             ++trials;
             double temp_chi, plain2;
-            LOCAMD_T0();
-            evaluate_edges<false>(a, L, inst, lane, nr, np, ns, temp_chi, plain2);
-            LOCAMD_T1(t_ev);
+            evaluate_edges<false, JAC>(a, L, inst, lane, nr, np, ns, temp_chi, plain2);
+            LOCAMD_TOC(6);
             last_plain = plain2;
             if (!ok2) temp_chi = DBL_MAX;
             double sc = 0.0;
             for (int j = lane; j < n; j += 64) sc += L.x[j] * (lambda * L.x[j] + L.b[j]);  // computeScale
             const double scale = wave_sum(sc) + 1e-3;
             rho = (cur_chi - temp_chi) / scale;
-            if (rho > 0.0 && fabs(temp_chi) < DBL_MAX && ok2) {
+            if (rho > 0.0 && fabs(temp_chi) <= DBL_MAX) {  // g2o: rho > 0 && isfinite(tempChi)
                 const double r21 = 2.0 * rho - 1.0;
                 double alpha = 1.0 - r21 * r21 * r21;
                 alpha = fmin(alpha, good_hi);
@@ -848,14 +1303,15 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
         if (q == max_trials || rho == 0.0) { ok = false; terminated = 1; }
     }
 
-    for (int i = lane; i < nv * 12; i += 64) gpose[i] = L.pose[i];
+    if (SP) { for (int i = lane; i < nv * 12; i += 64) gpose[i] = L.pose[L.perm[i / 12] * 12 + i % 12]; }
+    else { for (int i = lane; i < nv * 12; i += 64) gpose[i] = L.pose[i]; }
     if (lane == 0) {
         double* res = a.result + (size_t)inst * 8;
         res[0] = last_plain; res[1] = cur_chi; res[2] = lambda; res[3] = (double)it; res[4] = (double)trials;
-        res[5] = (double)terminated; res[6] = (double)L.shared[0]; res[7] = 0.0;
+        res[5] = (double)terminated; res[6] = (double)L.shared[0]; res[7] = SP ? (double)(L.nlev * 65536 + L.boff[nv] / 36) : 0.0;
 #ifdef LOCAMD_WINDOW_TIMING
-        res[6] = (double)t_fs * 1e6 + (double)t_ev * 1e-3; res[7] = (double)t_bd * 1e6 + (double)(clock64() - t_start) * 1e-3;
-        res[0] = (double)L.tim[0]; res[1] = (double)L.tim[1]; res[2] = (double)L.tim[2]; res[5] = (double)L.tim[3];
+        L.tim[7] = clock64() - t_start;
+        for (int i = 0; i < 8; ++i) res[i] = (double)L.tim[i];
 #endif
     }
 }
@@ -863,22 +1319,28 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
 }  // namespace
 
 size_t window_lds_bytes(const WindowCaps& c, bool global_a) {
-    if (global_a) return (4 * (size_t)c.nv_max + 4) * sizeof(int);  // fb, last, boff, ioff (+ the static 6x6 exchange block)
-    const size_t tables = (size_t)c.nr_max * 6 + (size_t)c.np_max * 18 + (c.np_max + 1) / 2 + (size_t)c.ns_max * 50;
-    return (window_instance_doubles(c) + tables) * sizeof(double);
+    // (+ the static 6x6 exchange block)
+    if (global_a) return window_table_bytes(c);
+    const size_t staged = (size_t)c.nr_max * 5 + (size_t)c.np_max * 18 + (size_t)c.ns_max * 48;
+    return (window_instance_doubles(c) + (window_table_bytes(c) + 7) / 8 + staged) * sizeof(double);
 }
 size_t window_workspace_doubles(const WindowCaps& c) { return window_instance_doubles(c); }
 
-template <bool GLOBAL_A>
+template <bool GLOBAL_A, int JAC, bool SP>
 static hipError_t launch_window_t(const WindowArgs& a, size_t lds, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&window_lm_kernel<GLOBAL_A>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);  // 288 B of static LDS on top
+    // the opt-in to more than 64 KiB of dynamic LDS is per device (and per kernel instantiation)
+    static std::atomic<uint64_t> attr_set{0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(attr_set.load(std::memory_order_acquire) & bit)) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&window_lm_kernel<GLOBAL_A, JAC, SP>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);  // 288 B of static LDS on top
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL((window_lm_kernel<GLOBAL_A>), dim3((unsigned)a.B), dim3(64), lds, stream, a);
+    hipLaunchKernelGGL((window_lm_kernel<GLOBAL_A, JAC, SP>), dim3((unsigned)a.B), dim3(64), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -887,7 +1349,18 @@ hipError_t launch_window(const WindowArgs& a, hipStream_t stream) {
     const bool global_a = a.workspace != nullptr;
     const size_t lds = window_lds_bytes(a.caps, global_a);
     if (lds > 160 * 1024 - 512) return hipErrorInvalidValue;
-    return global_a ? launch_window_t<true>(a, lds, stream) : launch_window_t<false>(a, lds, stream);
+    const bool sp = window_sparse_path(a.caps);
+    const int sel = (global_a ? 4 : 0) | (a.jacobian ? 2 : 0) | (sp ? 1 : 0);
+    switch (sel) {
+        case 0: return launch_window_t<false, 0, false>(a, lds, stream);
+        case 1: return launch_window_t<false, 0, true>(a, lds, stream);
+        case 2: return launch_window_t<false, 1, false>(a, lds, stream);
+        case 3: return launch_window_t<false, 1, true>(a, lds, stream);
+        case 4: return launch_window_t<true, 0, false>(a, lds, stream);
+        case 5: return launch_window_t<true, 0, true>(a, lds, stream);
+        case 6: return launch_window_t<true, 1, false>(a, lds, stream);
+        default: return launch_window_t<true, 1, true>(a, lds, stream);
+    }
 }
 
 }  // namespace locamd

@@ -10,7 +10,7 @@ from .snapshot import pack_ranges
 
 class FusionParams(C.Structure):
     _fields_ = [("maximum_iteration", C.c_int32), ("distance_outlier", C.c_double), ("gate_warmup_epochs", C.c_int32),
-                ("antenna_offset", C.c_double * 3), ("block_threads", C.c_int32)]
+                ("antenna_offset", C.c_double * 3), ("block_threads", C.c_int32), ("jacobian", C.c_int32)]
 
 
 def _bind(L):
@@ -32,7 +32,7 @@ class FusionSolver:
     """B tags, each a 6-DoF pose: M <= 8 anchor ranges with an antenna lever arm + an IMU rotation prior per epoch."""
 
     def __init__(self, anchors, batch, antenna_offset=(0.0, 0.0, 0.0), maximum_iteration=10, distance_outlier=3.0,
-                 gate_warmup_epochs=1, block_threads=0, device=0):
+                 gate_warmup_epochs=1, block_threads=0, device=0, jacobian="analytic"):
         L = lib(); _bind(L)
         if L.loc_device_count() <= 0:
             raise _lib.LocalizationAmdError(_lib.LOC_ERR_NO_DEVICE, "no HIP device visible: localization_amd has no CPU fallback")
@@ -42,6 +42,7 @@ class FusionSolver:
         L.loc_fusion_default_params(C.byref(prm))
         prm.maximum_iteration = int(maximum_iteration); prm.distance_outlier = float(distance_outlier)
         prm.gate_warmup_epochs = int(gate_warmup_epochs); prm.block_threads = int(block_threads)
+        prm.jacobian = _lib.JAC_NUMERIC_G2O if jacobian in ("numeric", _lib.JAC_NUMERIC_G2O) else _lib.JAC_ANALYTIC
         prm.antenna_offset[0], prm.antenna_offset[1], prm.antenna_offset[2] = [float(v) for v in antenna_offset]
         h = C.c_void_p()
         check(L.loc_fusion_create(C.byref(h), self.device, self.B, self.M, anchors.ctypes.data_as(C.POINTER(C.c_double)), C.byref(prm)))

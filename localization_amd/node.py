@@ -11,7 +11,8 @@ class NodeConfig(C.Structure):
     _fields_ = [("trajectory_length", C.c_int32), ("maximum_velocity", C.c_double), ("distance_outlier", C.c_double),
                 ("maximum_iteration", C.c_int32), ("minimum_optimize_error", C.c_double),
                 ("publish_range", C.c_int32), ("publish_pose", C.c_int32), ("publish_twist", C.c_int32),
-                ("publish_lidar", C.c_int32), ("publish_imu", C.c_int32), ("has_relative_range", C.c_int32)]
+                ("publish_lidar", C.c_int32), ("publish_imu", C.c_int32), ("has_relative_range", C.c_int32), ("jacobian", C.c_int32),
+                ("publish_relative_range", C.c_int32)]
 
 
 class NodeOutput(C.Structure):
@@ -33,12 +34,14 @@ def _bind(L):
     L.loc_node_add_pose.argtypes = [vp, C.c_double, dp, dp, C.c_char_p, po]
     L.loc_node_add_twist.argtypes = [vp, C.c_double, dp, dp, C.c_char_p, po]
     L.loc_node_add_lidar.argtypes = [vp, C.c_double, C.c_double, C.c_char_p, po]
+    L.loc_node_add_rl_range.argtypes = [vp, C.c_int32, C.c_int32, C.c_double, C.c_double, dp, po]
     L.loc_node_solve.argtypes = [vp, po]
     L.loc_node_get_path.argtypes = [vp, C.c_int32, dp, C.c_int32]
     L.loc_node_number_measurements.argtypes = [vp]; L.loc_node_number_measurements.restype = C.c_int32
     L.loc_node_set_deferred.argtypes = [vp, C.c_int32]
     L.loc_node_solve_pending.argtypes = [vp]; L.loc_node_solve_pending.restype = C.c_int32
     L.loc_nodes_solve_batch.argtypes = [C.POINTER(vp), C.c_int32, po]
+    L.loc_nodes_release_batch_cache.argtypes = []
     L._node_bound = True
 
 
@@ -58,12 +61,14 @@ class LocalizationNode:
     def __init__(self, nodes_id, nodes_pos, trajectory_length, maximum_velocity=1.0, distance_outlier=1.0,
                  maximum_iteration=20, minimum_optimize_error=1000.0, publish_range=False, publish_pose=False,
                  publish_twist=False, publish_lidar=False, publish_imu=False, has_relative_range=False,
-                 antenna_offsets=None, device=0):
+                 antenna_offsets=None, device=0, jacobian="analytic", publish_relative_range=False):
         L = lib(); _bind(L)
         self.L = L
         cfg = NodeConfig(int(trajectory_length), float(maximum_velocity), float(distance_outlier), int(maximum_iteration),
                          float(minimum_optimize_error), int(publish_range), int(publish_pose), int(publish_twist),
-                         int(publish_lidar), int(publish_imu), int(has_relative_range))
+                         int(publish_lidar), int(publish_imu), int(has_relative_range),
+                         _lib.JAC_NUMERIC_G2O if jacobian in ("numeric", _lib.JAC_NUMERIC_G2O) else _lib.JAC_ANALYTIC,
+                         int(publish_relative_range))
         ids = (C.c_int32 * len(nodes_id))(*[int(i) for i in nodes_id])
         pos = np.ascontiguousarray(nodes_pos, dtype=np.float64).reshape(-1)
         assert pos.size == 3 * len(nodes_id)
@@ -119,6 +124,11 @@ class LocalizationNode:
         p = np.ascontiguousarray(twist6, dtype=np.float64); c = np.ascontiguousarray(cov36, dtype=np.float64).reshape(-1)
         return self._ret(self.L.loc_node_add_twist(self.h, float(stamp), _dp(p), _dp(c), frame_id.encode(), C.byref(o)), o)
 
+    def add_rl_range(self, requester_id, responder_id, stamp, distance, requester_velocity):
+        o = NodeOutput()
+        v = np.ascontiguousarray(requester_velocity, dtype=np.float64)
+        return self._ret(self.L.loc_node_add_rl_range(self.h, int(requester_id), int(responder_id), float(stamp), float(distance), _dp(v), C.byref(o)), o)
+
     def add_lidar(self, stamp, z, frame_id="lidar"):
         o = NodeOutput()
         return self._ret(self.L.loc_node_add_lidar(self.h, float(stamp), float(z), frame_id.encode(), C.byref(o)), o)
@@ -144,6 +154,12 @@ class LocalizationNode:
     @property
     def number_measurements(self):
         return self.L.loc_node_number_measurements(self.h)
+
+
+def release_batch_cache():
+    """Free the batch solvers loc_nodes_solve_batch keeps cached for this thread."""
+    L = lib(); _bind(L)
+    check(L.loc_nodes_release_batch_cache())
 
 
 def solve_batch(nodes):

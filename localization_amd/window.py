@@ -70,7 +70,8 @@ class WindowBatch:
 
 
 class WindowSolver:
-    def __init__(self, anchors, batch, nv_max, nr_max, np_max=0, ns_max=0, maximum_iteration=10, device=0, bw_max=-1):
+    def __init__(self, anchors, batch, nv_max, nr_max, np_max=0, ns_max=0, maximum_iteration=10, device=0, bw_max=-1,
+                 jacobian="analytic", natural_order=False):
         L = lib()
         if L.loc_device_count() <= 0:
             raise _lib.LocalizationAmdError(_lib.LOC_ERR_NO_DEVICE, "no HIP device visible: localization_amd has no CPU fallback")
@@ -82,6 +83,8 @@ class WindowSolver:
         self.h, self.L, self.B = h, L, int(batch)
         self.caps = (nv_max, nr_max, np_max, ns_max)
         self.lds_bytes = L.loc_window_lds_bytes(C.byref(caps))
+        check(L.loc_window_set_jacobian(h, _lib.JAC_NUMERIC_G2O if jacobian in ("numeric", _lib.JAC_NUMERIC_G2O) else _lib.JAC_ANALYTIC))
+        check(L.loc_window_set_ordering(h, int(bool(natural_order))))
 
     def close(self):
         if getattr(self, "h", None):
@@ -105,6 +108,32 @@ class WindowSolver:
                                            wb.s_idx.ctypes.data_as(ip), wb.s_val.ctypes.data_as(dp),
                                            wb.result.ctypes.data_as(dp)))
         return wb.result
+
+    # ---- device-resident operation: upload once, solve any number of times from the uploaded estimates, download
+    def upload(self, wb: WindowBatch):
+        assert wb.caps == self.caps and wb.B <= self.B
+        ip, dp = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+        check(self.L.loc_window_upload(self.h, wb.B, wb.counts.ctypes.data_as(ip), wb.poses.ctypes.data_as(dp),
+                                       wb.r_idx.ctypes.data_as(ip), wb.r_val.ctypes.data_as(dp),
+                                       wb.p_idx.ctypes.data_as(ip), wb.p_val.ctypes.data_as(dp),
+                                       wb.s_idx.ctypes.data_as(ip), wb.s_val.ctypes.data_as(dp)))
+        self._resident = wb.B
+
+    def solve_resident(self, stream=None):
+        check(self.L.loc_window_solve_resident(self.h, stream))
+
+    def download(self, wb: WindowBatch):
+        dp = C.POINTER(C.c_double)
+        check(self.L.loc_window_download(self.h, wb.poses.ctypes.data_as(dp), wb.result.ctypes.data_as(dp)))
+        return wb.result
+
+    def timing_begin(self, max_launches):
+        check(self.L.loc_window_timing_begin(self.h, int(max_launches)))
+
+    def timing_end(self):
+        n = C.c_int32(); tot = C.c_double(); avg = C.c_double()
+        check(self.L.loc_window_timing_end(self.h, C.byref(n), C.byref(tot), C.byref(avg)))
+        return n.value, tot.value, avg.value
 
     def last_kernel_ms(self):
         ms = C.c_double()

@@ -211,6 +211,41 @@ int lo_add_range(lo_state* s, int requester_id, int responder_id, double stamp, 
     return 0;
 }
 
+/* Localization::addRLRangeEdge, localization.cpp:378-436 */
+int lo_add_rl_range(lo_state* s, int requester_id, int responder_id, double stamp, double d,
+                    const double* v, lo_output* out) {
+    if (out) memset(out, 0, sizeof(*out));
+    robot_t* rq = robot_at(s, requester_id);
+    robot_t* rs = robot_at(s, responder_id);
+    if (!rq || !rs) return -2;
+    header_t h; /* :380-382 */
+    memset(&h, 0, sizeof(h));
+    h.stamp = stamp;
+    snprintf(h.frame_id, FRAME_LEN, "uwb");
+    double dt_requester = stamp - rq->header[rq->index].stamp; /* :384 */
+    double dt_responder = stamp - rs->header[rs->index].stamp; /* :385 */
+    double distance_cov = pow(0.054, 2);                        /* :387 */
+    double cov_requester = pow(s->cfg.maximum_velocity * dt_requester / 3, 2); /* :388 */
+    double cov_responder = pow(s->cfg.maximum_velocity * dt_responder / 3, 2); /* :389 */
+    int vertex_last_requester = robot_last_vertex(rq);
+    int vertex_last_responder = robot_last_vertex(rs);
+    int vertex_requester = robot_new_vertex(s, rq, ST_RANGE, &h); /* :394 */
+    int vertex_responder = robot_new_vertex(s, rs, ST_RANGE, &h); /* :395 */
+    og_add_range_edge(s->g, vertex_requester, vertex_responder, d, 1.0 / distance_cov, NULL, NULL, 1); /* :397-398 */
+    if (!rs->is_static) /* :400-405 */
+        og_add_range_edge(s->g, vertex_last_responder, vertex_responder, 0.0, 1.0 / cov_responder, NULL, NULL, 1);
+    if (!rq->is_static) { /* :408-428: EdgeSE3 from the velocity, information on the translation only, no robust kernel */
+        const double I[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+        double tm[3] = { dt_requester * v[0], dt_requester * v[1], dt_requester * v[2] };
+        double info[36];
+        memset(info, 0, sizeof(info));
+        info[0] = info[7] = info[14] = 1.0 / cov_requester;
+        og_add_se3_edge(s->g, vertex_last_requester, vertex_requester, I, tm, info, 0);
+    }
+    if (s->cfg.publish_relative_range) { solve_and_publish(s, out); return 1; } /* :430-434 */
+    return 0;
+}
+
 /* Localization::addImuEdge, localization.cpp:499-535 */
 int lo_add_imu(lo_state* s, double stamp, const double* q_xyzw, const double* cov9, const char* frame_id, lo_output* out) {
     (void)stamp;

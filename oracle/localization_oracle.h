@@ -23,6 +23,7 @@ typedef struct lo_config {
     int publish_range, publish_pose, publish_twist, publish_lidar, publish_imu; /* :146-158 */
     int has_relative_range;         /* topic/relative_range present => every node moves, :94 */
     int jac_mode;                   /* OG_JAC_NUMERIC_G2O (reference behaviour) or OG_JAC_ANALYTIC */
+    int publish_relative_range;     /* publish_flag/relative_range, :158 */
 } lo_config;
 
 typedef struct lo_output {
@@ -52,6 +53,10 @@ int lo_add_pose(lo_state* s, double stamp, const double* pose_xyz_qxyzw, const d
 int lo_add_twist(lo_state* s, double stamp, const double* twist_lin_ang6, const double* cov36,
                  const char* frame_id, lo_output* out);
 int lo_add_lidar(lo_state* s, double stamp, double z, const char* frame_id, lo_output* out);
+/* Localization::addRLRangeEdge (localization.cpp:378-436; compiled only with -DRELATIVE_LOCALIZATION, CMakeLists.txt:137):
+ * uwb_reloc::uwbTalkData fields time_stamp, rqstrId, rspdrId, d, rqstr_vx/vy/vz */
+int lo_add_rl_range(lo_state* s, int requester_id, int responder_id, double stamp, double d,
+                    const double* requester_velocity_xyz, lo_output* out);
 
 /* Localization::solve() + publish() on demand (localization.cpp:164-251) */
 int lo_solve(lo_state* s, lo_output* out);

@@ -35,7 +35,7 @@ class LoConfig(C.Structure):
                 ("minimum_optimize_error", C.c_double),
                 ("publish_range", C.c_int), ("publish_pose", C.c_int), ("publish_twist", C.c_int),
                 ("publish_lidar", C.c_int), ("publish_imu", C.c_int),
-                ("has_relative_range", C.c_int), ("jac_mode", C.c_int)]
+                ("has_relative_range", C.c_int), ("jac_mode", C.c_int), ("publish_relative_range", C.c_int)]
 
 
 class LoOutput(C.Structure):
@@ -83,6 +83,7 @@ def lib():
         L.lo_add_pose.argtypes = [C.c_void_p, C.c_double, dp, dp, C.c_char_p, C.POINTER(LoOutput)]
         L.lo_add_twist.argtypes = [C.c_void_p, C.c_double, dp, dp, C.c_char_p, C.POINTER(LoOutput)]
         L.lo_add_lidar.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_char_p, C.POINTER(LoOutput)]
+        L.lo_add_rl_range.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, dp, C.POINTER(LoOutput)]
         L.lo_solve.argtypes = [C.c_void_p, C.POINTER(LoOutput)]
         L.lo_get_path.argtypes = [C.c_void_p, C.c_int, dp]
         L.lo_number_measurements.argtypes = [C.c_void_p]
@@ -199,11 +200,11 @@ class LocalizationOracle:
     def __init__(self, nodes_id, nodes_pos, trajectory_length, maximum_velocity=1.0, distance_outlier=1.0,
                  maximum_iteration=20, minimum_optimize_error=1000.0, publish_range=False, publish_pose=False,
                  publish_twist=False, publish_lidar=False, publish_imu=False, has_relative_range=False,
-                 antenna_offsets=None, jac_mode=JAC_NUMERIC_G2O):
+                 antenna_offsets=None, jac_mode=JAC_NUMERIC_G2O, publish_relative_range=False):
         self.L = lib()
         cfg = LoConfig(trajectory_length, maximum_velocity, distance_outlier, maximum_iteration,
                        minimum_optimize_error, int(publish_range), int(publish_pose), int(publish_twist),
-                       int(publish_lidar), int(publish_imu), int(has_relative_range), jac_mode)
+                       int(publish_lidar), int(publish_imu), int(has_relative_range), jac_mode, int(publish_relative_range))
         ids = (C.c_int * len(nodes_id))(*[int(i) for i in nodes_id])
         pos = np.ascontiguousarray(nodes_pos, dtype=np.float64).reshape(-1)
         assert pos.size == 3 * len(nodes_id)
@@ -248,6 +249,12 @@ class LocalizationOracle:
         o = LoOutput()
         p = np.ascontiguousarray(twist6, dtype=np.float64); c = np.ascontiguousarray(cov36, dtype=np.float64).reshape(-1)
         rc = self.L.lo_add_twist(self.h, stamp, _dp(p), _dp(c), frame_id.encode(), C.byref(o))
+        return self._out(o, rc)
+
+    def add_rl_range(self, requester_id, responder_id, stamp, distance, requester_velocity):
+        o = LoOutput()
+        v = np.ascontiguousarray(requester_velocity, dtype=np.float64)
+        rc = self.L.lo_add_rl_range(self.h, requester_id, responder_id, stamp, float(distance), _dp(v), C.byref(o))
         return self._out(o, rc)
 
     def add_lidar(self, stamp, z, frame_id="lidar"):

@@ -61,29 +61,39 @@ def build(B, shape, seed=0):
     return wb, graphs, anchors, T
 
 
-def build_pose64(B, rng, T=64):
+def build_pose64(B, rng, T=64, n_graphs=512):
     """cfg5: per pose one range (round-robin anchor) + one EdgeSE3 from the current key pose (new key
-    every 8 poses), Omega = diag(1e4), Cauchy."""
+    every 8 poses), Omega = diag(1e4), Cauchy.  Vectorised over the batch (the full B = 16 384 builds in seconds); the
+    oracle-side description is kept for the first n_graphs instances."""
     import localization_amd as la
     wb = la.WindowBatch(B, T, T, 0, T)
+    tt = np.cumsum(rng.normal(0, 0.05, (B, T, 3)), axis=1) + np.stack([rng.uniform(-1.5, 1.5, B), rng.uniform(-1.5, 1.5, B), np.full(B, 1.1)], 1)[:, None, :]
+    rv = np.cumsum(rng.normal(0, 0.03, (B, T, 3)), axis=1) + rng.normal(0, 0.3, (B, 1, 3))
+    tR = Rotation.from_rotvec(rv.reshape(-1, 3))
+    et = tt + rng.normal(0, 0.05, (B, T, 3))
+    eR = (tR * Rotation.from_rotvec(rng.normal(0, 0.02, (B * T, 3)))).as_matrix().reshape(B, T, 3, 3)
+    tRm = tR.as_matrix().reshape(B, T, 3, 3)
+    k = np.arange(T)
+    anch = k % 4
+    d = (np.linalg.norm(tt - ANCH4[anch][None], axis=2) + rng.normal(0, 0.03, (B, T))).astype(np.float32).astype(np.float64)
+    key = np.where(k < 8, 0, (k // 8) * 8 - 1)
+    Rk = tRm[:, key]                                                    # [B, T, 3, 3] rotation of each pose's key
+    Zt = np.einsum("btji,btj->bti", Rk, tt - tt[:, key]) + rng.normal(0, 0.01, (B, T, 3))
+    ZR = np.einsum("btji,btjk->btik", Rk, tRm) @ Rotation.from_rotvec(rng.normal(0, 0.01, (B * T, 3))).as_matrix().reshape(B, T, 3, 3)
+    wb.counts[:] = (T, T, 0, T - 1)
+    wb.poses[:, :, :9] = eR.reshape(B, T, 9); wb.poses[:, :, 9:] = et
+    wb.r_idx[:, :, 0] = k[None]; wb.r_idx[:, :, 1] = -1 - anch[None]
+    wb.r_val[:, :, 0] = d; wb.r_val[:, :, 1] = 1 / 0.055 ** 2; wb.r_val[:, :, 2:] = 0.0
+    wb.s_idx[:, : T - 1, 0] = key[1:][None]; wb.s_idx[:, : T - 1, 1] = k[1:][None]; wb.s_idx[:, : T - 1, 2] = 1
+    ZRi = np.swapaxes(ZR[:, 1:], -1, -2)                                # inverse measurement
+    wb.s_val[:, : T - 1, :9] = ZRi.reshape(B, T - 1, 9)
+    wb.s_val[:, : T - 1, 9:12] = -np.einsum("btij,btj->bti", ZRi, Zt[:, 1:])
+    wb.s_val[:, : T - 1, 12:] = (np.eye(6) * 1e4).reshape(36)
     graphs = []
-    info = np.eye(6) * 1e4
-    for i in range(B):
-        tt = np.cumsum(rng.normal(0, 0.05, (T, 3)), axis=0) + np.array([rng.uniform(-1.5, 1.5), rng.uniform(-1.5, 1.5), 1.1])
-        tR = Rotation.from_rotvec(np.cumsum(rng.normal(0, 0.03, (T, 3)), axis=0) + rng.normal(0, 0.3, 3))
-        et = tt + rng.normal(0, 0.05, (T, 3)); eR = (tR * Rotation.from_rotvec(rng.normal(0, 0.02, (T, 3)))).as_matrix()
-        g = dict(et=et, eR=eR, off=np.zeros(3), ranges=[], smooth=[], priors=[], se3=[])
-        for k in range(T):
-            wb.add_pose(i, et[k], eR[k])
-            a = k % 4
-            d = float(np.float32(np.linalg.norm(tt[k] - ANCH4[a]) + rng.normal(0, 0.03)))
-            wb.add_range(i, k, a, d, 1 / 0.055 ** 2, anchor=True); g["ranges"].append((k, a, d))
-            if k:
-                key = 0 if k < 8 else (k // 8) * 8 - 1
-                Zt = tR[key].inv().apply(tt[k] - tt[key]) + rng.normal(0, 0.01, 3)
-                ZR = (tR[key].inv() * tR[k] * Rotation.from_rotvec(rng.normal(0, 0.01, 3))).as_matrix()
-                wb.add_se3(i, key, k, Zt, ZR, info, True); g["se3"].append((key, k, Zt, ZR))
-        graphs.append(g)
+    for i in range(min(B, n_graphs)):
+        graphs.append(dict(et=et[i], eR=eR[i], off=np.zeros(3), smooth=[], priors=[],
+                           ranges=[(int(kk), int(anch[kk]), float(d[i, kk])) for kk in range(T)],
+                           se3=[(int(key[kk]), int(kk), Zt[i, kk], ZR[i, kk]) for kk in range(1, T)]))
     return wb, graphs, ANCH4, T
 
 
@@ -157,9 +167,24 @@ def main():
     ap.add_argument("--cpu-n", type=int, default=256)
     ap.add_argument("--bw", default="auto", help="'auto' = the widest pose-pose coupling in the batch (what the node front-end passes), "
                     "'dense' = nv_max - 1, or a number")
+    ap.add_argument("--jacobian", default="analytic", choices=["analytic", "numeric"])
+    ap.add_argument("--natural", action="store_true", help="windows of <= 64 poses: keep the caller's pose order (no in-kernel minimum-degree ordering)")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-window latency launches (profiling: one kernel shape only)")
+    ap.add_argument("--cache", default=None, help="npz file: load the generated batch from it if it exists, else build and save "
+                    "(profiling runs repeat the same command once per counter pass)")
     a = ap.parse_args()
     import localization_amd as la
-    wb, graphs, anchors, T = build(a.batch, a.shape)
+    names = ("counts", "poses", "r_idx", "r_val", "p_idx", "p_val", "s_idx", "s_val")
+    if a.cache and os.path.exists(a.cache):
+        z = np.load(a.cache)
+        wb = la.WindowBatch(a.batch, *[int(v) for v in z["caps"]])
+        for nm in names: getattr(wb, nm)[:] = z[nm]
+        graphs, anchors, T = [], z["anchors"], int(z["T"])
+        a.cpu_n = 0
+    else:
+        wb, graphs, anchors, T = build(a.batch, a.shape)
+        if a.cache:
+            np.savez(a.cache, caps=np.array(wb.caps), anchors=anchors, T=T, **{nm: getattr(wb, nm) for nm in names})
     if a.bw == "auto":
         bw = 0
         for b in range(a.batch):
@@ -169,7 +194,7 @@ def main():
             if ns: bw = max(bw, int(np.abs(wb.s_idx[b, :ns, 0] - wb.s_idx[b, :ns, 1]).max()))
     else:
         bw = -1 if a.bw == "dense" else int(a.bw)
-    solver = la.WindowSolver(anchors, a.batch, *wb.caps, maximum_iteration=10, bw_max=bw)
+    solver = la.WindowSolver(anchors, a.batch, *wb.caps, maximum_iteration=10, bw_max=bw, jacobian=a.jacobian, natural_order=a.natural)
     poses0 = wb.poses.copy()
     ms = []
     for r in range(a.reps + 1):
@@ -180,20 +205,24 @@ def main():
     one = la.WindowBatch(1, *wb.caps)
     for name in ("counts", "poses", "r_idx", "r_val", "p_idx", "p_val", "s_idx", "s_val"):
         getattr(one, name)[:] = getattr(wb, name)[:1] if name != "poses" else poses0[:1]
-    s1 = la.WindowSolver(anchors, 1, *wb.caps, maximum_iteration=10, bw_max=bw)
-    lat = []
-    for r in range(20):
+    s1 = la.WindowSolver(anchors, 1, *wb.caps, maximum_iteration=10, bw_max=bw, jacobian=a.jacobian, natural_order=a.natural)
+    lat = [float("nan")] if a.no_latency else []
+    for r in range(0 if a.no_latency else 20):
         one.poses[:] = poses0[:1]
         t0 = time.perf_counter(); s1.solve(one); lat.append((time.perf_counter() - t0) * 1e3)
-    cpu_s, cpu_t = oracle_time(graphs, anchors, T, min(a.cpu_n, a.batch))
-    diff = float(np.abs(wb.poses[: len(cpu_t), :, 9:] - cpu_t).max())
+    if a.cpu_n > 0:
+        cpu_s, cpu_t = oracle_time(graphs, anchors, T, min(a.cpu_n, a.batch))
+        diff = float(np.abs(wb.poses[: len(cpu_t), :, 9:] - cpu_t).max())
+    else:
+        cpu_s, cpu_t, diff = float("nan"), [0], None
     print(json.dumps({
         "shape": a.shape, "poses_per_window": T, "unknowns": 6 * T, "batch": a.batch, "bw_max": bw, "lds_bytes_per_instance": solver.lds_bytes,
         "gpu_kernel_ms_per_batch": k_ms, "gpu_windows_per_s_kernel": a.batch / (k_ms * 1e-3),
         "gpu_windows_per_s_incl_pcie": a.batch / (w_ms * 1e-3),
         "gpu_single_window_latency_ms_incl_pcie": float(np.median(lat)), "gpu_single_window_kernel_ms": s1.last_kernel_ms(),
         "cpu_oracle_windows_per_s_1core": len(cpu_t) / cpu_s, "cpu_ms_per_window": cpu_s / len(cpu_t) * 1e3,
-        "mean_lm_trials": float(wb.result[:, 4].mean()),
+        "mean_lm_trials": float(wb.result[:, 4].mean()), "jacobian": a.jacobian, "natural_order": bool(a.natural),
+        "elimination_levels": float(wb.result[0, 7] // 65536), "factor_blocks": float(wb.result[0, 7] % 65536),
         "max_abs_diff_vs_oracle_numeric_m": diff}))
 
 

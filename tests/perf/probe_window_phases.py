@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Diagnostic: cycle shares of the window kernel's phases.  Needs a build with -DLOCAMD_WINDOW_TIMING:
-  hipcc ... -DLOCAMD_WINDOW_TIMING -c window_kernel.hip   (link into a separate .so, pass it as argv[1])
-Never quote this build's run time (the stamps serialise the phases); read the SHARES."""
+"""Diagnostic: cycle shares of the window kernel's phases.  Needs the timing build of the library:
+    make -C localization_amd/csrc timing          (-> localization_amd/liblocalization_amd_timing.so)
+    python tests/perf/probe_window_phases.py SHAPE [BATCH] [--natural]
+Never quote this build's run time (the stamps serialise the phases); read the SHARES.  The result record of this build holds
+the phase counters instead of chi2 etc. (window_kernel.hip, LOCAMD_WINDOW_TIMING)."""
 import os
 import sys
 
@@ -9,24 +11,26 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-so = sys.argv[1]
-shape = sys.argv[2] if len(sys.argv) > 2 else "uwb_only"
+shape = sys.argv[1] if len(sys.argv) > 1 else "uwb_only"
+NB = int(sys.argv[2]) if len(sys.argv) > 2 and not sys.argv[2].startswith("-") else 64   # 64 = unloaded GPU, thousands = under load
+natural = "--natural" in sys.argv
 import localization_amd._lib as _lib
-_lib._SO = os.path.abspath(so)
+_lib._SO = os.path.join(ROOT, "localization_amd", "liblocalization_amd_timing.so")
 import localization_amd as la
 sys.path.insert(0, os.path.join(ROOT, "tests", "perf"))
 import bench_window as bw
-NB = int(sys.argv[4]) if len(sys.argv) > 4 else 64   # instances (argv[4]): 64 = unloaded GPU, thousands = under load
 wb, graphs, anchors, T = bw.build(NB, shape)
-bwm = int(sys.argv[3]) if len(sys.argv) > 3 else -1   # pose band (argv[3]); -1 = dense
-s = la.WindowSolver(anchors, NB, *wb.caps, maximum_iteration=10, bw_max=bwm)
+bwm = 0
+for b in range(min(NB, 64)):
+    nr, ns = int(wb.counts[b, 1]), int(wb.counts[b, 3])
+    r = wb.r_idx[b, :nr]; pp = r[r[:, 1] >= 0]
+    if len(pp): bwm = max(bwm, int(np.abs(pp[:, 0] - pp[:, 1]).max()))
+    if ns: bwm = max(bwm, int(np.abs(wb.s_idx[b, :ns, 0] - wb.s_idx[b, :ns, 1]).max()))
+s = la.WindowSolver(anchors, NB, *wb.caps, maximum_iteration=10, bw_max=bwm, natural_order=natural)
 s.solve(wb)
-r = wb.result
-fs = np.floor(r[:, 6] / 1e6); ev = (r[:, 6] - fs * 1e6) * 1e3
-bd = np.floor(r[:, 7] / 1e6); tot = (r[:, 7] - bd * 1e6) * 1e3
-print(f"{shape}: trials {r[:, 4].mean():.1f} iters {r[:, 3].mean():.1f}; cycles per solve: total {tot.mean():.0f}; "
-      f"factor+solve {fs.mean():.0f} ({(fs / r[:, 4]).mean():.0f}/trial, {100 * fs.mean() / tot.mean():.0f} %); "
-      f"trial errors {ev.mean():.0f} ({(ev / r[:, 4]).mean():.0f}/trial, {100 * ev.mean() / tot.mean():.0f} %); "
-      f"linearise+build {bd.mean():.0f} ({(bd / r[:, 3]).mean():.0f}/iteration, {100 * bd.mean() / tot.mean():.0f} %)")
-print(f"  inside factor+solve (cycles per solve): (a) band segments {r[:, 0].mean():.0f}, (b) block exchange + 6x6 factor {r[:, 1].mean():.0f}, "
-      f"(c) row finish {r[:, 2].mean():.0f}, back-substitution {r[:, 5].mean():.0f}")
+r = wb.result.mean(axis=0)
+names = ["set-up (ordering, structure, incidence)", "linearise", "build H, b", "factor phase 1 (SKYLINE: whole sweep)", "factor phase 2",
+         "back-substitution", "update + trial evaluation", "TOTAL"]
+print(f"{shape} x {NB}{' natural order' if natural else ''}: cycles per solve (lane-0 stamps)")
+for i, nm in enumerate(names):
+    print(f"  {nm:45s} {r[i]:12.0f}  {100 * r[i] / r[7]:5.1f} %")

@@ -49,14 +49,132 @@ def _rmse(bag, traj):
     return np.sqrt(((traj[:, 1:4] - v) ** 2).mean(axis=0))
 
 
-def _pair(bag, cfg, antenna=None):
+def _pair(bag, cfg, antenna=None, jac="analytic"):
     import localization_amd as la
     from oracle import oracle as O
     ids = list(bag["anchor_ids"]) + [200]
     pos = np.concatenate([bag["anchor_pos"], [[0.0, 0.0, 1.0]]])
-    node = la.LocalizationNode(ids, pos, antenna_offsets=antenna, **cfg)
-    ora = O.LocalizationOracle(ids, pos, antenna_offsets=antenna, jac_mode=O.JAC_ANALYTIC, **cfg)
+    node = la.LocalizationNode(ids, pos, antenna_offsets=antenna, jacobian=jac, **cfg)
+    ora = O.LocalizationOracle(ids, pos, antenna_offsets=antenna, jac_mode=O.JAC_ANALYTIC if jac == "analytic" else O.JAC_NUMERIC_G2O, **cfg)
     return node, ora
+
+
+def test_bag_uwb_only_reference_configuration_numeric_jacobians(gpu, bag):
+    """BASELINE config 1 in the REFERENCE's configuration: EdgeSE3Range has no linearizeOplus (types_edge_se3range.h:45-74),
+    so g2o differentiates numerically (delta = 1e-9) — node kernel in LOC_JAC_NUMERIC_G2O against the oracle front-end in
+    JAC_NUMERIC_G2O, cfg/uwb_only.yaml parameters, the whole bag.  Numeric-vs-numeric bound 1e-5 m on the first 60 solves
+    (before any drift), identical publish decisions throughout, ATE difference <= 1 mm."""
+    cfg = dict(trajectory_length=10, maximum_velocity=5.0, distance_outlier=1.0, maximum_iteration=10,
+               minimum_optimize_error=2000.0, publish_range=True)
+    node, ora = _pair(bag, cfg, jac="numeric")
+    ev = _events(bag, False)
+    g, gp, gc = _replay(bag, node, ev)
+    o, op, oc = _replay(bag, ora, ev)
+    assert len(g) == len(o) and np.array_equal(gp, op)
+    assert np.abs(g[:60, 1:4] - o[:60, 1:4]).max() < 1e-5, np.abs(g[:60, 1:4] - o[:60, 1:4]).max()
+    d = np.abs(g[:, 1:4] - o[:, 1:4]).max(axis=1)
+    assert np.median(d) < 1e-4, (np.median(d), d.max())
+    from localization_amd import ate
+    truth = np.column_stack([bag["vicon_stamp"], bag["vicon_pos"], bag["vicon_q_xyzw"]])
+    ra, rb = ate.evaluate_ate(g[gp], truth), ate.evaluate_ate(o[op], truth)
+    assert ra["pairs"] == rb["pairs"] and abs(ra["rmse"] - rb["rmse"]) < 1e-3, (ra, rb)
+    assert np.abs(_rmse(bag, g[gp]) - _rmse(bag, o[op])).max() < 1e-3
+    node.close()
+
+
+def test_bag_uwb_imu_reference_configuration_numeric_jacobians(gpu, bag):
+    """cfg/uwb_imu.yaml in the reference's configuration (numeric range Jacobians, lever arm, IMU priors), 400 ranges."""
+    cfg = dict(trajectory_length=12, maximum_velocity=3.0, distance_outlier=3.0, maximum_iteration=10,
+               minimum_optimize_error=1000.0, publish_range=True, publish_imu=False)
+    ant = [[0.05, 0.0, -0.02]] * 3
+    node, ora = _pair(bag, cfg, ant, jac="numeric")
+    ev = _events(bag, True, 400)
+    g, gp, gc = _replay(bag, node, ev)
+    o, op, oc = _replay(bag, ora, ev)
+    assert len(g) == len(o) and np.array_equal(gp, op)
+    d = np.abs(g[:, 1:8] - o[:, 1:8]).max(axis=1)
+    assert d[:40].max() < 1e-5 and np.median(d) < 1e-4, (d[:40].max(), np.median(d))
+    assert np.abs(_rmse(bag, g[gp]) - _rmse(bag, o[op])).max() < 1e-3
+    node.close()
+
+
+def test_uwb_imu_lidar_two_priors_per_vertex_T20(gpu, bag):
+    """cfg/uwb_imu_lidar.yaml's shape: trajectory_length 20 with an IMU prior AND a lidar prior on every vertex (frame_id
+    gating admits one of each, localization.cpp:470,501) — up to 2 T priors in the window; and a pose-vertex stream where
+    several ranges pile onto one vertex (the else-branch, localization.cpp:348).  The node has no edge-count limits."""
+    cfg = dict(trajectory_length=20, maximum_velocity=3.0, distance_outlier=3.0, maximum_iteration=10,
+               minimum_optimize_error=1e9, publish_range=True)
+    node, ora = _pair(bag, cfg)
+    n = 120
+    worst, solves = 0.0, 0
+    for i in range(n):
+        for obj in (node, ora):
+            obj.add_imu(float(bag["uwb_stamp"][i]) - 1e-3, bag["imu_q_xyzw"][3 * i], np.diag(bag["imu_orientation_cov_diag"][3 * i]).ravel(), "imu_link")
+            obj.add_lidar(float(bag["uwb_stamp"][i]) - 5e-4, 1.0 + 0.001 * i, "lidar")
+        outs = [obj.add_range(200, int(bag["uwb_responder"][i]), float(bag["uwb_stamp"][i]), bag["uwb_distance"][i],
+                              bag["uwb_distance_err"][i], 0, "uwb") for obj in (node, ora)]
+        assert outs[0]["solved"] == outs[1]["solved"]
+        if outs[0]["solved"]:
+            solves += 1
+            worst = max(worst, np.abs(outs[0]["realtime"][1:] - outs[1]["realtime"][1:]).max())
+    assert solves >= 90 and worst < 1e-5, (solves, worst)
+    node.close()
+    # several ranges per pose vertex
+    import localization_amd as la
+    from oracle import oracle as O
+    ids = list(bag["anchor_ids"]) + [200]
+    pos = np.concatenate([bag["anchor_pos"], [[0.0, 0.0, 1.0]]])
+    cfg = dict(trajectory_length=18, maximum_velocity=2.0, distance_outlier=5.0, maximum_iteration=10,
+               minimum_optimize_error=1e9, publish_range=True, publish_pose=False)
+    node = la.LocalizationNode(ids, pos, **cfg)
+    ora = O.LocalizationOracle(ids, pos, jac_mode=O.JAC_ANALYTIC, **cfg)
+    t, worst, solves = 50.0, 0.0, 0
+    cov = (np.eye(6) * 1e-3).ravel()
+    for step in range(40):
+        t += 0.1
+        pose = np.array([0.01 * (step % 5 + 1), 0.0, 0.0, 0.0, 0.0, 0.0, 1.0])
+        for obj in (node, ora):
+            assert obj.add_pose(t, pose, cov, f"key_{step // 5}")["rc"] == 0
+        for j in range(5):      # five ranges onto the same pose vertex
+            i = (5 * step + j) % 1000
+            outs = [obj.add_range(200, int(bag["uwb_responder"][i]), t + 0.01 * (j + 1), 2.0 + 0.1 * j, 0.055, 0, "uwb") for obj in (node, ora)]
+            assert outs[0]["solved"] == outs[1]["solved"]
+            if outs[0]["solved"]:
+                solves += 1
+                worst = max(worst, np.abs(outs[0]["realtime"][1:4] - outs[1]["realtime"][1:4]).max())
+    assert solves > 100 and worst < 1e-5, (solves, worst)
+    node.close()
+
+
+def test_heterogeneous_fleet_and_failed_call_leaves_node_untouched(gpu, bag):
+    """loc_nodes_solve_batch groups pending nodes by (device, maximum_iteration, jacobian): every node is solved with ITS
+    parameters (one launch per group); loc_node_add_range validates before it mutates."""
+    import localization_amd as la
+    ids = list(bag["anchor_ids"]) + [200]
+    pos = np.concatenate([bag["anchor_pos"], [[0.0, 0.0, 1.0]]])
+    base = dict(trajectory_length=6, maximum_velocity=5.0, distance_outlier=1.0, minimum_optimize_error=2000.0, publish_range=True)
+    variants = [dict(maximum_iteration=3), dict(maximum_iteration=10), dict(maximum_iteration=10, jacobian="numeric"), dict(maximum_iteration=3)]
+    solo = [la.LocalizationNode(ids, pos, **base, **v) for v in variants]
+    fleet = [la.LocalizationNode(ids, pos, **base, **v) for v in variants]
+    for n in fleet: n.set_deferred(True)
+    for i in range(30):
+        args = (200, int(bag["uwb_responder"][i]), float(bag["uwb_stamp"][i]), float(bag["uwb_distance"][i]), float(bag["uwb_distance_err"][i]), 1, "uwb")
+        outs_solo = [n.add_range(*args) for n in solo]
+        for n in fleet: n.add_range(*args)
+        n_solved, outs = la.solve_batch(fleet)
+        assert n_solved == sum(o["solved"] for o in outs_solo)
+        for k in range(len(fleet)):
+            if outs_solo[k]["solved"]:
+                assert outs[k]["outer_iterations"] == outs_solo[k]["outer_iterations"] == variants[k]["maximum_iteration"]
+                assert np.array_equal(outs[k]["realtime"], outs_solo[k]["realtime"]) and outs[k]["chi2"] == outs_solo[k]["chi2"]
+    la.release_batch_cache()
+    # an invalid antenna index is refused before anything changes
+    node = solo[1]
+    before = (node.number_measurements, node.path(200).copy())
+    with pytest.raises(la.LocalizationAmdError):
+        node.add_range(200, int(bag["uwb_responder"][0]), 99.0, 3.0, 0.055, 7, "uwb")
+    assert node.number_measurements == before[0] and np.array_equal(node.path(200), before[1])
+    for n in solo + fleet: n.close()
 
 
 def test_bag_uwb_only_first_solves_match_tightly(gpu, bag):
@@ -241,6 +359,41 @@ def test_relative_range_mode_moving_responders(gpu):
             for nid in ids:
                 assert np.abs(node.path(nid)[:, 1:4] - ora.path(nid)[:, 1:4]).max() < 1e-6
     assert solved > 30 and worst < 1e-6, (solved, worst)
+    node.close()
+
+
+def test_rl_range_edges_match_oracle(gpu):
+    """Localization::addRLRangeEdge (localization.cpp:378-436; the reference builds it only with -DRELATIVE_LOCALIZATION):
+    peer ranges with the fixed sigma_d = 0.054 m, responder smoothness edges, and velocity-integrated EdgeSE3 factors with
+    information diag(1/sigma_v^2 x3, 0 x3) and no robust kernel — cfg/RL_uwb.yaml's profile at test size."""
+    import localization_amd as la
+    from oracle import oracle as O
+    ids = [1, 2, 3, 4]
+    pos = np.array([[2.0, -2.0, 0.5], [2.0, 2.0, 1.5], [-2.0, 0.0, 1.0], [0.2, 0.1, 1.0]])
+    cfg = dict(trajectory_length=5, maximum_velocity=2.0, maximum_iteration=20, minimum_optimize_error=1e9,
+               has_relative_range=True, publish_relative_range=True)
+    node = la.LocalizationNode(ids, pos.ravel(), **cfg)
+    ora = O.LocalizationOracle(ids, pos.ravel(), jac_mode=O.JAC_ANALYTIC, **cfg)
+    rng = np.random.default_rng(8)
+    truth = pos.copy()
+    vel = rng.normal(0, 0.3, (4, 3)); vel[:, 2] *= 0.2
+    worst, solves = 0.0, 0
+    for step in range(48):
+        t = 20.0 + 0.05 * (step + 1)
+        truth = truth + 0.05 * vel
+        a, b = step % 4, (step + 1 + step // 4) % 4
+        if a == b: b = (b + 1) % 4
+        d = np.linalg.norm(truth[a] - truth[b]) + rng.normal(0, 0.02)
+        v_meas = vel[a] + rng.normal(0, 0.02, 3)
+        g = node.add_rl_range(ids[a], ids[b], t, d, v_meas)
+        o = ora.add_rl_range(ids[a], ids[b], t, d, v_meas)
+        assert g["solved"] and o["solved"] and g["outer_iterations"] == o["outer_iterations"]
+        solves += 1
+        worst = max(worst, np.abs(g["realtime"][1:4] - o["realtime"][1:4]).max())
+        for nid in ids:
+            worst = max(worst, np.abs(node.path(nid)[:, 1:4] - ora.path(nid)[:, 1:4]).max())
+        assert abs(g["chi2"] - o["chi2"]) <= 1e-6 * max(1.0, abs(o["chi2"]))
+    assert solves == 48 and worst < 1e-6, worst
     node.close()
 
 
