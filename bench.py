@@ -10,8 +10,15 @@ fresh epochs of one long seeded random-walk stream (no buffer is re-read between
 
 N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL only for the barrier and the
 max-over-ranks of the time: the path has no data-path collective; the batch is sharded by tag, "weak" scaling).
+
+Besides the headline (the top-level keys of the ONE JSON line), the line carries driver-timed secondary legs under
+"legs": cfg2 in the reference's numeric-Jacobian configuration, cfg3 (fusion kernel), cfg5 (64-pose windows) and cfg4
+(anchor self-calibration) — each with its own roofline and, at N = 1, cpu_baseline.  For N > 1 the window legs shard the
+SURVEY §8(e) totals (16 384 windows, 1 024 hypotheses) over the ranks ("strong"), cfg2/cfg3 keep 65 536 tags per GPU.
+--legs none|all|comma list selects them (default all).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -22,8 +29,24 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_UPDATE = 120.0  # 8x4 dist + 8x4 err + 3x8 prior read, 3x8 pos + 8 chi2 written
+ALGO_BYTES_CFG3 = 248.0
+ALGO_BYTES_CFG5 = 7408.0       # SURVEY.md §8(d), cfg5 row (per window)
+ALGO_BYTES_CFG4_PER_IT = 33248.0  # SURVEY.md §8(d), cfg4 row (per hypothesis per LM iteration)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0          # same guide: measured copy ceiling (SURVEY.md §8(d) asks for the fraction of both)
+F64_VECTOR_PEAK_TFLOPS = 78.6  # datasheet fp64 vector peak
+
+
+def kernel_source_hash(names):
+    """sha256 over the kernel sources a PMC summary was measured on: when they change, the committed counters are stale."""
+    h = hashlib.sha256()
+    for n in names:
+        with open(os.path.join(ROOT, "localization_amd", "csrc", n), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+SNAPSHOT_KERNEL_SOURCES = ("snapshot_kernel.hip", "snapshot_kernel.h", "device_math.h")
 
 
 def cpu_baseline(anchors, dist_tiles, err_tiles, init, n_tags, n_epochs, gpu_pos, M):
@@ -86,6 +109,230 @@ def cpu_baseline_all_cores(anchors, dist_tiles, err_tiles, init, tags_per_core, 
                       f"over {used} single-threaded worker processes, same oracle and settings as cpu_baseline"}
 
 
+class Dist:
+    """The rank plumbing every leg shares: barrier + synchronize on both sides of a timed region, max over ranks."""
+
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.backend = args.dist_backend
+        n_dev = torch.cuda.device_count()
+        if self.backend == "gloo":
+            self.local_rank = self.local_rank % max(n_dev, 1)  # rehearsal: ranks may share a device
+        if self.world > 1:
+            import torch.distributed as dist
+            torch.cuda.set_device(self.local_rank)
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            else:
+                dist.init_process_group("gloo")
+        self.dev = torch.device("cuda", self.local_rank)
+        torch.cuda.set_device(self.dev)
+
+    def barrier(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        if self.world == 1:
+            return float(x)
+        import torch.distributed as dist
+        t = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(self, step, warmup, steps):
+        """warmup untimed calls of step(i), then exactly `steps` timed ones; returns the max-over-ranks wall seconds."""
+        for i in range(warmup):
+            step(i)
+        self.barrier()
+        t0 = time.perf_counter()
+        for i in range(warmup, warmup + steps):
+            step(i)
+        self.barrier()
+        return self.max_over_ranks(time.perf_counter() - t0)
+
+    def close(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+
+
+def hbm_roofline(kernel, algo_bytes_per_launch, kern_ms_avg, n_launch, unit_note):
+    ach = algo_bytes_per_launch / (kern_ms_avg * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "frac_of_measured_copy_ceiling": ach / HBM_COPY_GBS, "traffic": None,
+            "algorithmic_bytes_per_launch": algo_bytes_per_launch, "kernel": kernel, "kernel_ms_avg": kern_ms_avg,
+            "launches_timed": n_launch, "note": unit_note}
+
+
+# ---------------------------------------------------------------------------------------------------------------- legs
+def leg_cfg2_numeric(D, args, stream, B, E, M):
+    """cfg2 in the REFERENCE's configuration: g2o's central-difference range Jacobians (types_edge_se3range.h:45-74)."""
+    import localization_amd as la
+    from localization_amd.synthetic import ANCHORS_8
+    torch = D.torch
+    steps, warmup = max(2, min(args.steps, 5)), 1
+    solver = la.SnapshotSolver(ANCHORS_8, B, maximum_iteration=10, distance_outlier=1.0, jacobian="numeric", device=D.local_rank)
+    solver.set_positions(stream["init"])
+    n_ep = stream["dist_tiles"].shape[0]
+    out_pos = torch.empty((E, 3, B), dtype=torch.float64, device=D.dev)
+    out_chi2 = torch.empty((E, B), dtype=torch.float64, device=D.dev)
+
+    def step(i):
+        k = (i * E) % (n_ep - E + 1)
+        solver.solve_device(stream["dist_tiles"][k:k + E], stream["err_tiles"][k:k + E], out_pos, out_chi2, None)
+
+    for i in range(warmup):
+        step(i)
+    D.barrier()
+    solver.timing_begin(steps)
+    t0 = time.perf_counter()
+    for i in range(warmup, warmup + steps):
+        step(i)
+    D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0)
+    n_launch, _, kern_ms = solver.timing_end()
+    solver.close()
+    upd = float(B) * E
+    return {"workload": "BASELINE cfg2 with g2o's numeric range Jacobians (delta = 1e-9): the reference's exact configuration",
+            "metric": "localization updates/sec", "value": upd * steps * D.world / elapsed, "unit": "updates/s", "steps": steps,
+            "ms_per_step": elapsed / steps * 1e3, "scaling": "weak", "dtype": "f64", "batch_per_gpu": B, "epochs_per_step": E,
+            "roofline": hbm_roofline("snapshot_lm_kernel<.., JAC = numeric>", ALGO_BYTES_PER_UPDATE * upd, kern_ms, n_launch,
+                                     "120 B/update; VALU-bound (six extra IEEE square roots per edge)")}
+
+
+def leg_cfg3(D, args):
+    """BASELINE cfg3: 8 anchors + IMU rotation prior + antenna lever arm, 6-DoF, B = 65 536 tags per GPU (fusion kernel)."""
+    import numpy as np
+    import localization_amd as la
+    from localization_amd.synthetic import make_fusion_stream
+    torch = D.torch
+    B, E = args.batch, 64
+    steps, warmup = max(2, min(args.steps, 5)), 1
+    s = make_fusion_stream(B, E, seed=args.seed + 1000 * D.rank)
+    dist = torch.from_numpy(la.pack_ranges(s["dist"])).to(D.dev)
+    err = torch.from_numpy(la.pack_ranges(s["err"])).to(D.dev)
+    imu = torch.from_numpy(s["imu"]).to(D.dev)
+    f = la.FusionSolver(s["anchors"], B, antenna_offset=s["offset"], maximum_iteration=10, distance_outlier=3.0, device=D.local_rank)
+    out_pose = torch.empty((E, 7, B), dtype=torch.float64, device=D.dev)
+    out_chi2 = torch.empty((E, B), dtype=torch.float64, device=D.dev)
+    kms = []
+
+    def step(i):
+        # every step replays the same 64 resident epochs from the same start (the state reset is a 3.7 MB upload)
+        f.set_poses(s["init"])
+        torch.cuda.synchronize()
+        f.solve_device(dist, err, imu, out_pose, out_chi2, None)
+        torch.cuda.synchronize()
+        kms.append(f.last_kernel_ms())
+
+    elapsed = D.timed(step, warmup, steps)
+    kern_ms = float(np.mean(kms[warmup:]))
+    upd = float(B) * E
+    res = {"workload": "BASELINE cfg3: 8 anchors + IMU rotation prior + antenna lever arm, 6-DoF, g2o-style LM, 10 iterations",
+           "metric": "localization updates/sec", "value": upd * D.world / (kern_ms * 1e-3), "unit": "updates/s", "steps": steps,
+           "ms_per_step": elapsed / steps * 1e3, "value_note": "updates / kernel time (HIP events on the launch stream): the step also "
+           "re-uploads the initial poses, which is not part of the hot path", "scaling": "weak", "dtype": "f64", "batch_per_gpu": B,
+           "epochs_per_step": E,
+           "roofline": hbm_roofline("fusion_lm_kernel", ALGO_BYTES_CFG3 * upd, kern_ms, steps, "248 B/update; VALU-issue bound")}
+    if D.rank == 0 and D.world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as O
+        nt, ne = 512, 32
+        t0 = time.perf_counter()
+        rp, _, _, _ = O.fusion_batch(s["anchors"], s["offset"], s["dist"][:ne, :, :nt], s["err"][:ne, :, :nt], s["imu"][:ne, :nt],
+                                     s["init"][:, :nt], iterations=10, gate=3.0, jac_mode=O.JAC_NUMERIC_G2O)
+        dt = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": nt * ne / dt, "unit": "updates/s", "cores": 1, "kind": "port",
+                               "sample": f"first {nt} tags x {ne} epochs ({dt:.1f} s): oracle g2o restatement, numeric Jacobians, 1 thread",
+                               "max_abs_diff_vs_gpu": float(np.abs(out_pose[:ne, :, :nt].cpu().numpy() - rp).max())}
+    f.close()
+    return res
+
+
+def _window_leg(D, args, wb, anchors, bw_max, name, workload, metric, unit, algo_bytes_per_instance, total_instances, oracle_fn, n_cpu,
+                flops_per_instance=None):
+    """Resident window solves: upload once, `steps` launches from the same initial estimates, HIP-event kernel times."""
+    import numpy as np
+    import localization_amd as la
+    steps, warmup = max(2, min(args.steps, 5)), 1
+    B = wb.B
+    poses0 = wb.poses.copy()
+    solver = la.WindowSolver(anchors, B, *wb.caps, maximum_iteration=10, bw_max=bw_max, device=D.local_rank)
+    solver.upload(wb)
+
+    def step(i):
+        solver.solve_resident()
+
+    for i in range(warmup):
+        step(i)
+    D.barrier()
+    solver.timing_begin(steps)
+    t0 = time.perf_counter()
+    for i in range(warmup, warmup + steps):
+        step(i)
+    D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0)
+    n_launch, _, kern_ms = solver.timing_end()
+    solver.download(wb)
+    solver.close()
+    res = {"workload": workload, "metric": metric, "value": float(total_instances) * steps / elapsed, "unit": unit, "steps": steps,
+           "ms_per_step": elapsed / steps * 1e3, "scaling": "strong", "dtype": "f64", "instances_per_gpu": B,
+           "instances_total": int(total_instances), "mean_lm_trials": float(wb.result[:, 4].mean()),
+           "elimination_levels": float(wb.result[0, 7] // 65536), "factor_blocks": float(wb.result[0, 7] % 65536),
+           "roofline": hbm_roofline("window_lm_kernel", algo_bytes_per_instance * B, kern_ms, n_launch, name)}
+    if flops_per_instance:
+        tf = flops_per_instance * B / (kern_ms * 1e-3) / 1e12
+        res["valu_f64"] = {"achieved_tflops": tf, "peak_tflops": F64_VECTOR_PEAK_TFLOPS, "frac": tf / F64_VECTOR_PEAK_TFLOPS,
+                           "note": "useful f64 flops per instance (estimate, see DESIGN.md) / kernel time"}
+    if D.rank == 0 and D.world == 1 and not args.no_cpu_baseline and n_cpu > 0:
+        t0 = time.perf_counter()
+        want = oracle_fn(n_cpu)
+        dt = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": n_cpu / dt, "unit": unit, "cores": 1, "kind": "port",
+                               "sample": f"first {n_cpu} instances ({dt:.1f} s): oracle g2o restatement (dense Cholesky, numeric range Jacobians), 1 thread",
+                               "max_abs_diff_vs_gpu_m": float(np.abs(wb.poses[:n_cpu, :, 9:] - want).max())}
+    wb.poses[:] = poses0
+    return res
+
+
+def leg_cfg5(D, args):
+    """BASELINE cfg5: 64-pose sliding windows, range + key-frame pose factors, LM with Cauchy kernels, 16 384 windows in total."""
+    import numpy as np
+    from localization_amd.sharding import shard_bounds
+    sys.path.insert(0, os.path.join(ROOT, "tests", "perf"))
+    import bench_window as bw
+    total = 16384
+    lo, hi = shard_bounds(total, D.rank, D.world)
+    wb, graphs, anchors, T = bw.build_pose64(max(hi - lo, 1), np.random.default_rng(args.seed + 7 + 1000 * D.rank), n_graphs=256)
+    return _window_leg(D, args, wb, anchors, 8, "7408 B/window (SURVEY §8(d)); the kernel is bound by latency and VALU issue, not bytes",
+                       "BASELINE cfg5: 64-pose windows (cfg/uwb_pose.yaml topology), one range + one key-frame EdgeSE3 per pose, Cauchy, 10 LM iterations",
+                       "window solves/sec", "windows/s", ALGO_BYTES_CFG5, total,
+                       lambda n: bw.oracle_time(graphs, anchors, T, n)[1], 256)
+
+
+def leg_cfg4(D, args):
+    """BASELINE cfg4: Monte-Carlo anchor self-calibration, 10 unknown anchors x 256 timesteps per hypothesis, 1 024 hypotheses."""
+    import numpy as np
+    from localization_amd.sharding import shard_bounds
+    sys.path.insert(0, os.path.join(ROOT, "tests", "perf"))
+    import bench_window as bw
+    total = 1024 if D.world > 1 else 128   # one GPU's share at G = 8 (SURVEY §8(e)) when run alone
+    lo, hi = shard_bounds(total, D.rank, D.world)
+    wb, graphs, anchors, nv = bw.build_selfcal(max(hi - lo, 1), np.random.default_rng(args.seed + 11))
+    res = _window_leg(D, args, wb, anchors, nv - 1, "33 248 B per hypothesis per LM iteration x 10 iterations (SURVEY §8(d))",
+                      "BASELINE cfg4: anchor self-calibration, 256 tag poses + 10 unknown anchors per hypothesis (1596 unknowns, 2815 range edges), 10 LM iterations",
+                      "hypothesis solves/sec", "solves/s", ALGO_BYTES_CFG4_PER_IT * 10, total,
+                      lambda n: np.array([bw.oracle_selfcal(g, 256, 10) for g in graphs[:n]]), 8)
+    res["lm_iterations_per_s"] = res["value"] * 10
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,6 +351,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tags", type=int, default=2048)
     ap.add_argument("--cpu-epochs", type=int, default=96)
+    ap.add_argument("--legs", default="all", help="secondary legs: all, none, or a comma list of cfg2_numeric,cfg3,cfg5,cfg4")
     args = ap.parse_args()
 
     import numpy as np
@@ -111,26 +359,13 @@ def main():
     import localization_amd as la
     from localization_amd.synthetic import ANCHORS_8, make_snapshot_stream_torch
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    n_dev = torch.cuda.device_count()
-    if args.dist_backend == "gloo":
-        local_rank = local_rank % max(n_dev, 1)  # rehearsal: ranks may share a device
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo")
+    D = Dist(args)
+    world, rank, dev = D.world, D.rank, D.dev
     n_gpus = world
     if args.gpus != n_gpus and rank == 0:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
 
     B, E, M = args.batch, args.epochs, 8
     total_steps = args.warmup + args.steps
@@ -146,7 +381,7 @@ def main():
         del hs
     dist_t, err_t = stream["dist_tiles"], stream["err_tiles"]
     solver = la.SnapshotSolver(ANCHORS_8, B, maximum_iteration=10, distance_outlier=1.0, jacobian=args.jacobian,
-                               lanes_per_instance=args.lpi, block_threads=args.block, device=local_rank)
+                               lanes_per_instance=args.lpi, block_threads=args.block, device=D.local_rank)
     solver.set_positions(stream["init"])
     out_pos = torch.empty((total_steps * E, 3, B), dtype=torch.float64, device=dev)
     out_chi2 = torch.empty((total_steps * E, B), dtype=torch.float64, device=dev)
@@ -156,46 +391,40 @@ def main():
         sl = slice(i * E, (i + 1) * E)
         solver.solve_device(dist_t[sl], err_t[sl], out_pos[sl], out_chi2[sl], out_trials[sl])
 
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for i in range(args.warmup):
         step(i)
-    barrier()
+    D.barrier()
     solver.timing_begin(args.steps)
     t0 = time.perf_counter()
     for i in range(args.warmup, total_steps):
         step(i)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0)
     n_launch, kern_ms_total, kern_ms_avg = solver.timing_end()
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     updates_per_launch = float(B) * E
     total_updates = updates_per_launch * args.steps * n_gpus
     value = total_updates / elapsed
     achieved_gbs = ALGO_BYTES_PER_UPDATE * updates_per_launch / (kern_ms_avg * 1e-3) / 1e9
 
+    res = None
     if rank == 0:
         trials_mean = float(out_trials[args.warmup * E:].cpu().numpy().mean())
         err_last = torch.from_numpy(np.sqrt(((out_pos[-1].cpu().numpy() - stream["truth_last"].cpu().numpy()) ** 2).sum(axis=0)))
-        # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process); they apply
-        # to the default launch shape only
-        traffic, traffic_src, f64_flop, issue_slots, issue_ceiling = None, None, None, None, None
+        # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process); they apply to the
+        # default launch shape AND to the kernel source they were measured on: a hash of the sources is stored with them
+        traffic, traffic_src, f64_flop, issue_slots, issue_ceiling, stale = None, None, None, None, None, None
         prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(prof) and (B, E) == (65536, 128) and args.jacobian == "analytic":
             try:
                 with open(prof) as f:
                     pj = json.load(f)
-                traffic, traffic_src, f64_flop = pj["hbm_bytes_per_launch"], pj["source"], pj.get("f64_flop_per_launch")
-                issue_slots, issue_ceiling = pj.get("issue_lane_slots_per_launch"), pj.get("measured_issue_ceiling_lane_slots_per_s")
+                if pj.get("kernel_source_sha256") == kernel_source_hash(SNAPSHOT_KERNEL_SOURCES):
+                    traffic, traffic_src, f64_flop = pj["hbm_bytes_per_launch"], pj["source"], pj.get("f64_flop_per_launch")
+                    issue_slots, issue_ceiling = pj.get("issue_lane_slots_per_launch"), pj.get("measured_issue_ceiling_lane_slots_per_s")
+                else:
+                    stale = ("stale: profiles/hbm_traffic.json was measured on a different snapshot_kernel.hip (source hash mismatch); "
+                             "PMC-derived fields are withheld until the counters are re-collected")
             except Exception:
                 traffic = None
         res = {
@@ -218,11 +447,16 @@ def main():
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_UPDATE * updates_per_launch,
                          "kernel": "snapshot_lm_kernel", "kernel_ms_avg": kern_ms_avg, "launches_timed": n_launch,
                          "algorithmic_bytes_per_update": ALGO_BYTES_PER_UPDATE,
-                         "note": "fp64, 10 LM iterations: VALU-bound, see DESIGN.md"},
+                         "binding_resource": "valu_issue",
+                         "note": "north_star names the HBM roofline, so `bound`/`frac` price the algorithmic bytes against 8 TB/s; "
+                                 "at fp64 and the reference's 10 LM iterations the kernel is VALU-issue bound (see valu_issue / "
+                                 "valu_f64 and DESIGN.md), the HBM fraction is small by construction"},
         }
+        if stale:
+            res["roofline"]["stale"] = stale
         if f64_flop:
             tf = f64_flop / (kern_ms_avg * 1e-3) / 1e12
-            res["valu_f64"] = {"achieved_tflops": tf, "peak_tflops": 78.6, "frac": tf / 78.6,
+            res["valu_f64"] = {"achieved_tflops": tf, "peak_tflops": F64_VECTOR_PEAK_TFLOPS, "frac": tf / F64_VECTOR_PEAK_TFLOPS,
                                "note": "f64 add+mul+2*fma+trans lane-ops per launch (PMC, profiles/) / live kernel time; "
                                        "the kernel is VALU-issue bound at one wave per SIMD, not HBM bound"}
         if issue_slots and issue_ceiling:
@@ -238,11 +472,36 @@ def main():
                                                                        min(args.cpu_epochs, E * total_steps), M)
             except Exception as exc:  # noqa: BLE001
                 res["cpu_baseline_all_cores"] = {"value": None, "error": f"{type(exc).__name__}: {exc}"}
-        print(json.dumps(res))
     solver.close()
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    del out_pos, out_chi2, out_trials
+
+    # ---- secondary legs (every rank takes part: they carry their own barriers) ------------------------------------------------
+    want = [] if args.legs == "none" else (["cfg2_numeric", "cfg3", "cfg5", "cfg4"] if args.legs == "all" else args.legs.split(","))
+    legs = {}
+    for name in want:
+        try:
+            if name == "cfg2_numeric":
+                out = leg_cfg2_numeric(D, args, stream, B, E, M)
+            elif name == "cfg3":
+                out = leg_cfg3(D, args)
+            elif name == "cfg5":
+                out = leg_cfg5(D, args)
+            elif name == "cfg4":
+                out = leg_cfg4(D, args)
+            else:
+                out = {"error": "unknown leg"}
+        except Exception as exc:  # noqa: BLE001 — a secondary leg must not cost the bench its headline line
+            if world > 1:
+                raise   # (with several ranks a one-sided failure would deadlock the next barrier: fail loudly instead)
+            out = {"error": f"{type(exc).__name__}: {exc}"}
+        out["n_gpus"] = n_gpus
+        legs[name] = out
+        torch.cuda.empty_cache()
+    if rank == 0:
+        if legs:
+            res["legs"] = legs
+        print(json.dumps(res))
+    D.close()
 
 
 if __name__ == "__main__":

@@ -31,19 +31,24 @@ def read_tum(path):
 
 
 def associate(stamps_a, stamps_b, offset=0.0, max_difference=0.02):
-    """Greedy best-first matching of two stamp lists (associate.py:71-101). Returns index pairs sorted by a."""
-    a = np.asarray(stamps_a, dtype=float); b = np.asarray(stamps_b, dtype=float) + offset
-    order_b = np.argsort(b)
-    bs = b[order_b]
+    """Greedy best-first matching of two stamp lists (associate.py:71-101): EVERY pair with |a - (b + offset)| <
+    max_difference is a candidate, candidates are taken in ascending (difference, a, b) order, each stamp is used once.
+    Returns index pairs sorted by a."""
+    a = np.asarray(stamps_a, dtype=float); b = np.asarray(stamps_b, dtype=float)
+    order_b = np.argsort(b + offset, kind="stable")
+    bs = (b + offset)[order_b]
+    lo = np.searchsorted(bs, a - max_difference, side="left")
+    hi = np.searchsorted(bs, a + max_difference, side="right")
     cand = []
     for i, t in enumerate(a):
-        j = np.searchsorted(bs, t)
-        for jj in (j - 1, j):
-            if 0 <= jj < len(bs) and abs(bs[jj] - t) < max_difference:
-                cand.append((abs(bs[jj] - t), i, int(order_b[jj])))
+        for jj in range(lo[i], hi[i]):
+            j = int(order_b[jj])
+            diff = abs(t - (b[j] + offset))
+            if diff < max_difference:
+                cand.append((diff, t, b[j], i, j))
     cand.sort()
     used_a, used_b, out = set(), set(), []
-    for _, i, j in cand:
+    for _, _, _, i, j in cand:
         if i in used_a or j in used_b:
             continue
         used_a.add(i); used_b.add(j); out.append((i, j))

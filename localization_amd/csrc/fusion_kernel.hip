@@ -75,10 +75,13 @@ __device__ __forceinline__ void quat_to_mat(double w, double x, double y, double
 //           g2o's central differences through X * fromVectorMQT(+-1e-9 e_d) (the reference's mode: the twelve perturbed
 //           antenna points are shared by the tag's ranges)
 //   prior : e = vec(q(Rm^T R)), J_rot = w I + [q]x, information pinfo (rotation rows only)
+// The epoch's measurements are NOT held in registers across the passes: ep points at this lane's column of the epoch slot in
+// LDS ([28][256] doubles: d0 w0 d1 w1 .. d7 w7, Rm[9], pinfo[3]) and every value is read where it is used.  The gate (first
+// pass of an update only) writes the zeroed weights back.
+constexpr int EP_STRIDE = 256;
 template <int JAC>
 __device__ __forceinline__ Sys6 evaluate6(const Pose& X, const double (&ax)[M8], const double (&ay)[M8], const double (&az)[M8],
-                                          const double (&d)[M8], double (&w)[M8], const double (&Rm)[9], const double (&pinfo)[3],
-                                          const double ox, const double oy, const double oz, const bool gate_now, const double gate) {
+                                          double* ep, const double ox, const double oy, const double oz, const bool gate_now, const double gate) {
     Sys6 s;
 #pragma unroll
     for (int i = 0; i < 21; ++i) s.h[i] = 0.0;
@@ -106,11 +109,13 @@ __device__ __forceinline__ Sys6 evaluate6(const Pose& X, const double (&ax)[M8],
     }
 #pragma unroll
     for (int j = 0; j < M8; ++j) {
+        const double dj = ep[(2 * j) * EP_STRIDE];
+        double wj = ep[(2 * j + 1) * EP_STRIDE];
         if (gate_now) {  // |‖t - a‖ - d| > gate on the vertex origin, without a square root
             const double gx = X.t[0] - ax[j], gy = X.t[1] - ay[j], gz = X.t[2] - az[j];
             const double g2 = gx * gx + gy * gy + gz * gz;
-            const double hi = d[j] + gate, lo = d[j] - gate;
-            if (g2 > hi * hi || (lo > 0.0 && g2 < lo * lo)) w[j] = 0.0;
+            const double hi = dj + gate, lo = dj - gate;
+            if (g2 > hi * hi || (lo > 0.0 && g2 < lo * lo)) { wj = 0.0; ep[(2 * j + 1) * EP_STRIDE] = 0.0; }
         }
         double e, J[6];
         if (JAC == 0) {
@@ -118,7 +123,7 @@ __device__ __forceinline__ Sys6 evaluate6(const Pose& X, const double (&ax)[M8],
             const double n2 = fmax(ux * ux + uy * uy + uz * uz, 1e-300);
             double n, inv;
             sqrt_and_rsqrt(n2, n, inv);
-            e = d[j] - n;
+            e = dj - n;
             const double vx = ux * inv, vy = uy * inv, vz = uz * inv;  // unit vector u
             // uR = R^T u
             const double rx = R[0] * vx + R[3] * vy + R[6] * vz;
@@ -127,15 +132,15 @@ __device__ __forceinline__ Sys6 evaluate6(const Pose& X, const double (&ax)[M8],
             J[0] = -rx; J[1] = -ry; J[2] = -rz;
             J[3] = ry * o2z - rz * o2y; J[4] = rz * o2x - rx * o2z; J[5] = rx * o2y - ry * o2x;  // 2 (uR x o)
         } else {
-            e = d[j] - norm_to_plain(P0, ax[j], ay[j], az[j]);
+            e = dj - norm_to_plain(P0, ax[j], ay[j], az[j]);
 #pragma unroll
             for (int dd = 0; dd < 6; ++dd)
-                J[dd] = central_difference_plain(d[j], norm_to_plain(Pp[dd], ax[j], ay[j], az[j]), norm_to_plain(Pm[dd], ax[j], ay[j], az[j]));
+                J[dd] = central_difference_plain(dj, norm_to_plain(Pp[dd], ax[j], ay[j], az[j]), norm_to_plain(Pm[dd], ax[j], ay[j], az[j]));
         }
-        const double we = w[j] * e;
+        const double we = wj * e;
         const double chi = e * we;
         const double aux = 1.0 + chi;
-        const double wr = fast_rcp_1nr(aux) * w[j];
+        const double wr = fast_rcp_1nr(aux) * wj;
         double wJ[6];
 #pragma unroll
         for (int r = 0; r < 6; ++r) wJ[r] = wr * J[r];
@@ -149,6 +154,11 @@ __device__ __forceinline__ Sys6 evaluate6(const Pose& X, const double (&ax)[M8],
         s.chi += chi;
     }
     // ---- rotation prior ---------------------------------------------------------------------------------------
+    double Rm[9], pinfo[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Rm[i] = ep[(16 + i) * EP_STRIDE];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pinfo[i] = ep[(25 + i) * EP_STRIDE];
     double E[9];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -239,17 +249,18 @@ __device__ __forceinline__ Pose oplus(const Pose& X, const double (&dx)[6]) {
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* glb_void_ptr;
 
-// LDS per block (256 lanes): next epoch converted: d,w (8 double2) + Rm (9) + pinfo (3) = 28 doubles per lane;
+// LDS per block (256 lanes): TWO converted epochs (epoch e lives in slot e & 1; a wave's lanes are at epoch c or c + 1):
+// d,w (8 pairs) + Rm (9) + pinfo (3) = 28 doubles per lane and slot; the accepted pose X (12 doubles per lane);
 // raw epoch in flight: 4 float4 range tiles + 4 x 16 B of IMU = 8 x 16 B per lane.
 constexpr int NEXT_DOUBLES = 28;
 constexpr int RAW_PIECES = 8;
-constexpr int FUSION_LDS_BYTES = NEXT_DOUBLES * 256 * 8 + RAW_PIECES * 256 * 16;
+constexpr int FUSION_LDS_BYTES = 2 * NEXT_DOUBLES * 256 * 8 + RAW_PIECES * 256 * 16;
 
 template <int JAC>
 __global__ void __launch_bounds__(256) fusion_lm_kernel(const FusionArgs a) {
     __shared__ __attribute__((aligned(16))) char lds_bytes[FUSION_LDS_BYTES];
-    double* const s_next = reinterpret_cast<double*>(lds_bytes);                      // [28][256]
-    float4* const s_raw = reinterpret_cast<float4*>(lds_bytes + NEXT_DOUBLES * 256 * 8);  // [8][256]
+    double* const s_ep = reinterpret_cast<double*>(lds_bytes);                            // [2][28][256]
+    float4* const s_raw = reinterpret_cast<float4*>(lds_bytes + 2 * NEXT_DOUBLES * 256 * 8);  // [8][256]
     const int tib = threadIdx.x;
     const long long inst = (long long)blockIdx.x * blockDim.x + tib;
     const long long B = a.B;
@@ -293,29 +304,14 @@ __global__ void __launch_bounds__(256) fusion_lm_kernel(const FusionArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) im[i] = ip[i];
     };
-    auto put_next = [&](const double (&dd)[M8], const double (&ww)[M8], const double (&Rm)[9], const double (&pi)[3]) {
+    auto put_epoch = [&](int ke, const double (&dd)[M8], const double (&ww)[M8], const double (&Rm)[9], const double (&pi)[3]) {
+        double* sl = s_ep + (ke & 1) * NEXT_DOUBLES * 256 + tib;
 #pragma unroll
-        for (int j = 0; j < M8; ++j) { s_next[(2 * j) * 256 + tib] = dd[j]; s_next[(2 * j + 1) * 256 + tib] = ww[j]; }
+        for (int j = 0; j < M8; ++j) { sl[(2 * j) * 256] = dd[j]; sl[(2 * j + 1) * 256] = ww[j]; }
 #pragma unroll
-        for (int i = 0; i < 9; ++i) s_next[(16 + i) * 256 + tib] = Rm[i];
+        for (int i = 0; i < 9; ++i) sl[(16 + i) * 256] = Rm[i];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) s_next[(25 + i) * 256 + tib] = pi[i];
-    };
-    // hand-issued LDS reads: see snapshot_kernel.hip (keeps the compiler from waiting on vmcnt here on every pass)
-    auto take_next = [&](double (&dd)[M8], double (&ww)[M8], double (&Rm)[9], double (&pi)[3]) {
-        const unsigned addr = (unsigned)(unsigned long long)(s_next + tib);
-        double v[NEXT_DOUBLES];
-#pragma unroll
-        for (int i = 0; i < NEXT_DOUBLES; ++i) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v[i]) : "v"(addr), "n"(i * 2048));
-#pragma unroll
-        for (int i = 0; i < NEXT_DOUBLES; i += 7)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[i]), "+v"(v[i + 1]), "+v"(v[i + 2]), "+v"(v[i + 3]), "+v"(v[i + 4]), "+v"(v[i + 5]), "+v"(v[i + 6]) :: "memory");
-#pragma unroll
-        for (int j = 0; j < M8; ++j) { dd[j] = v[2 * j]; ww[j] = v[2 * j + 1]; }
-#pragma unroll
-        for (int i = 0; i < 9; ++i) Rm[i] = v[16 + i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) pi[i] = v[25 + i];
+        for (int i = 0; i < 3; ++i) sl[(25 + i) * 256] = pi[i];
     };
     auto prefetch = [&](int ke) {
         const int wave_base = (tib / 64) * 64;
@@ -357,17 +353,17 @@ __global__ void __launch_bounds__(256) fusion_lm_kernel(const FusionArgs a) {
         X.t[0] = a.pose[0 * B + inst]; X.t[1] = a.pose[1 * B + inst]; X.t[2] = a.pose[2 * B + inst];
         quat_to_mat(a.pose[6 * B + inst], a.pose[3 * B + inst], a.pose[4 * B + inst], a.pose[5 * B + inst], X.R);
     }
-    double d[M8], w[M8], Rm[9], pinfo[3];
     {
         float df[M8], sf[M8];
         double im[8];
+        double dn[M8], wn[M8], Rn[9], pn[3];
         load_direct(0, df, sf, im);
-        convert(df, sf, im, d, w, Rm, pinfo);
+        convert(df, sf, im, dn, wn, Rn, pn);
+        put_epoch(0, dn, wn, Rn, pn);
         if (K > 1) {
-            double dn[M8], wn[M8], Rn[9], pn[3];
             load_direct(1, df, sf, im);
             convert(df, sf, im, dn, wn, Rn, pn);
-            put_next(dn, wn, Rn, pn);
+            put_epoch(1, dn, wn, Rn, pn);
         }
         if (K > 2) prefetch(2);
     }
@@ -385,10 +381,11 @@ __global__ void __launch_bounds__(256) fusion_lm_kernel(const FusionArgs a) {
 
     while (__any(!exhausted)) {
         const bool active = !exhausted && !waiting;
+        double* const ep = s_ep + (k & 1) * NEXT_DOUBLES * 256 + tib;  // this lane's epoch slot
         // a fresh epoch starts from the IMU's rotation (localization.cpp:505-513); the first pass evaluates that pose
         if (active && init) {
 #pragma unroll
-            for (int i = 0; i < 9; ++i) X.R[i] = Rm[i];
+            for (int i = 0; i < 9; ++i) X.R[i] = ep[(16 + i) * EP_STRIDE];
         }
         double x[6];
         const bool ok2 = solve6(cur, lambda, x) && !init;
@@ -398,7 +395,11 @@ __global__ void __launch_bounds__(256) fusion_lm_kernel(const FusionArgs a) {
         }
         const Pose T = oplus(X, x);
         const bool gate_now = active && init && (a.gate > 0.0) && (k >= a.gate_from_epoch);
-        const Sys6 tr = evaluate6<JAC>(T, ax, ay, az, d, w, Rm, pinfo, ox, oy, oz, gate_now, a.gate);
+        // computeScale needs the step and the accepted b only: formed here, so x is dead across the edge loop
+        double scale = 1e-3;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) scale = __builtin_fma(x[i], __builtin_fma(lambda, x[i], cur.b[i]), scale);
+        const Sys6 tr = evaluate6<JAC>(T, ax, ay, az, ep, ox, oy, oz, gate_now, a.gate);
 
         bool finished = false;
         if (active) {
@@ -416,9 +417,6 @@ __global__ void __launch_bounds__(256) fusion_lm_kernel(const FusionArgs a) {
                 finished = (a.iterations <= 0) || !(tr6 > 0.0);
             } else {
                 const double temp_chi = ok2 ? tr.rchi : DBL_MAX;
-                double scale = 1e-3;
-#pragma unroll
-                for (int i = 0; i < 6; ++i) scale = __builtin_fma(x[i], __builtin_fma(lambda, x[i], cur.b[i]), scale);  // computeScale
                 const double rho = (cur_chi - temp_chi) * fast_rcp(scale);
                 const bool accept = (rho > 0.0) && (fabs(temp_chi) < DBL_MAX) && ok2;
                 ++trials;
@@ -460,8 +458,7 @@ __global__ void __launch_bounds__(256) fusion_lm_kernel(const FusionArgs a) {
                     a.pose[0 * B + inst] = X.t[0]; a.pose[1 * B + inst] = X.t[1]; a.pose[2 * B + inst] = X.t[2];
                     a.pose[3 * B + inst] = qq[1]; a.pose[4 * B + inst] = qq[2]; a.pose[5 * B + inst] = qq[3]; a.pose[6 * B + inst] = qq[0];
                 } else if (k == c) {
-                    take_next(d, w, Rm, pinfo);
-                    k = c + 1;
+                    k = c + 1;   // the next epoch is already converted, in slot (c + 1) & 1
                     init = true;
                 } else {
                     waiting = true;
@@ -473,16 +470,10 @@ __global__ void __launch_bounds__(256) fusion_lm_kernel(const FusionArgs a) {
             if (c + 1 < K) {
                 double dn[M8], wn[M8], Rn[9], pn[3];
                 consume(dn, wn, Rn, pn);
-                put_next(dn, wn, Rn, pn);
+                put_epoch(c + 1, dn, wn, Rn, pn);   // slot (c + 1) & 1 held epoch c - 1: no lane is there any more
                 asm volatile("" ::: "memory");
                 if (c + 2 < K) prefetch(c + 2);
                 if (waiting) {
-#pragma unroll
-                    for (int j = 0; j < M8; ++j) { d[j] = dn[j]; w[j] = wn[j]; }
-#pragma unroll
-                    for (int i = 0; i < 9; ++i) Rm[i] = Rn[i];
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) pinfo[i] = pn[i];
                     k = c + 1;
                     init = true;
                     waiting = false;

@@ -40,9 +40,13 @@ namespace locamd {
 
 namespace {
 
-constexpr int RREC = 16;   // J0[6] J1[6] wr omega_r chi rho0
-constexpr int PREC = 56;   // J[36] W[6] omega_r[6] (+pad)
-constexpr int SREC = 152;  // J0[36] J1[36] WJ0[36] WJ1[36] omega_r[6] (+pad)
+// Edge records written by the linearisation.  Unary and SE3 edges store their finished CONTRIBUTIONS to the normal equations
+// (the 6x6 products are formed once, by the lane that evaluated the edge, from values it holds in registers), so building H
+// and b is one load per (edge, entry); diagonal blocks as 21 lower-triangle entries k = r (r + 1) / 2 + c, r >= c.
+constexpr int RREC = 16;   // J0[6] J1[6] wr omega_r (+pad): rank-1, expanded on the fly
+constexpr int PREC = 28;   // H_vv[21] b_v[6] (+pad)
+constexpr int SREC = 90;   // H_ii[21] H_jj[21] H_(later,earlier)[36, column-major like the storage] b_i[6] b_j[6]
+constexpr int S_HJJ = 21, S_OFF = 42, S_BI = 78, S_BJ = 84;
 
 // Wave-wide reductions on the VALU (DPP row shifts + row broadcasts, then one readlane): every lane gets the same
 // bits, no LDS crossbar round trips (a __shfl_xor butterfly on doubles costs ~6 dependent ds_bpermute pairs).
@@ -296,15 +300,33 @@ __device__ __forceinline__ void evaluate_edges(const WindowArgs& a, const Lds& L
         csum += chi;
         if (FULL) {
             double* rec = L.prec + e * PREC;
+            double J[36];
 #pragma unroll
-            for (int i = 0; i < 36; ++i) rec[i] = 0.0;
+            for (int i = 0; i < 36; ++i) J[i] = 0.0;
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) rec[i * 6 + j] = RE[i * 3 + j];
-            quat_right_jac(q, 1.0, rec, 6);
+                for (int j = 0; j < 3; ++j) J[i * 6 + j] = RE[i * 3 + j];
+            quat_right_jac(q, 1.0, J, 6);
+            const double* W = val + 12;
+            // J = blockdiag(RE, Q): row i of the Jacobian touches columns of its own 3-block only, so entry (r, cc) of
+            // J^T W J is non-zero only inside a diagonal 3-block (IEEE arithmetic cannot drop 0 * x by itself)
 #pragma unroll
-            for (int i = 0; i < 6; ++i) { rec[36 + i] = val[12 + i]; rec[42 + i] = -val[12 + i] * err[i]; }
+            for (int r = 0; r < 6; ++r) {
+#pragma unroll
+                for (int cc = 0; cc <= r; ++cc) {
+                    double h = 0.0;
+                    if ((r < 3) == (cc < 3)) {
+#pragma unroll
+                        for (int i = (r < 3 ? 0 : 3); i < (r < 3 ? 3 : 6); ++i) h += J[i * 6 + r] * W[i] * J[i * 6 + cc];
+                    }
+                    rec[r * (r + 1) / 2 + cc] = h;
+                }
+                double bb = 0.0;
+#pragma unroll
+                for (int i = (r < 3 ? 0 : 3); i < (r < 3 ? 3 : 6); ++i) bb += J[i * 6 + r] * (-W[i] * err[i]);
+                rec[21 + r] = bb;
+            }
         }
     }
     // ---- binary SE3 edges ---------------------------------------------------------------------------------------
@@ -342,9 +364,9 @@ __device__ __forceinline__ void evaluate_edges(const WindowArgs& a, const Lds& L
         if (FULL) {
             double* rec = L.srec + e * SREC;
             const double w = robust ? 1.0 / aux : 1.0;
-            double* J0 = rec; double* J1 = rec + 36;
+            double J0[36], J1[36];
 #pragma unroll
-            for (int i = 0; i < 72; ++i) rec[i] = 0.0;
+            for (int i = 0; i < 36; ++i) { J0[i] = 0.0; J1[i] = 0.0; }
             // Jj : E' = E * Delta
 #pragma unroll
             for (int i = 0; i < 3; ++i)
@@ -374,19 +396,86 @@ __device__ __forceinline__ void evaluate_edges(const WindowArgs& a, const Lds& L
 #pragma unroll
                 for (int i = 0; i < 3; ++i) J0[(3 + i) * 6 + 3 + k] = -s * nrm * r2[1 + i];
             }
-            // WJ = w * Omega * J, omega_r = -w * Omega * e
+            // contributions: WJ = w Omega J;  H_ii = J0^T WJ0, H_jj = J1^T WJ1, the off-diagonal block with the rows of the
+            // later-labelled pose (J1^T WJ0 if vj > vi, else J0^T WJ1), b = J^T omega_r with omega_r = -w Omega e.
+            // Structure (IEEE arithmetic cannot drop 0 * x by itself, so it is spelled out):
+            //   J1 = [[RE, 0], [0, Q1]]: column c has rows [0,3) if c < 3, else [3,6);  J0 = [[-A, 2 R A S], [0, Q0]]: column c
+            //   has rows [0,3) if c < 3, else [0,6).
+#define LOCAMD_J1_LO(c) ((c) < 3 ? 0 : 3)
+#define LOCAMD_J1_HI(c) ((c) < 3 ? 3 : 6)
+#define LOCAMD_J0_HI(c) ((c) < 3 ? 3 : 6)
+            double WJ[36];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
+            for (int i = 0; i < 6; ++i)
 #pragma unroll
                 for (int cc = 0; cc < 6; ++cc) {
-                    double s0 = 0.0, s1 = 0.0;
+                    double s0 = 0.0;
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) { s0 += Om[i * 6 + j] * J0[j * 6 + cc]; s1 += Om[i * 6 + j] * J1[j * 6 + cc]; }
-                    rec[72 + i * 6 + cc] = w * s0;
-                    rec[108 + i * 6 + cc] = w * s1;
+                    for (int j = 0; j < LOCAMD_J0_HI(cc); ++j) s0 += Om[i * 6 + j] * J0[j * 6 + cc];
+                    WJ[i * 6 + cc] = w * s0;
                 }
-                rec[144 + i] = -w * Oe[i];
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int cc = 0; cc <= r; ++cc) {
+                    double h = 0.0;
+#pragma unroll
+                    for (int i = 0; i < LOCAMD_J0_HI(r); ++i) h += J0[i * 6 + r] * WJ[i * 6 + cc];
+                    rec[r * (r + 1) / 2 + cc] = h;
+                }
+            if (vj > vi) {
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+#pragma unroll
+                    for (int cc = 0; cc < 6; ++cc) {
+                        double h = 0.0;
+#pragma unroll
+                        for (int i = LOCAMD_J1_LO(r); i < LOCAMD_J1_HI(r); ++i) h += J1[i * 6 + r] * WJ[i * 6 + cc];
+                        rec[S_OFF + 6 * cc + r] = h;
+                    }
             }
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int cc = 0; cc < 6; ++cc) {
+                    double s1 = 0.0;
+#pragma unroll
+                    for (int j = LOCAMD_J1_LO(cc); j < LOCAMD_J1_HI(cc); ++j) s1 += Om[i * 6 + j] * J1[j * 6 + cc];
+                    WJ[i * 6 + cc] = w * s1;
+                }
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int cc = 0; cc <= r; ++cc) {
+                    double h = 0.0;
+#pragma unroll
+                    for (int i = LOCAMD_J1_LO(r); i < LOCAMD_J1_HI(r); ++i) h += J1[i * 6 + r] * WJ[i * 6 + cc];
+                    rec[S_HJJ + r * (r + 1) / 2 + cc] = h;
+                }
+            if (vi > vj) {
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+#pragma unroll
+                    for (int cc = 0; cc < 6; ++cc) {
+                        double h = 0.0;
+#pragma unroll
+                        for (int i = 0; i < LOCAMD_J0_HI(r); ++i) h += J0[i * 6 + r] * WJ[i * 6 + cc];
+                        rec[S_OFF + 6 * cc + r] = h;
+                    }
+            }
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                double bi = 0.0, bj = 0.0;
+#pragma unroll
+                for (int i = 0; i < LOCAMD_J0_HI(r); ++i) bi += J0[i * 6 + r] * (-w * Oe[i]);
+#pragma unroll
+                for (int i = LOCAMD_J1_LO(r); i < LOCAMD_J1_HI(r); ++i) bj += J1[i * 6 + r] * (-w * Oe[i]);
+                rec[S_BI + r] = bi;
+                rec[S_BJ + r] = bj;
+            }
+#undef LOCAMD_J1_LO
+#undef LOCAMD_J1_HI
+#undef LOCAMD_J0_HI
         }
     }
     robust_chi = wave_sum(rsum);
@@ -413,13 +502,21 @@ __host__ __device__ inline size_t window_incidences(const WindowCaps& c) {
     return 2 * (size_t)c.nr_max + (size_t)c.np_max + 2 * (size_t)c.ns_max;
 }
 __host__ __device__ inline size_t ints_as_doubles(size_t n) { return (n + 1) / 2; }
+// the edge-index tables and incidence lists of one instance, in doubles; in HBM-workspace mode they move to LDS as well when
+// they are small (every gather starts with a look-up in them; from HBM that is a full memory round trip of pure latency)
+__host__ __device__ inline size_t window_index_doubles(const WindowCaps& c) {
+    return ints_as_doubles(window_incidences(c)) + ints_as_doubles((size_t)c.nr_max + c.ns_max + 1) +
+           ints_as_doubles(2 * (size_t)c.nr_max) + ints_as_doubles((size_t)c.np_max) + ints_as_doubles(4 * (size_t)c.ns_max);
+}
+constexpr size_t INDEX_TABLES_LDS_MAX = 16 * 1024;
+__host__ __device__ inline bool window_index_in_lds(const WindowCaps& c) { return window_index_doubles(c) * 8 <= INDEX_TABLES_LDS_MAX; }
+
 // doubles of one instance's MAIN arrays (block-sparse pair, dense vectors, poses, edge records, incidence lists, a
 // writable copy of the edge index tables) — the layout the kernel carves, in LDS or in the HBM workspace
 __host__ __device__ inline size_t window_instance_doubles(const WindowCaps& c) {
     const size_t n_max = 6 * (size_t)c.nv_max;
     return 2 * sky_nnz_bound(c.nv_max, c.bw_max) + 4 * n_max + 2 * (size_t)c.nv_max * 12 + (size_t)c.nr_max * RREC + (size_t)c.np_max * PREC +
-           (size_t)c.ns_max * SREC + ints_as_doubles(window_incidences(c)) + ints_as_doubles((size_t)c.nr_max + c.ns_max + 1) +
-           ints_as_doubles(2 * (size_t)c.nr_max) + ints_as_doubles((size_t)c.np_max) + ints_as_doubles(4 * (size_t)c.ns_max);
+           (size_t)c.ns_max * SREC + window_index_doubles(c);
 }
 // bytes of the small index tables that always live in LDS
 __host__ __device__ inline size_t window_table_bytes(const WindowCaps& c) {
@@ -593,52 +690,77 @@ __device__ __forceinline__ int compute_sparse(Lds& L, int lane, int nv, int nv_m
 }
 
 // Once per solve (the topology does not change between iterations): the incidence lists, and the list of binary edges
-// that share their pair of poses with another edge.
+// that share their pair of poses with another edge.  Everything wave-parallel:
+//   incidence lists   one lane per pose walks the edge tables (uniform, broadcast loads) twice: count, then fill in fold
+//                     order (ranges, priors, SE3; ascending edge number) — the order every sum over a pose's edges uses;
+//   shared pairs      every binary edge stamps its number on the first entry of its off-diagonal block (H is not in use
+//                     yet) and clears the second; an edge that does not read its own stamp back raises the pair's flag
+//                     (second entry = -1); the edges of flagged pairs then take the minimum of their stamps (atomic min on
+//                     the bit patterns of positive doubles), which names the pair's first edge; the flagged edges are
+//                     listed in fold order by ballot compaction.
 template <bool SP>
-__device__ __forceinline__ void compute_incidence(const Lds& L, int lane, int nv, int nr, int np, int ns, int* cursor) {
-    if (lane == 0) {
-        // incidence lists in the order the fold visits the edges: ranges, priors, SE3 (stable counting sort by pose)
-        for (int v = 0; v <= nv; ++v) L.ioff[v] = 0;
-        for (int e = 0; e < nr; ++e) { ++L.ioff[L.r_idx[2 * e] + 1]; if (L.r_idx[2 * e + 1] >= 0) ++L.ioff[L.r_idx[2 * e + 1] + 1]; }
-        for (int e = 0; e < np; ++e) ++L.ioff[L.p_idx[e] + 1];
-        for (int e = 0; e < ns; ++e) { ++L.ioff[L.s_idx[4 * e] + 1]; ++L.ioff[L.s_idx[4 * e + 1] + 1]; }
-        for (int v = 0; v < nv; ++v) L.ioff[v + 1] += L.ioff[v];
-        for (int v = 0; v < nv; ++v) cursor[v] = L.ioff[v];
+__device__ __forceinline__ void compute_incidence(const Lds& L, int lane, int nv, int nr, int np, int ns) {
+    for (int v0 = 0; v0 < nv; v0 += 64) {
+        const int v = v0 + lane;
+        int cnt = 0;
+        for (int e = 0; e < nr; ++e) cnt += (L.r_idx[2 * e] == v) + (L.r_idx[2 * e + 1] == v);
+        for (int e = 0; e < np; ++e) cnt += (L.p_idx[e] == v);
+        for (int e = 0; e < ns; ++e) cnt += (L.s_idx[4 * e] == v) + (L.s_idx[4 * e + 1] == v);
+        if (v < nv) L.ioff[v + 1] = cnt;
+    }
+    __syncthreads();
+    int carry = 0;
+    for (int v0 = 0; v0 < nv; v0 += 64) {
+        const int v = v0 + lane;
+        const int c = v < nv ? L.ioff[v + 1] : 0;
+        const int ex = wave_excl_scan_i(c, lane) + carry;
+        carry = __shfl(ex + c, 63, 64);
+        __syncthreads();
+        if (v < nv) L.ioff[v] = ex;
+        __syncthreads();
+    }
+    if (lane == 0) L.ioff[nv] = carry;
+    __syncthreads();
+    for (int v0 = 0; v0 < nv; v0 += 64) {
+        const int v = v0 + lane;
+        int cur = v < nv ? L.ioff[v] : 0;
         for (int e = 0; e < nr; ++e) {
-            const int v0 = L.r_idx[2 * e], v1 = L.r_idx[2 * e + 1];
-            L.ilist[cursor[v0]++] = e;
-            if (v1 >= 0) L.ilist[cursor[v1]++] = (1 << INC_ROLE_SHIFT) | e;
+            if (L.r_idx[2 * e] == v) L.ilist[cur++] = e;
+            if (L.r_idx[2 * e + 1] == v) L.ilist[cur++] = (1 << INC_ROLE_SHIFT) | e;
         }
-        for (int e = 0; e < np; ++e) L.ilist[cursor[L.p_idx[e]]++] = (1 << INC_KIND_SHIFT) | e;
+        for (int e = 0; e < np; ++e) if (L.p_idx[e] == v) L.ilist[cur++] = (1 << INC_KIND_SHIFT) | e;
         for (int e = 0; e < ns; ++e) {
-            L.ilist[cursor[L.s_idx[4 * e]]++] = (2 << INC_KIND_SHIFT) | e;
-            L.ilist[cursor[L.s_idx[4 * e + 1]]++] = (2 << INC_KIND_SHIFT) | (1 << INC_ROLE_SHIFT) | e;
+            if (L.s_idx[4 * e] == v) L.ilist[cur++] = (2 << INC_KIND_SHIFT) | e;
+            if (L.s_idx[4 * e + 1] == v) L.ilist[cur++] = (2 << INC_KIND_SHIFT) | (1 << INC_ROLE_SHIFT) | e;
         }
     }
     __syncthreads();
-    // Binary edges that share their pair of poses with another one: every binary edge stamps its number on the first
-    // entry of its off-diagonal block (H is not in use yet); whoever does not read its own stamp back overwrites it with
-    // -1, and after that everybody on a shared pair reads -1.  Lane 0 lists those edges in fold order.
     auto block_entry = [&](int t) {
         const bool is_r = t < nr;
         const int va = is_r ? L.r_idx[2 * t] : L.s_idx[4 * (t - nr)], vb = is_r ? L.r_idx[2 * t + 1] : L.s_idx[4 * (t - nr) + 1];
-        return vb >= 0 ? sky<SP>(L, 6 * max(va, vb), 6 * min(va, vb)) : -1;
+        return vb >= 0 ? blk_off<SP>(L, max(va, vb), min(va, vb)) : -1;
     };
-    for (int t = lane; t < nr + ns; t += 64) { const int a0 = block_entry(t); if (a0 >= 0) L.Hs[a0] = (double)(t + 1); }
+    const int nbin = nr + ns;
+    for (int t = lane; t < nbin; t += 64) { const int a0 = block_entry(t); if (a0 >= 0) { L.Hs[a0] = (double)(t + 1); L.Hs[a0 + 1] = 0.0; } }
     __syncthreads();
-    for (int t = lane; t < nr + ns; t += 64) { const int a0 = block_entry(t); if (a0 >= 0 && L.Hs[a0] != (double)(t + 1)) L.Hs[a0] = -1.0; }
+    for (int t = lane; t < nbin; t += 64) { const int a0 = block_entry(t); if (a0 >= 0 && L.Hs[a0] != (double)(t + 1)) L.Hs[a0 + 1] = -1.0; }
     __syncthreads();
-    if (lane == 0) {
-        int cnt = 0;
-        for (int t = 0; t < nr + ns; ++t) {
-            const int a0 = block_entry(t);
-            if (a0 < 0) continue;
-            const double stamp = L.Hs[a0];
-            if (stamp == -1.0) { L.shared[1 + cnt++] = (1 << INC_KIND_SHIFT) | t; L.Hs[a0] = -2.0; }  // first edge of its pair
-            else if (stamp == -2.0) L.shared[1 + cnt++] = t;
-        }
-        L.shared[0] = cnt;
+    for (int t = lane; t < nbin; t += 64) {
+        const int a0 = block_entry(t);
+        if (a0 >= 0 && L.Hs[a0 + 1] == -1.0) atomicMin(reinterpret_cast<u64*>(L.Hs + a0), (u64)__double_as_longlong((double)(t + 1)));
     }
+    __syncthreads();
+    int cnt = 0;
+    for (int t0 = 0; t0 < nbin; t0 += 64) {
+        const int t = t0 + lane;
+        const int a0 = t < nbin ? block_entry(t) : -1;
+        const bool sh = a0 >= 0 && L.Hs[a0 + 1] == -1.0;
+        const bool first = sh && L.Hs[a0] == (double)(t + 1);
+        const u64 bal = __ballot(sh);
+        if (sh) L.shared[1 + cnt + __popcll(bal & ((1ull << lane) - 1))] = (first ? (1 << INC_KIND_SHIFT) : 0) | t;
+        cnt += __popcll(bal);
+    }
+    if (lane == 0) L.shared[0] = cnt;
     __syncthreads();
 }
 
@@ -654,69 +776,60 @@ __device__ __forceinline__ void build_system(const Lds& L, int lane, int n, int 
     const int nnz = L.boff[nv];
     for (int i = lane; i < nnz; i += 64) L.Hs[i] = 0.0;
     __syncthreads();
-    for (int task = lane; task < nv * 27; task += 64) {
-        const int v = task / 27, k = task - 27 * v;  // k < 21: lower-triangle entry (r, cc) of the diagonal block; else b[k - 21]
-        int r = 0;
-        while ((r + 1) * (r + 2) / 2 <= k && r < 5) ++r;
-        const int cc = k - r * (r + 1) / 2;
-        const bool is_b = k >= 21;
-        const int rb = k - 21;
-        double acc = 0.0;
+    // diagonal blocks and b: one lane per pose, its 21 + 6 sums in registers, ONE pass over the pose's incidence list — the
+    // 27 loads of an incidence are independent of each other, so a list costs one memory round trip per edge, not per entry
+    for (int v = lane; v < nv; v += 64) {
+        double acc[27];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) acc[k] = 0.0;
         const int p1 = L.ioff[v + 1];
         for (int p = L.ioff[v]; p < p1; ++p) {
             const int code = L.ilist[p];
             const int kind = code >> INC_KIND_SHIFT, role = (code >> INC_ROLE_SHIFT) & 1, e = code & INC_EDGE_MASK;
             if (kind == 0) {
                 const double* rec = L.rrec + e * RREC;
-                const double* J = rec + 6 * role;
-                if (is_b) acc += J[rb] * rec[13];
-                else acc += rec[12] * J[r] * J[cc];
-            } else if (kind == 1) {
-                const double* rec = L.prec + e * PREC;
-                double t = 0.0;
-                if (is_b) {
+                double J[6];
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) t += rec[i * 6 + rb] * rec[42 + i];
-                } else {
+                for (int i = 0; i < 6; ++i) J[i] = rec[6 * role + i];
+                const double wr = rec[12], wre = rec[13];
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) t += rec[i * 6 + r] * rec[36 + i] * rec[i * 6 + cc];
+                for (int r = 0; r < 6; ++r) {
+#pragma unroll
+                    for (int cc = 0; cc <= r; ++cc) acc[r * (r + 1) / 2 + cc] += wr * J[r] * J[cc];
+                    acc[21 + r] += J[r] * wre;
                 }
-                acc += t;
             } else {
-                const double* rec = L.srec + e * SREC;
-                const double* J = rec + 36 * role;
-                double t = 0.0;
-                if (is_b) {
+                const double* rec = kind == 1 ? L.prec + e * PREC : L.srec + e * SREC + S_HJJ * role;
+                const double* recb = kind == 1 ? L.prec + e * PREC + 21 : L.srec + e * SREC + S_BI + 6 * role;
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) t += J[i * 6 + rb] * rec[144 + i];
-                } else {
-                    const double* WJ = rec + 72 + 36 * role;
+                for (int k = 0; k < 21; ++k) acc[k] += rec[k];
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) t += J[i * 6 + r] * WJ[i * 6 + cc];
-                }
-                acc += t;
+                for (int r = 0; r < 6; ++r) acc[21 + r] += recb[r];
             }
         }
-        if (is_b) L.b[v * 6 + rb] = acc;
-        else L.Hs[sky<SP>(L, v * 6 + r, v * 6 + cc)] = acc;
+        const int dv = L.boff[v + 1] - 36;  // the diagonal block is the last one of its block row (both storage schemes)
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+#pragma unroll
+            for (int cc = 0; cc <= r; ++cc) L.Hs[dv + 6 * cc + r] = acc[r * (r + 1) / 2 + cc];
+            L.b[v * 6 + r] = acc[21 + r];
+        }
     }
-    // off-diagonal blocks: one task per (binary edge, entry); the value of entry (r, cc) of edge t
-    auto offdiag = [&](int t, int r, int cc, int& addr) {
-        double h = 0.0;
+    // off-diagonal blocks: one task per (binary edge, entry q = 6 cc + r of the block, column-major like the storage)
+    auto offdiag = [&](int t, int q, int& addr) {
+        double h;
         if (t < nr) {
+            const int r = q % 6, cc = q / 6;
             const int v0 = L.r_idx[2 * t], v1 = L.r_idx[2 * t + 1];
             const double* rec = L.rrec + t * RREC;
             const double wr = rec[12];
-            if (v0 > v1) { h = wr * rec[r] * rec[6 + cc]; addr = sky<SP>(L, v0 * 6 + r, v1 * 6 + cc); }
-            else         { h = wr * rec[6 + r] * rec[cc]; addr = sky<SP>(L, v1 * 6 + r, v0 * 6 + cc); }
+            if (v0 > v1) { h = wr * rec[r] * rec[6 + cc]; addr = blk_off<SP>(L, v0, v1) + q; }
+            else         { h = wr * rec[6 + r] * rec[cc]; addr = blk_off<SP>(L, v1, v0) + q; }
         } else {
             const int e = t - nr;
             const int vi = L.s_idx[4 * e], vj = L.s_idx[4 * e + 1];
-            const double* rec = L.srec + e * SREC;
-            const double *J0 = rec, *J1 = rec + 36, *WJ0 = rec + 72, *WJ1 = rec + 108;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) h += (vi > vj) ? J0[i * 6 + r] * WJ1[i * 6 + cc] : J1[i * 6 + r] * WJ0[i * 6 + cc];  // rows of the later pose
-            addr = (vi > vj) ? sky<SP>(L, vi * 6 + r, vj * 6 + cc) : sky<SP>(L, vj * 6 + r, vi * 6 + cc);
+            h = L.srec[e * SREC + S_OFF + q];
+            addr = (vi > vj ? blk_off<SP>(L, vi, vj) : blk_off<SP>(L, vj, vi)) + q;
         }
         return h;
     };
@@ -724,7 +837,7 @@ __device__ __forceinline__ void build_system(const Lds& L, int lane, int n, int 
         const int t = task / 36, q = task - 36 * t;
         if (t < nr && L.r_idx[2 * t + 1] < 0) continue;  // a range to a fixed anchor has no off-diagonal block
         int addr;
-        const double h = offdiag(t, q / 6, q - 6 * (q / 6), addr);
+        const double h = offdiag(t, q, addr);
         L.Hs[addr] = h;   // (for a pair with several edges this is overwritten below)
     }
     __syncthreads();
@@ -736,7 +849,7 @@ __device__ __forceinline__ void build_system(const Lds& L, int lane, int n, int 
         const bool first = (code >> INC_KIND_SHIFT) != 0;
         if (lane < 36) {
             int addr;
-            const double h = offdiag(t, lane / 6, lane % 6, addr);
+            const double h = offdiag(t, lane, addr);
             L.Hs[addr] = first ? h : L.Hs[addr] + h;
         }
     }
@@ -902,10 +1015,137 @@ __device__ __forceinline__ bool factor_and_solve(const Lds& L, int lane, int n, 
 //            the factor), then  diagonal rows store their row of G_J;  the others form their 6-entry segment
 //            S = H_iJ - sum_{K in row i and row J} L_iK L_JK^T  and finish it with the 6x6 triangular solve.
 //   Back-substitution walks the levels downwards, one lane per column (a gather over the column's blocks).
+constexpr int WIDE_LEVEL = 12;  // columns per level from which one lane takes a whole column (below: one lane per row)
 __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, double lambda) {
     for (int l = 0; l < L.nlev; ++l) {
         const int c0 = L.lvl_col[l], ncol = L.lvl_col[l + 1] - c0;
         const int b0 = L.lvl_blk[l], nblk = L.lvl_blk[l + 1] - b0;
+        if (ncol >= WIDE_LEVEL) {
+            // A wide level (the leaves of a tree: BASELINE config 5's 56 non-key poses): ONE LANE PER COLUMN does the whole
+            // column — diagonal block, its Cholesky factor, the right-hand side and every off-diagonal block — so G_J is
+            // factored once instead of once per row, and the level costs one pass and one barrier.
+            LOCAMD_TIC();
+            bool okw = true;
+            for (int base = 0; base < ncol; base += 64) {
+                const int idx = base + lane;
+                if (idx < ncol) {
+                    const int J = L.colorder[c0 + idx];
+                    const u64 rmJ = L.rowmask[J], belowJ = (1ull << J) - 1;
+                    const int rowJ = L.boff[J], dJ = L.boff[J + 1] - 36;
+                    const int nK = (dJ - rowJ) / 36;
+                    double G[6][6], ig[6], y[6];
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) {
+#pragma unroll
+                        for (int c = 0; c <= r; ++c) G[r][c] = L.Hs[dJ + 6 * c + r];
+                        G[r][r] += lambda;
+                        y[r] = L.b[6 * J + r];
+                    }
+                    {
+                        u64 m = rmJ & belowJ;
+                        for (int kb = 0; kb < nK; ++kb) {
+                            const int K = __ffsll((long long)m) - 1;
+                            m &= m - 1;
+                            const double* blk = L.Ls + rowJ + 36 * kb;
+                            double bl[36], yk[6];
+#pragma unroll
+                            for (int q = 0; q < 36; ++q) bl[q] = blk[q];
+#pragma unroll
+                            for (int k = 0; k < 6; ++k) yk[k] = L.yrow[6 * K + k];
+#pragma unroll
+                            for (int r = 0; r < 6; ++r) {
+#pragma unroll
+                                for (int c = 0; c <= r; ++c) {
+                                    double acc = 0.0;
+#pragma unroll
+                                    for (int k = 0; k < 6; ++k) acc = __builtin_fma(bl[6 * k + r], bl[6 * k + c], acc);
+                                    G[r][c] -= acc;
+                                }
+                                double acc = 0.0;
+#pragma unroll
+                                for (int k = 0; k < 6; ++k) acc = __builtin_fma(bl[6 * k + r], yk[k], acc);
+                                y[r] -= acc;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        double dj = G[j][j];
+#pragma unroll
+                        for (int k = 0; k < j; ++k) dj = __builtin_fma(-G[j][k], G[j][k], dj);
+                        okw = okw && (dj > 0.0) && (dj < DBL_MAX);
+                        double g, igj;
+                        sqrt_and_rsqrt(fmax(dj, 1e-300), g, igj);
+                        igj = __builtin_fma(igj, __builtin_fma(-g, igj, 1.0), igj);
+                        ig[j] = igj;
+#pragma unroll
+                        for (int i2 = j + 1; i2 < 6; ++i2) {
+                            double v = G[i2][j];
+#pragma unroll
+                            for (int k = 0; k < j; ++k) v = __builtin_fma(-G[i2][k], G[j][k], v);
+                            G[i2][j] = v * igj;
+                        }
+                        L.diagL[6 * J + j] = igj;
+                    }
+#pragma unroll
+                    for (int r = 1; r < 6; ++r)
+#pragma unroll
+                        for (int c = 0; c < r; ++c) L.Ls[dJ + 6 * c + r] = G[r][c];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {
+                        double v = y[c];
+#pragma unroll
+                        for (int k = 0; k < c; ++k) v = __builtin_fma(-y[k], G[c][k], v);
+                        y[c] = v * ig[c];
+                        L.yrow[6 * J + c] = y[c];
+                    }
+                    u64 mi = L.colmask[J];
+                    while (mi) {
+                        const int i = __ffsll((long long)mi) - 1;
+                        mi &= mi - 1;
+                        const u64 rmi = L.rowmask[i];
+                        const int rowi = L.boff[i];
+                        const int bi = rowi + 36 * __popcll(rmi & belowJ);
+                        double S[36];
+#pragma unroll
+                        for (int q = 0; q < 36; ++q) S[q] = L.Hs[bi + q];
+                        u64 m = rmi & rmJ & belowJ;
+                        while (m) {
+                            const int K = __ffsll((long long)m) - 1;
+                            m &= m - 1;
+                            const u64 belowK = (1ull << K) - 1;
+                            const double* bki = L.Ls + rowi + 36 * __popcll(rmi & belowK);
+                            const double* bkj = L.Ls + rowJ + 36 * __popcll(rmJ & belowK);
+                            for (int k = 0; k < 6; ++k) {
+                                double li[6], lj[6];
+#pragma unroll
+                                for (int r = 0; r < 6; ++r) { li[r] = bki[6 * k + r]; lj[r] = bkj[6 * k + r]; }
+#pragma unroll
+                                for (int c = 0; c < 6; ++c)
+#pragma unroll
+                                    for (int r = 0; r < 6; ++r) S[6 * c + r] = __builtin_fma(-li[r], lj[c], S[6 * c + r]);
+                            }
+                        }
+#pragma unroll
+                        for (int r = 0; r < 6; ++r) {
+                            double x[6];
+#pragma unroll
+                            for (int c = 0; c < 6; ++c) {
+                                double v = S[6 * c + r];
+#pragma unroll
+                                for (int k = 0; k < c; ++k) v = __builtin_fma(-x[k], G[c][k], v);
+                                x[c] = v * ig[c];
+                                L.Ls[bi + 6 * c + r] = x[c];
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            LOCAMD_TOC(4);
+            if (__ballot(!okw)) return false;
+            continue;
+        }
         LOCAMD_TIC();
         for (int base = 0; base < 6 * ncol; base += 64) {
             const int idx = base + lane;
@@ -1109,8 +1349,10 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
 // GLOBAL_A: the main arrays (H, its factor, vectors, poses, records) live in an HBM workspace slice instead of LDS (large
 // windows); a workgroup is one wave on one CU, whose L1 is coherent for its own stores after the workgroup barrier.
 // JAC: range-edge Jacobians analytic (0) or g2o's central differences (1).  SP: SPARSE path (nv_max <= 64) or SKYLINE.
+// (launch bounds: at least two waves per SIMD, i.e. at most 256 registers — a few rarely used values spill to scratch, which
+//  costs far less than the halved occupancy a 257th register would)
 template <bool GLOBAL_A, int JAC, bool SP>
-__global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
+__global__ void __launch_bounds__(64, 2) window_lm_kernel(const WindowArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int inst = blockIdx.x;
     const int lane = threadIdx.x;
@@ -1141,11 +1383,8 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
     L.rrec = p; p += c.nr_max * RREC;
     L.prec = p; p += c.np_max * PREC;
     L.srec = p; p += c.ns_max * SREC;
-    L.ilist = reinterpret_cast<int*>(p); p += ints_as_doubles(window_incidences(c));
-    L.shared = reinterpret_cast<int*>(p); p += ints_as_doubles((size_t)c.nr_max + c.ns_max + 1);
-    L.r_idx = reinterpret_cast<int32_t*>(p); p += ints_as_doubles(2 * (size_t)c.nr_max);
-    L.p_idx = reinterpret_cast<int32_t*>(p); p += ints_as_doubles((size_t)c.np_max);
-    L.s_idx = reinterpret_cast<int32_t*>(p); p += ints_as_doubles(4 * (size_t)c.ns_max);
+    double* const p_index = p;  // (index tables: here, or in LDS — below)
+    p += window_index_doubles(c);
     // the small index tables stay in LDS even when everything else is in the HBM workspace: every address in the sweep and
     // in the edge fold starts with a lookup in them, and an HBM round trip there is pure latency
     {
@@ -1166,6 +1405,12 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
             L.fb = ti; L.last = ti + c.nv_max; L.boff = ti + 2 * c.nv_max; L.ioff = ti + 3 * c.nv_max + 1;
             L.rowmask = L.colmask = L.scr = nullptr; L.perm = L.lvl_col = L.lvl_blk = L.colorder = L.otask = nullptr;
         }
+        double* q = GLOBAL_A && window_index_in_lds(c) ? lds + (window_table_bytes(c) + 7) / 8 : p_index;
+        L.ilist = reinterpret_cast<int*>(q); q += ints_as_doubles(window_incidences(c));
+        L.shared = reinterpret_cast<int*>(q); q += ints_as_doubles((size_t)c.nr_max + c.ns_max + 1);
+        L.r_idx = reinterpret_cast<int32_t*>(q); q += ints_as_doubles(2 * (size_t)c.nr_max);
+        L.p_idx = reinterpret_cast<int32_t*>(q); q += ints_as_doubles((size_t)c.np_max);
+        L.s_idx = reinterpret_cast<int32_t*>(q);
         if (!GLOBAL_A) p += (window_table_bytes(c) + 7) / 8;
     }
     L.nlev = 0;
@@ -1208,7 +1453,7 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
         for (int i = lane; i < nv * 12; i += 64) L.pose[i] = gpose_in[i];
     }
     __syncthreads();
-    compute_incidence<SP>(L, lane, nv, nr, np, ns, reinterpret_cast<int*>(L.x));
+    compute_incidence<SP>(L, lane, nv, nr, np, ns);
 
     constexpr double tau = 1e-5, good_lo = 1.0 / 3.0, good_hi = 2.0 / 3.0;
     constexpr int max_trials = 10;
@@ -1320,7 +1565,7 @@ __global__ void __launch_bounds__(64) window_lm_kernel(const WindowArgs a) {
 
 size_t window_lds_bytes(const WindowCaps& c, bool global_a) {
     // (+ the static 6x6 exchange block)
-    if (global_a) return window_table_bytes(c);
+    if (global_a) return (window_table_bytes(c) + 7) / 8 * 8 + (window_index_in_lds(c) ? window_index_doubles(c) * 8 : 0);
     const size_t staged = (size_t)c.nr_max * 5 + (size_t)c.np_max * 18 + (size_t)c.ns_max * 48;
     return (window_instance_doubles(c) + (window_table_bytes(c) + 7) / 8 + staged) * sizeof(double);
 }

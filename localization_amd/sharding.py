@@ -22,6 +22,18 @@ def shard_array(x, rank, world, axis=-1):
     return x[tuple(idx)]
 
 
+def shard_window_batch(wb, rank, world):
+    """The contiguous slice of a WindowBatch's instances owned by `rank` (windows / hypotheses are independent problems:
+    SURVEY §8(e) — cfg5: 2 048 windows per GPU at G = 8, cfg4: 128 hypotheses per GPU).  Returns (shard, lo, hi)."""
+    from .window import WindowBatch
+    lo, hi = shard_bounds(wb.B, rank, world)
+    part = WindowBatch(max(hi - lo, 1), *wb.caps)
+    part.B = hi - lo
+    for name in ("counts", "poses", "r_idx", "r_val", "p_idx", "p_val", "s_idx", "s_val", "result"):
+        getattr(part, name)[: hi - lo] = getattr(wb, name)[lo:hi]
+    return part, lo, hi
+
+
 def barrier_and_max(elapsed_s, device=None):
     """barrier, then the max of `elapsed_s` over ranks (the whole job is as slow as its slowest rank)."""
     import torch

@@ -180,6 +180,27 @@ def test_written_bag_round_trips_through_the_reader(tmp_path, compression):
     assert all(a["record_time"] <= b["record_time"] for a, b in zip(ev, ev[1:]))
 
 
+def test_associate_matches_the_reference_rule_on_dense_stamps():
+    """script/associate.py:86-97 restated by brute force (all pairs inside max_difference, sorted by (difference, a, b),
+    greedy): with stamps denser than max_difference a stamp whose two nearest partners are taken still gets the third."""
+    from localization_amd import ate
+    rng = np.random.default_rng(2)
+    for trial in range(20):
+        a = np.sort(rng.uniform(0, 1.0, 60)); b = np.sort(rng.uniform(0, 1.0, 80))
+        md, off = 0.02, 0.003 * trial
+        pot = sorted((abs(x - (y + off)), x, y) for x in a for y in b if abs(x - (y + off)) < md)
+        fa, fb, want = set(a), set(b), []
+        for _, x, y in pot:
+            if x in fa and y in fb:
+                fa.remove(x); fb.remove(y); want.append((x, y))
+        want.sort()
+        got = [(a[i], b[j]) for i, j in ate.associate(a, b, off, md)]
+        assert got == want
+    # the case the two-nearest shortcut dropped: b's nearest two taken by closer a's, a third still inside the window
+    a = np.array([0.000, 0.004, 0.012]); b = np.array([0.001, 0.005, 0.030])
+    assert ate.associate(a, b, 0.0, 0.02) == [(0, 0), (1, 1), (2, 2)]
+
+
 def test_shim_header_compiles_standalone(tmp_path):
     src = tmp_path / "shim_use.cpp"
     src.write_text('#include "localization_amd_shim.hpp"\n'

@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-from localization_amd.sharding import all_gather_results, all_reduce_scalars, barrier_and_max, shard_array, shard_bounds
+from localization_amd.sharding import all_gather_results, all_reduce_scalars, barrier_and_max, shard_array, shard_bounds, shard_window_batch
 
 
 def test_shard_bounds_cover_batch_exactly():
@@ -67,3 +67,42 @@ def test_two_rank_shard_equals_single_process(tmp_path, B):
     assert np.array_equal(got["pos"], pos) and np.array_equal(got["chi2"], chi2)
     assert got["tot"][0] == pytest.approx(chi2.sum(), rel=1e-12) and got["tot"][1] == trials.sum()
     assert float(got["t"]) == pytest.approx(0.2)
+
+
+def _window_worker(rank, world, port, B, out_path):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "perf"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench_window as bw
+    from _oracle_window import oracle_solve_instance
+    wb, _, anchors, T = bw.build_pose64(B, np.random.default_rng(5), T=12, n_graphs=0)
+    part, lo, hi = shard_window_batch(wb, rank, world)
+    poses = np.zeros((hi - lo, T, 12)); chi2 = np.zeros(hi - lo)
+    for i in range(hi - lo):
+        poses[i], chi2[i], _ = oracle_solve_instance(part, i, anchors)
+    full_pose = all_gather_results(torch.from_numpy(poses), B, axis=0)
+    full_chi = all_gather_results(torch.from_numpy(chi2), B, axis=0)
+    if rank == 0:
+        np.savez(out_path, poses=full_pose.numpy(), chi2=full_chi.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [6, 5])
+def test_two_rank_window_shard_equals_single_process(tmp_path, B):
+    """cfg5 / cfg4 style sharding: a WindowBatch split by instance over two gloo ranks, each rank solving its
+    windows independently (the oracle standing in for the device), poses and chi2 all-gathered: bit-identical to one process."""
+    from oracle import oracle as O
+    O.build()
+    sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "perf"))
+    import bench_window as bw
+    from _oracle_window import oracle_solve_instance
+    out = str(tmp_path / "gathered_windows.npz")
+    mp.start_processes(_window_worker, args=(2, _free_port(), B, out), nprocs=2, join=True, start_method="spawn")
+    got = np.load(out)
+    wb, _, anchors, T = bw.build_pose64(B, np.random.default_rng(5), T=12, n_graphs=0)
+    for i in range(B):
+        p, c, _ = oracle_solve_instance(wb, i, anchors)
+        assert np.array_equal(got["poses"][i], p) and got["chi2"][i] == c
+    part, lo, hi = shard_window_batch(wb, 1, 2)
+    assert (lo, hi) == (-(-B // 2), B) and np.array_equal(part.s_val[: hi - lo], wb.s_val[lo:hi])
