@@ -171,6 +171,10 @@ struct Lds {
     int *colorder;          //   block columns sorted by level
     int *otask;             //   off-diagonal blocks (i << 8 | J) sorted by the level of J
     int nlev;
+    u64 colmode;            //   bit l: level l is factored one lane per column (every column has <= 1 off-diagonal block, or the level is wide)
+    u64 pushmask;           //   bit K: column K has exactly one off-diagonal block (i, K) and is factored in column mode: its lane
+                            //   also forms the update U_K = L_iK L_iK^T, u_K = L_iK y_K that the parent i subtracts ("pushed")
+    double *Us, *As;        //   per column 28 doubles: pushed update (U lower triangle 21, u 6); per column: the sum of its children's
     int *ioff, *ilist;      // per pose: its incident edges in fold order (CSR), entry = kind << 28 | role << 27 | edge
     int *shared;            // [0] = count, then the binary edges (range e, or nr + SE3 e) whose pair of poses has another edge, in fold order
     double* blk; // 6x6 scratch: the diagonal block being factored (SKYLINE path)
@@ -516,7 +520,7 @@ __host__ __device__ inline bool window_index_in_lds(const WindowCaps& c) { retur
 __host__ __device__ inline size_t window_instance_doubles(const WindowCaps& c) {
     const size_t n_max = 6 * (size_t)c.nv_max;
     return 2 * sky_nnz_bound(c.nv_max, c.bw_max) + 4 * n_max + 2 * (size_t)c.nv_max * 12 + (size_t)c.nr_max * RREC + (size_t)c.np_max * PREC +
-           (size_t)c.ns_max * SREC + window_index_doubles(c);
+           (size_t)c.ns_max * SREC + window_index_doubles(c) + (window_sparse_path(c) ? 56 * (size_t)c.nv_max : 0);
 }
 // bytes of the small index tables that always live in LDS
 __host__ __device__ inline size_t window_table_bytes(const WindowCaps& c) {
@@ -539,6 +543,7 @@ __device__ __forceinline__ int sky(const Lds& L, int row, int col) {
     return blk_off<SP>(L, i, K) + 6 * (col - 6 * K) + (row - 6 * i);
 }
 
+constexpr int WIDE_LEVEL = 12;  // columns per level from which one lane takes a whole column whatever the columns look like
 constexpr int INC_KIND_SHIFT = 28, INC_ROLE_SHIFT = 27, INC_EDGE_MASK = (1 << 27) - 1;
 
 __device__ __forceinline__ int wave_min_i(int v) {
@@ -658,17 +663,26 @@ __device__ __forceinline__ int compute_sparse(Lds& L, int lane, int nv, int nv_m
     }
     const int nlev = wave_max_i(lane < nv ? lev : 0) + 1;
     int rank = 0, base = 0;
+    const int nbc = __popcll(mycol);  // off-diagonal blocks in my column
+    u64 colmode = 0, pushmask = 0;
     for (int l = 0; l < nlev; ++l) {
-        const u64 bl = __ballot(lane < nv && lev == l);
+        const bool mine = lane < nv && lev == l;
+        const u64 bl = __ballot(mine);
         if (lane == 0) L.lvl_col[l] = base;
-        if (lane < nv && lev == l) rank = base + __popcll(bl & below);
+        if (mine) rank = base + __popcll(bl & below);
         base += __popcll(bl);
+        // column mode: every column of the level has at most one off-diagonal block (trees, chains), or the level is wide
+        if (__ballot(mine && nbc > 1) == 0 || __popcll(bl) >= WIDE_LEVEL) {
+            colmode |= 1ull << l;
+            pushmask |= __ballot(mine && nbc == 1);
+        }
     }
+    L.colmode = colmode;
+    L.pushmask = pushmask;
     if (lane == 0) L.lvl_col[nlev] = base;
     if (lane < nv) L.colorder[rank] = lane;
     // off-diagonal blocks of the columns, in level order
     int* tmp = reinterpret_cast<int*>(L.scr);  // 2 nv_max ints
-    const int nbc = __popcll(mycol);
     __syncthreads();
     if (lane < nv) tmp[rank] = nbc;
     __syncthreads();
@@ -1015,15 +1029,49 @@ __device__ __forceinline__ bool factor_and_solve(const Lds& L, int lane, int n, 
 //            the factor), then  diagonal rows store their row of G_J;  the others form their 6-entry segment
 //            S = H_iJ - sum_{K in row i and row J} L_iK L_JK^T  and finish it with the 6x6 triangular solve.
 //   Back-substitution walks the levels downwards, one lane per column (a gather over the column's blocks).
-constexpr int WIDE_LEVEL = 12;  // columns per level from which one lane takes a whole column (below: one lane per row)
+// Pushed updates: a column K with exactly one off-diagonal block (i, K) that is factored in column mode leaves
+// U_K = L_iK L_iK^T (lower triangle, 21) and u_K = L_iK y_K (6) in Us[28 K ..]; its parent i then subtracts 27 numbers instead of
+// re-forming the products from the 36-entry block (and, with the arrays in the HBM workspace, the sums over a parent's children
+// are formed first by a wave-parallel reduction step — one lane per (parent, entry), four loads in flight — so a key pose with
+// eight children costs two memory round trips, not eight).
+template <bool GLOBAL_A>
 __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, double lambda) {
     for (int l = 0; l < L.nlev; ++l) {
         const int c0 = L.lvl_col[l], ncol = L.lvl_col[l + 1] - c0;
         const int b0 = L.lvl_blk[l], nblk = L.lvl_blk[l + 1] - b0;
-        if (ncol >= WIDE_LEVEL) {
-            // A wide level (the leaves of a tree: BASELINE config 5's 56 non-key poses): ONE LANE PER COLUMN does the whole
-            // column — diagonal block, its Cholesky factor, the right-hand side and every off-diagonal block — so G_J is
-            // factored once instead of once per row, and the level costs one pass and one barrier.
+        if (GLOBAL_A) {
+            // reduction step: As[J] = sum over J's pushed children K (ascending) of Us[K], for the columns of this level
+            LOCAMD_TIC();
+            bool any = false;
+            for (int base = 0; base < 27 * ncol; base += 64) {
+                const int idx = base + lane;
+                if (idx < 27 * ncol) {
+                    const int J = L.colorder[c0 + idx / 27], e = idx % 27;
+                    u64 m = L.rowmask[J] & ((1ull << J) - 1) & L.pushmask;
+                    if (m) {
+                        any = true;
+                        double acc = 0.0;
+                        while (m) {
+                            // four children per round: the loads are independent, the sum stays in ascending order
+                            double v[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                v[u] = 0.0;
+                                if (m) { const int K = __ffsll((long long)m) - 1; m &= m - 1; v[u] = L.Us[28 * K + e]; }
+                            }
+                            acc = ((acc + v[0]) + v[1]) + v[2];
+                            acc += v[3];
+                        }
+                        L.As[28 * J + e] = acc;
+                    }
+                }
+            }
+            if (__ballot(any)) __syncthreads();
+            LOCAMD_TOC(3);
+        }
+        if ((L.colmode >> l) & 1ull) {
+            // COLUMN MODE: one lane does the whole column — diagonal block, its Cholesky factor, the right-hand side, the
+            // off-diagonal block(s) and the pushed update — so G_J is factored once and the level costs one pass, one barrier.
             LOCAMD_TIC();
             bool okw = true;
             for (int base = 0; base < ncol; base += 64) {
@@ -1041,11 +1089,30 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
                         G[r][r] += lambda;
                         y[r] = L.b[6 * J + r];
                     }
+                    if (GLOBAL_A && (rmJ & belowJ & L.pushmask)) {
+#pragma unroll
+                        for (int r = 0; r < 6; ++r) {
+#pragma unroll
+                            for (int c = 0; c <= r; ++c) G[r][c] -= L.As[28 * J + r * (r + 1) / 2 + c];
+                            y[r] -= L.As[28 * J + 21 + r];
+                        }
+                    }
                     {
                         u64 m = rmJ & belowJ;
                         for (int kb = 0; kb < nK; ++kb) {
                             const int K = __ffsll((long long)m) - 1;
                             m &= m - 1;
+                            if ((L.pushmask >> K) & 1ull) {
+                                if (!GLOBAL_A) {
+#pragma unroll
+                                    for (int r = 0; r < 6; ++r) {
+#pragma unroll
+                                        for (int c = 0; c <= r; ++c) G[r][c] -= L.Us[28 * K + r * (r + 1) / 2 + c];
+                                        y[r] -= L.Us[28 * K + 21 + r];
+                                    }
+                                }
+                                continue;
+                            }
                             const double* blk = L.Ls + rowJ + 36 * kb;
                             double bl[36], yk[6];
 #pragma unroll
@@ -1099,7 +1166,9 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
                         y[c] = v * ig[c];
                         L.yrow[6 * J + c] = y[c];
                     }
-                    u64 mi = L.colmask[J];
+                    const u64 cmJ = L.colmask[J];
+                    const bool push = (L.pushmask >> J) & 1ull;   // exactly one off-diagonal block
+                    u64 mi = cmJ;
                     while (mi) {
                         const int i = __ffsll((long long)mi) - 1;
                         mi &= mi - 1;
@@ -1128,14 +1197,30 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
                         }
 #pragma unroll
                         for (int r = 0; r < 6; ++r) {
-                            double x[6];
 #pragma unroll
                             for (int c = 0; c < 6; ++c) {
                                 double v = S[6 * c + r];
 #pragma unroll
-                                for (int k = 0; k < c; ++k) v = __builtin_fma(-x[k], G[c][k], v);
-                                x[c] = v * ig[c];
-                                L.Ls[bi + 6 * c + r] = x[c];
+                                for (int k = 0; k < c; ++k) v = __builtin_fma(-S[6 * k + r], G[c][k], v);
+                                v *= ig[c];
+                                S[6 * c + r] = v;          // S becomes X = L_iJ, entry (r, c)
+                                L.Ls[bi + 6 * c + r] = v;
+                            }
+                        }
+                        if (push) {
+#pragma unroll
+                            for (int r = 0; r < 6; ++r) {
+#pragma unroll
+                                for (int c = 0; c <= r; ++c) {
+                                    double acc = 0.0;
+#pragma unroll
+                                    for (int k = 0; k < 6; ++k) acc = __builtin_fma(S[6 * k + r], S[6 * k + c], acc);
+                                    L.Us[28 * J + r * (r + 1) / 2 + c] = acc;
+                                }
+                                double acc = 0.0;
+#pragma unroll
+                                for (int k = 0; k < 6; ++k) acc = __builtin_fma(S[6 * k + r], y[k], acc);
+                                L.Us[28 * J + 21 + r] = acc;
                             }
                         }
                     }
@@ -1156,7 +1241,21 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
 #pragma unroll
                 for (int c = 0; c < 6; ++c) S[c] = c <= r ? L.Hs[dJ + 6 * c + r] : 0.0;
                 const int nK = (dJ - rowJ) / 36;
+                u64 mK = L.rowmask[J] & ((1ull << J) - 1);
+                if (GLOBAL_A && (mK & L.pushmask)) {   // the pushed children's updates were summed by the reduction step
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) if (c <= r) S[c] -= L.As[28 * J + r * (r + 1) / 2 + c];
+                }
                 for (int kb = 0; kb < nK; ++kb) {
+                    const int K = __ffsll((long long)mK) - 1;
+                    mK &= mK - 1;
+                    if ((L.pushmask >> K) & 1ull) {
+                        if (!GLOBAL_A) {
+#pragma unroll
+                            for (int c = 0; c < 6; ++c) if (c <= r) S[c] -= L.Us[28 * K + r * (r + 1) / 2 + c];
+                        }
+                        continue;
+                    }
                     const double* blk = L.Ls + rowJ + 36 * kb;
                     double li[6];
 #pragma unroll
@@ -1226,11 +1325,22 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
 #pragma unroll
                     for (int c = 0; c < 6; ++c) S[c] = L.b[6 * J + c];
                     u64 m = L.rowmask[J] & ((1ull << J) - 1);
+                    if (GLOBAL_A && (m & L.pushmask)) {
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) S[c] -= L.As[28 * J + 21 + c];
+                    }
                     int kb = 0;
                     while (m) {
                         const int K = __ffsll((long long)m) - 1;
                         m &= m - 1;
                         const double* bkj = L.Ls + rowJ + 36 * kb++;
+                        if ((L.pushmask >> K) & 1ull) {
+                            if (!GLOBAL_A) {
+#pragma unroll
+                                for (int c = 0; c < 6; ++c) S[c] -= L.Us[28 * K + 21 + c];
+                            }
+                            continue;
+                        }
                         double li[6];
 #pragma unroll
                         for (int k = 0; k < 6; ++k) li[k] = L.yrow[6 * K + k];
@@ -1385,6 +1495,8 @@ __global__ void __launch_bounds__(64, 2) window_lm_kernel(const WindowArgs a) {
     L.srec = p; p += c.ns_max * SREC;
     double* const p_index = p;  // (index tables: here, or in LDS — below)
     p += window_index_doubles(c);
+    L.Us = p; L.As = p + 28 * c.nv_max;
+    if (SP) p += 56 * c.nv_max;
     // the small index tables stay in LDS even when everything else is in the HBM workspace: every address in the sweep and
     // in the edge fold starts with a lookup in them, and an HBM round trip there is pure latency
     {
@@ -1494,7 +1606,7 @@ __global__ void __launch_bounds__(64, 2) window_lm_kernel(const WindowArgs a) {
 #ifdef LOCAMD_WINDOW_TIMING
             const long long locamd_tf = clock64();
 #endif
-            const bool ok2 = SP ? factor_and_solve_sparse(L, lane, lambda) : factor_and_solve(L, lane, n, lambda);
+            const bool ok2 = SP ? factor_and_solve_sparse<GLOBAL_A>(L, lane, lambda) : factor_and_solve(L, lane, n, lambda);
 #ifdef LOCAMD_WINDOW_TIMING
             if (!SP && lane == 0) L.tim[3] += clock64() - locamd_tf;  // SKYLINE: the whole sweep incl. back-substitution (slot 5)
 #endif
