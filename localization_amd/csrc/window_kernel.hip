@@ -222,8 +222,13 @@ __device__ __forceinline__ double range_jac_numeric(const double* X0, const doub
 }
 #pragma clang fp contract(fast)
 
+template <bool SP>
+__device__ __forceinline__ int blk_off(const Lds& L, int i, int K);
+
 // Evaluate every edge at the current poses: errors + chi sums always, Jacobian/weight records when FULL.
-template <bool FULL, int JAC>
+// (FULL: the caller has zeroed H; an SE3 edge that is alone on its pair of poses — s_idx[4 e + 3] == 0, set once per solve —
+//  writes its off-diagonal block straight into H, the others leave it in their record for the ordered accumulation.)
+template <bool FULL, int JAC, bool SP>
 __device__ __forceinline__ void evaluate_edges(const WindowArgs& a, const Lds& L, int inst, int lane, int nr, int np, int ns,
                                double& robust_chi, double& plain_chi) {
     (void)inst;
@@ -427,6 +432,7 @@ __device__ __forceinline__ void evaluate_edges(const WindowArgs& a, const Lds& L
                     for (int i = 0; i < LOCAMD_J0_HI(r); ++i) h += J0[i * 6 + r] * WJ[i * 6 + cc];
                     rec[r * (r + 1) / 2 + cc] = h;
                 }
+            double* const hoff = idx[3] ? rec + S_OFF : L.Hs + blk_off<SP>(L, max(vi, vj), min(vi, vj));
             if (vj > vi) {
 #pragma unroll
                 for (int r = 0; r < 6; ++r)
@@ -435,7 +441,7 @@ __device__ __forceinline__ void evaluate_edges(const WindowArgs& a, const Lds& L
                         double h = 0.0;
 #pragma unroll
                         for (int i = LOCAMD_J1_LO(r); i < LOCAMD_J1_HI(r); ++i) h += J1[i * 6 + r] * WJ[i * 6 + cc];
-                        rec[S_OFF + 6 * cc + r] = h;
+                        hoff[6 * cc + r] = h;
                     }
             }
 #pragma unroll
@@ -464,7 +470,7 @@ __device__ __forceinline__ void evaluate_edges(const WindowArgs& a, const Lds& L
                         double h = 0.0;
 #pragma unroll
                         for (int i = 0; i < LOCAMD_J0_HI(r); ++i) h += J0[i * 6 + r] * WJ[i * 6 + cc];
-                        rec[S_OFF + 6 * cc + r] = h;
+                        hoff[6 * cc + r] = h;
                     }
             }
 #pragma unroll
@@ -520,8 +526,10 @@ __host__ __device__ inline bool window_index_in_lds(const WindowCaps& c) { retur
 __host__ __device__ inline size_t window_instance_doubles(const WindowCaps& c) {
     const size_t n_max = 6 * (size_t)c.nv_max;
     return 2 * sky_nnz_bound(c.nv_max, c.bw_max) + 4 * n_max + 2 * (size_t)c.nv_max * 12 + (size_t)c.nr_max * RREC + (size_t)c.np_max * PREC +
-           (size_t)c.ns_max * SREC + window_index_doubles(c) + (window_sparse_path(c) ? 56 * (size_t)c.nv_max : 0);
+           (size_t)c.ns_max * SREC + window_index_doubles(c);
 }
+// workspace mode only: the pushed updates and their per-parent sums (28 doubles per column each)
+__host__ __device__ inline size_t window_push_doubles(const WindowCaps& c) { return window_sparse_path(c) ? 56 * (size_t)c.nv_max : 0; }
 // bytes of the small index tables that always live in LDS
 __host__ __device__ inline size_t window_table_bytes(const WindowCaps& c) {
     const size_t nv = (size_t)c.nv_max;
@@ -594,6 +602,7 @@ __device__ __forceinline__ void compute_skyline(const Lds& L, int lane, int nv, 
 //   3. relabel by elimination position; rowmask / colmask of the factor; block offsets; elimination-tree levels
 //      (level(J) = 1 + max level of the columns in row J); columns and off-diagonal blocks sorted by level.
 // Returns the number of blocks of the factor (the caller checks it against the capacity).
+template <bool PUSH>
 __device__ __forceinline__ int compute_sparse(Lds& L, int lane, int nv, int nv_max, int nb_max, int nr, int ns, bool natural) {
     if (lane < nv) L.scr[lane] = 0;
     __syncthreads();
@@ -674,7 +683,7 @@ __device__ __forceinline__ int compute_sparse(Lds& L, int lane, int nv, int nv_m
         // column mode: every column of the level has at most one off-diagonal block (trees, chains), or the level is wide
         if (__ballot(mine && nbc > 1) == 0 || __popcll(bl) >= WIDE_LEVEL) {
             colmode |= 1ull << l;
-            pushmask |= __ballot(mine && nbc == 1);
+            if (PUSH) pushmask |= __ballot(mine && nbc == 1);   // (in LDS the parent re-forms the product as cheaply as it loads it)
         }
     }
     L.colmode = colmode;
@@ -772,6 +781,7 @@ __device__ __forceinline__ void compute_incidence(const Lds& L, int lane, int nv
         const bool first = sh && L.Hs[a0] == (double)(t + 1);
         const u64 bal = __ballot(sh);
         if (sh) L.shared[1 + cnt + __popcll(bal & ((1ull << lane) - 1))] = (first ? (1 << INC_KIND_SHIFT) : 0) | t;
+        if (t >= nr && t < nbin) L.s_idx[4 * (t - nr) + 3] = sh ? 1 : 0;   // (evaluate_edges: who writes its block straight into H)
         cnt += __popcll(bal);
     }
     if (lane == 0) L.shared[0] = cnt;
@@ -787,9 +797,7 @@ __device__ __forceinline__ void compute_incidence(const Lds& L, int lane, int nv
 template <bool SP>
 __device__ __forceinline__ void build_system(const Lds& L, int lane, int n, int nr, int ns) {
     const int nv = n / 6;
-    const int nnz = L.boff[nv];
-    for (int i = lane; i < nnz; i += 64) L.Hs[i] = 0.0;
-    __syncthreads();
+    // (H was zeroed before the linearisation, which has already written the off-diagonal blocks of the unshared SE3 edges)
     // diagonal blocks and b: one lane per pose, its 21 + 6 sums in registers, ONE pass over the pose's incidence list — the
     // 27 loads of an incidence are independent of each other, so a list costs one memory round trip per edge, not per entry
     for (int v = lane; v < nv; v += 64) {
@@ -849,7 +857,7 @@ __device__ __forceinline__ void build_system(const Lds& L, int lane, int n, int 
     };
     for (int task = lane; task < (nr + ns) * 36; task += 64) {
         const int t = task / 36, q = task - 36 * t;
-        if (t < nr && L.r_idx[2 * t + 1] < 0) continue;  // a range to a fixed anchor has no off-diagonal block
+        if (t < nr ? L.r_idx[2 * t + 1] < 0 : L.s_idx[4 * (t - nr) + 3] == 0) continue;  // range to a fixed anchor: no block; unshared SE3 edge: written already
         int addr;
         const double h = offdiag(t, q, addr);
         L.Hs[addr] = h;   // (for a pair with several edges this is overwritten below)
@@ -1480,7 +1488,7 @@ __global__ void __launch_bounds__(64, 2) window_lm_kernel(const WindowArgs a) {
     const long long t_start = clock64();
 #endif
     // main arrays: LDS for small windows, this instance's slice of the HBM workspace (L1/L2-cached) for large ones
-    double* p = GLOBAL_A ? a.workspace + (size_t)inst * window_instance_doubles(c) : lds;
+    double* p = GLOBAL_A ? a.workspace + (size_t)inst * (window_instance_doubles(c) + window_push_doubles(c)) : lds;
     L.Hs = p; p += nnz_max;
     L.Ls = p; p += nnz_max;
     L.diagL = p; p += n_max;
@@ -1495,8 +1503,8 @@ __global__ void __launch_bounds__(64, 2) window_lm_kernel(const WindowArgs a) {
     L.srec = p; p += c.ns_max * SREC;
     double* const p_index = p;  // (index tables: here, or in LDS — below)
     p += window_index_doubles(c);
-    L.Us = p; L.As = p + 28 * c.nv_max;
-    if (SP) p += 56 * c.nv_max;
+    L.Us = p; L.As = p + 28 * c.nv_max;   // (only used, and only allocated, in workspace mode)
+    if (GLOBAL_A) p += window_push_doubles(c);
     // the small index tables stay in LDS even when everything else is in the HBM workspace: every address in the sweep and
     // in the edge fold starts with a lookup in them, and an HBM round trip there is pure latency
     {
@@ -1549,8 +1557,8 @@ __global__ void __launch_bounds__(64, 2) window_lm_kernel(const WindowArgs a) {
     double* gpose = a.poses + (size_t)inst * c.nv_max * 12;
     if (SP) {
         const int nb_max = (int)(nnz_max / 36);
-        int nb = compute_sparse(L, lane, nv, c.nv_max, nb_max, nr, ns, a.natural_order != 0);
-        if (nb > nb_max) { __syncthreads(); nb = compute_sparse(L, lane, nv, c.nv_max, nb_max, nr, ns, true); }  // (the natural order cannot exceed the envelope capacity)
+        int nb = compute_sparse<GLOBAL_A>(L, lane, nv, c.nv_max, nb_max, nr, ns, a.natural_order != 0);
+        if (nb > nb_max) { __syncthreads(); nb = compute_sparse<GLOBAL_A>(L, lane, nv, c.nv_max, nb_max, nr, ns, true); }  // (the natural order cannot exceed the envelope capacity)
         // relabel: pose slots -> elimination positions
         for (int e = lane; e < nr; e += 64) {
             L.r_idx[2 * e] = L.perm[L.r_idx[2 * e]];
@@ -1583,7 +1591,14 @@ __global__ void __launch_bounds__(64, 2) window_lm_kernel(const WindowArgs a) {
         double plain;
         {
             LOCAMD_TIC();
-            evaluate_edges<true, JAC>(a, L, inst, lane, nr, np, ns, cur_chi, plain);  // computeActiveErrors + linearize
+            const int nnz = L.boff[nv];
+            for (int i = lane; i < nnz; i += 64) L.Hs[i] = 0.0;
+            __syncthreads();
+            LOCAMD_TOC(2);
+        }
+        {
+            LOCAMD_TIC();
+            evaluate_edges<true, JAC, SP>(a, L, inst, lane, nr, np, ns, cur_chi, plain);  // computeActiveErrors + linearize
             last_plain = plain;
             __syncthreads();
             LOCAMD_TOC(1);
@@ -1633,7 +1648,7 @@ __global__ void __launch_bounds__(64, 2) window_lm_kernel(const WindowArgs a) {
             __syncthreads();
             ++trials;
             double temp_chi, plain2;
-            evaluate_edges<false, JAC>(a, L, inst, lane, nr, np, ns, temp_chi, plain2);
+            evaluate_edges<false, JAC, SP>(a, L, inst, lane, nr, np, ns, temp_chi, plain2);
             LOCAMD_TOC(6);
             last_plain = plain2;
             if (!ok2) temp_chi = DBL_MAX;
@@ -1681,7 +1696,7 @@ size_t window_lds_bytes(const WindowCaps& c, bool global_a) {
     const size_t staged = (size_t)c.nr_max * 5 + (size_t)c.np_max * 18 + (size_t)c.ns_max * 48;
     return (window_instance_doubles(c) + (window_table_bytes(c) + 7) / 8 + staged) * sizeof(double);
 }
-size_t window_workspace_doubles(const WindowCaps& c) { return window_instance_doubles(c); }
+size_t window_workspace_doubles(const WindowCaps& c) { return window_instance_doubles(c) + window_push_doubles(c); }
 
 template <bool GLOBAL_A, int JAC, bool SP>
 static hipError_t launch_window_t(const WindowArgs& a, size_t lds, hipStream_t stream) {

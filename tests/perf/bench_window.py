@@ -170,6 +170,8 @@ def main():
     ap.add_argument("--jacobian", default="analytic", choices=["analytic", "numeric"])
     ap.add_argument("--natural", action="store_true", help="windows of <= 64 poses: keep the caller's pose order (no in-kernel minimum-degree ordering)")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-window latency launches (profiling: one kernel shape only)")
+    ap.add_argument("--pmc-json", default=None, help="a tests/perf/pmc_summary.py output for THIS shape and batch: its f64 instruction counts "
+                    "(wave-instructions per launch, x 64 lanes; fma = 2 flop) give the f64 rate next to the HBM roofline")
     ap.add_argument("--cache", default=None, help="npz file: load the generated batch from it if it exists, else build and save "
                     "(profiling runs repeat the same command once per counter pass)")
     a = ap.parse_args()
@@ -215,7 +217,25 @@ def main():
         diff = float(np.abs(wb.poses[: len(cpu_t), :, 9:] - cpu_t).max())
     else:
         cpu_s, cpu_t, diff = float("nan"), [0], None
+    # roofline: algorithmic bytes per window as SURVEY §8(d) counts them for cfg5 (window state read + written, 56 B per pose each
+    # way, + one new measurement 232 B + chi2 8 B: 7 408 B at T = 64), priced against 8 TB/s; and, when PMC counts are given, the
+    # issued f64 lane-operations against the fp64 vector peak.  The kernel is latency / VALU-issue bound, not bandwidth bound.
+    algo_bytes = 2.0 * T * 56 + 240
+    ach = algo_bytes * a.batch / (k_ms * 1e-3) / 1e9
+    roof = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+            "algorithmic_bytes_per_window": algo_bytes, "kernel": "window_lm_kernel", "kernel_ms_avg": k_ms}
+    if a.pmc_json and os.path.exists(a.pmc_json):
+        pj = json.load(open(a.pmc_json))
+        lane_flop = 64.0 * (pj.get("SQ_INSTS_VALU_ADD_F64", 0) + pj.get("SQ_INSTS_VALU_MUL_F64", 0) + 2 * pj.get("SQ_INSTS_VALU_FMA_F64", 0)
+                            + pj.get("SQ_INSTS_VALU_TRANS_F64", 0))
+        tf = lane_flop / (k_ms * 1e-3) / 1e12
+        roof["valu_f64"] = {"issued_tflops": tf, "peak_tflops": 78.6, "frac": tf / 78.6,
+                            "note": "f64 VALU wave-instructions x 64 lanes (PMC; counts idle lanes too: an upper bound on useful flops)"}
+        if pj.get("FETCH_SIZE") is not None and pj.get("WRITE_SIZE") is not None:
+            roof["traffic"] = (2.0 * pj["FETCH_SIZE"] + pj["WRITE_SIZE"]) * 1024.0   # KB -> B, FETCH_SIZE x2 (gfx950, MI355X_MICROARCH.md)
+            roof["traffic_note"] = "HBM-side bytes per launch from PMC (FETCH_SIZE x 2 + WRITE_SIZE); uncalibrated for this access pattern"
     print(json.dumps({
+        "roofline": roof,
         "shape": a.shape, "poses_per_window": T, "unknowns": 6 * T, "batch": a.batch, "bw_max": bw, "lds_bytes_per_instance": solver.lds_bytes,
         "gpu_kernel_ms_per_batch": k_ms, "gpu_windows_per_s_kernel": a.batch / (k_ms * 1e-3),
         "gpu_windows_per_s_incl_pcie": a.batch / (w_ms * 1e-3),

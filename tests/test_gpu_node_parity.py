@@ -389,7 +389,10 @@ def test_rl_range_edges_match_oracle(gpu):
     from oracle import oracle as O
     ids = [1, 2, 3, 4]
     pos = np.array([[2.0, -2.0, 0.5], [2.0, 2.0, 1.5], [-2.0, 0.0, 1.0], [0.2, 0.1, 1.0]])
-    cfg = dict(trajectory_length=5, maximum_velocity=2.0, maximum_iteration=20, minimum_optimize_error=1e9,
+    # (cfg/RL_uwb.yaml runs 20 iterations; with every node free the constellation has a gauge freedom and LM then stops early on
+    #  rho == 0 / ten failed trials, a rounding-edge decision after which two correct implementations sit a few 1e-5 apart.  Four
+    #  iterations per message keep the comparison on the deterministic part: same graph, same factors, same LM steps.)
+    cfg = dict(trajectory_length=5, maximum_velocity=2.0, maximum_iteration=4, minimum_optimize_error=1e9,
                has_relative_range=True, publish_relative_range=True)
     node = la.LocalizationNode(ids, pos.ravel(), **cfg)
     ora = O.LocalizationOracle(ids, pos.ravel(), jac_mode=O.JAC_ANALYTIC, **cfg)
@@ -406,16 +409,13 @@ def test_rl_range_edges_match_oracle(gpu):
         v_meas = vel[a] + rng.normal(0, 0.02, 3)
         g = node.add_rl_range(ids[a], ids[b], t, d, v_meas)
         o = ora.add_rl_range(ids[a], ids[b], t, d, v_meas)
-        # (every node moves, nothing is fixed: the constellation has a free gauge, H is singular up to lambda and LM often stops
-        #  early on rho == 0 / ten failed trials — a decision at the rounding edge, so the iteration at which the two stop may
-        #  differ by one; the poses it leaves are converged either way)
-        assert g["solved"] and o["solved"] and abs(g["outer_iterations"] - o["outer_iterations"]) <= 2
+        assert g["solved"] and o["solved"] and g["outer_iterations"] == o["outer_iterations"]
         solves += 1
         worst = max(worst, np.abs(g["realtime"][1:4] - o["realtime"][1:4]).max())
         for nid in ids:
             worst = max(worst, np.abs(node.path(nid)[:, 1:4] - ora.path(nid)[:, 1:4]).max())
-        assert abs(g["chi2"] - o["chi2"]) <= 1e-5 * max(1.0, abs(o["chi2"])) + 1e-9
-    assert solves == 48 and worst < 1e-5, worst
+        assert abs(g["chi2"] - o["chi2"]) <= 1e-6 * max(1.0, abs(o["chi2"])) + 1e-9
+    assert solves == 48 and worst < 1e-6, worst
     node.close()
 
 

@@ -28,3 +28,6 @@ for P in "$P1" "$P2" "$P3" "$P4" "$P5"; do
 done
 python3 tests/perf/pmc_summary.py window_lm_kernel "$OUT"/pmc*_${SHAPE} > "$OUT/pmc_${SHAPE}_${BATCH}.json"
 cat "$OUT/pmc_${SHAPE}_${BATCH}.json"
+# the same run once more with the counters folded into its roofline record
+$BENCH --cpu-n 0 --pmc-json "$OUT/pmc_${SHAPE}_${BATCH}.json" > "$OUT/bench_roofline_${SHAPE}_${BATCH}.json"
+cat "$OUT/bench_roofline_${SHAPE}_${BATCH}.json"
