@@ -38,5 +38,53 @@ __device__ __forceinline__ void sqrt_and_rsqrt(double x, double& n, double& inv)
     inv = h + h;
 }
 
+// n = sqrt(x) to 4.1e-15 relative (the Goldschmidt step without the residual correction; profiles/r01_math_probe.txt) and
+// inv = 1/sqrt(x) to 4.2e-15:
+// the range norm of the analytic kernels, where 1e-14 m is five orders below anything the estimate resolves; two
+// instructions per range fewer than sqrt_and_rsqrt.
+__device__ __forceinline__ void sqrt_and_rsqrt_fast(double x, double& n, double& inv) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    n = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    inv = h + h;
+}
+
+// log(x) for x >= 1 (what the robust cost needs: 1 + chi, and products of such) — the kernel of fdlibm's e_log.c without the
+// argument classes that cannot occur: x = 2^k (1 + f) with sqrt(1/2) < 1 + f < sqrt(2), s = f / (2 + f),
+// log(1 + f) = f - hfsq + s (hfsq + R(s^2)), R a degree-7 minimax polynomial: < 1 ulp (checked against long-double log over
+// [1, 1e300], 7e6 samples: max 0.84 ulp).  About 40 instructions; the general-purpose library log is about 110, and it was a
+// fifth of every LM pass of the snapshot kernel.  inf and NaN pass through.
+__device__ __forceinline__ double fast_log_ge1(double x) {
+    constexpr double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                     Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                     Lg7 = 1.479819860511658591e-01;
+    constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+    int k = __builtin_amdgcn_frexp_exp(x);
+    const int small = m < 0.70710678118654752440 ? 1 : 0;
+    m = __builtin_amdgcn_ldexp(m, small);
+    k -= small;
+    const double f = m - 1.0;
+    const double dk = (double)k;
+    const double den = 2.0 + f;
+    double r = __builtin_amdgcn_rcp(den);
+    double e = __builtin_fma(-den, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-den, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double s = f * r;
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * __builtin_fma(w, __builtin_fma(w, Lg6, Lg4), Lg2);
+    const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, Lg7, Lg5), Lg3), Lg1);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double res = __builtin_fma(dk, ln2_hi, -((hfsq - __builtin_fma(s, hfsq + R, dk * ln2_lo)) - f));
+    return x <= 1.7976931348623157e308 ? res : x;
+}
+
 }  // namespace
 }  // namespace locamd

@@ -122,7 +122,7 @@ __device__ __forceinline__ Sys6 evaluate6(const Pose& X, const double (&ax)[M8],
             const double ux = p0x - ax[j], uy = p0y - ay[j], uz = p0z - az[j];
             const double n2 = fmax(ux * ux + uy * uy + uz * uz, 1e-300);
             double n, inv;
-            sqrt_and_rsqrt(n2, n, inv);
+            sqrt_and_rsqrt_fast(n2, n, inv);
             e = dj - n;
             const double vx = ux * inv, vy = uy * inv, vz = uz * inv;  // unit vector u
             // uR = R^T u
@@ -187,7 +187,7 @@ __device__ __forceinline__ Sys6 evaluate6(const Pose& X, const double (&ax)[M8],
         s.b[3 + r] = bb;
     }
     s.chi += pchi;
-    s.rchi = log(prod) + pchi;  // Cauchy on the ranges, plain chi2 on the prior
+    s.rchi = fast_log_ge1(prod) + pchi;  // Cauchy on the ranges, plain chi2 on the prior
     return s;
 }
 

@@ -103,7 +103,7 @@ __device__ __forceinline__ System evaluate(const double px, const double py, con
             // coincident endpoints: n2 = 0 is clamped, dx = dy = dz = 0 -> J = 0
             const double n2 = fmax(dx * dx + dy * dy + dz * dz, 1e-300);
             double inv;
-            sqrt_and_rsqrt(n2, n, inv);
+            sqrt_and_rsqrt_fast(n2, n, inv);
             jx = -dx * inv; jy = -dy * inv; jz = -dz * inv;
         } else {
             constexpr double delta = 1e-9;
@@ -134,7 +134,7 @@ __device__ __forceinline__ System evaluate(const double px, const double py, con
     s.h11 = group_sum<LPI>(s.h11); s.h12 = group_sum<LPI>(s.h12); s.h22 = group_sum<LPI>(s.h22);
     s.b0 = group_sum<LPI>(s.b0); s.b1 = group_sum<LPI>(s.b1); s.b2 = group_sum<LPI>(s.b2);
     s.chi = group_sum<LPI>(s.chi);
-    s.rchi = log(group_prod<LPI>(prod));
+    s.rchi = fast_log_ge1(group_prod<LPI>(prod));
     return s;
 }
 

@@ -251,7 +251,7 @@ __device__ __forceinline__ void evaluate_edges(const WindowArgs& a, const Lds& L
         const double err = JAC == 0 ? meas - n : range_error_plain(X0, X0 + 9, off, p1, meas);
         const double chi = err * (info * err);
         const double aux = 1.0 + chi;
-        rsum += log(aux);
+        rsum += fast_log_ge1(aux);
         csum += chi;
         if (FULL) {
             double* rec = L.rrec + e * RREC;
@@ -368,7 +368,7 @@ __device__ __forceinline__ void evaluate_edges(const WindowArgs& a, const Lds& L
             chi += err[i] * r;
         }
         const double aux = 1.0 + chi;
-        rsum += robust ? log(aux) : chi;
+        rsum += robust ? fast_log_ge1(aux) : chi;
         csum += chi;
         if (FULL) {
             double* rec = L.srec + e * SREC;
