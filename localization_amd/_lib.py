@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "liblocalization_amd.so")
+# (LOCALIZATION_AMD_LIB: an alternative build of the same library, for experiments such as the diagnostic timing build)
+_SO = os.environ.get("LOCALIZATION_AMD_LIB") or os.path.join(_HERE, "liblocalization_amd.so")
 _LIB = None
 
 LOC_OK = 0

@@ -1470,7 +1470,13 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
 // (launch bounds: at least two waves per SIMD, i.e. at most 256 registers — a few rarely used values spill to scratch, which
 //  costs far less than the halved occupancy a 257th register would)
 template <bool GLOBAL_A, int JAC, bool SP>
-__global__ void __launch_bounds__(64, 2) window_lm_kernel(const WindowArgs a) {
+// (experiment kept as a switch: forcing 3 or 4 waves per SIMD for the workspace-mode SPARSE kernel — 168 / 128 registers, 204 /
+//  484 values spilled to scratch — made BASELINE config 5 slower, 19.7 -> 26.0 / 33.1 ms per 16 384 windows: the extra waves do
+//  not pay for the spill traffic)
+#ifndef LOCAMD_WS_WAVES
+#define LOCAMD_WS_WAVES 2
+#endif
+__global__ void __launch_bounds__(64, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 2) window_lm_kernel(const WindowArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int inst = blockIdx.x;
     const int lane = threadIdx.x;
