@@ -31,3 +31,5 @@ for P in "$P1" "$P2" "FETCH_SIZE" "WRITE_SIZE"; do
 done
 python3 tests/perf/pmc_summary.py fusion_lm_kernel "$OUT"/pmc*_fusion > "$OUT/pmc_fusion.json"
 cat "$OUT/pmc_fusion.json"
+# keep the summaries only: the raw traces and counter CSVs are tens of MB (gpurun copies back at most 64 MiB)
+rm -rf "$OUT"/trace_bench "$OUT"/trace_fusion "$OUT"/pmc*_bench "$OUT"/pmc*_fusion

@@ -31,3 +31,4 @@ cat "$OUT/pmc_${SHAPE}_${BATCH}.json"
 # the same run once more with the counters folded into its roofline record
 $BENCH --cpu-n 0 --pmc-json "$OUT/pmc_${SHAPE}_${BATCH}.json" > "$OUT/bench_roofline_${SHAPE}_${BATCH}.json"
 cat "$OUT/bench_roofline_${SHAPE}_${BATCH}.json"
+rm -rf "$OUT"/trace_${SHAPE} "$OUT"/pmc*_${SHAPE}
