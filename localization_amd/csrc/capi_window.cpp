@@ -57,7 +57,7 @@ size_t loc_window_lds_bytes(const loc_window_caps* caps) {
     if (caps->nv_max <= 0) return 0;
     locamd::WindowCaps c = to_caps(caps);
     const size_t in_lds = locamd::window_lds_bytes(c, false);
-    return in_lds <= 160 * 1024 - 512 ? in_lds : locamd::window_lds_bytes(c, true) + 36 * sizeof(double);  // large windows: index tables + exchange block; the rest in the HBM workspace
+    return (in_lds <= 160 * 1024 - 512 && c.nv_max <= 64) ? in_lds : locamd::window_lds_bytes(c, true) + 36 * sizeof(double);  // large windows: index tables + exchange block; the rest in the HBM workspace
 }
 
 int loc_window_destroy(loc_window* w) {
@@ -92,7 +92,8 @@ int loc_window_create(loc_window** out, int32_t device, int64_t batch, const loc
     if (!w) return locamd_fail(LOC_ERR_INVALID, "out of host memory");
     w->device = device; w->B = batch; w->n_anchors = n_anchors; w->anchors_cap = n_anchors > 0 ? n_anchors : 1; w->iterations = maximum_iteration;
     w->caps = to_caps(caps);
-    const bool global_a = locamd::window_lds_bytes(w->caps, false) > 160 * 1024 - 512;
+    // windows of more than 64 poses always keep their arrays in the HBM workspace (their structure tables alone fill the LDS)
+    const bool global_a = locamd::window_lds_bytes(w->caps, false) > 160 * 1024 - 512 || w->caps.nv_max > 64;
     const size_t B = (size_t)batch;
     const size_t na = (size_t)(n_anchors > 0 ? n_anchors : 1);
     hipError_t e;

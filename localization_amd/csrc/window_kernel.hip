@@ -165,7 +165,11 @@ struct Lds {
     int *fb, *last;         // SKYLINE path: first / last connected block of a block row / column
     // SPARSE path (nv <= 64), everything in elimination-order labels:
     u64 *rowmask, *colmask; //   rowmask[i]: block columns K <= i with L(i,K) != 0 (bit i set); colmask[J]: block rows i > J with L(i,J) != 0
-    u64 *scr;               //   nv_max words of scratch for the ordering
+    u64 *scr;               //   nv_max x W words of scratch for the ordering
+    int W;                  //   words per mask: 1 (<= 64 poses) or 8 (<= 512 poses)
+    int *rowpre;            //   W > 1: per (row, word) the number of blocks in the lower words (rank look-ups)
+    u64 *pushw;             //   W > 1: the pushed columns as W words (W = 1: pushmask below)
+    int *lvl_mode;          //   W > 1: per level 1 = column mode (W = 1: colmode below)
     int *perm;              //   caller's pose slot -> elimination position
     int *lvl_col, *lvl_blk; //   per elimination-tree level: first entry in colorder / otask (nlev + 1 entries)
     int *colorder;          //   block columns sorted by level
@@ -505,7 +509,8 @@ __host__ __device__ inline size_t sky_nnz_bound(int nv, int bw) {
     for (int v = 0; v < nv; ++v) s += 36 * ((size_t)(v < bw ? v : bw) + 1);
     return s;
 }
-__host__ __device__ inline bool window_sparse_path(const WindowCaps& c) { return c.nv_max <= 64; }
+__host__ __device__ inline bool window_sparse_path(const WindowCaps& c) { return c.nv_max <= 512; }
+__host__ __device__ inline int window_mask_words(const WindowCaps& c) { return c.nv_max <= 64 ? 1 : 8; }
 
 // entries of the per-pose incidence lists: every edge once per moving endpoint
 __host__ __device__ inline size_t window_incidences(const WindowCaps& c) {
@@ -528,20 +533,32 @@ __host__ __device__ inline size_t window_instance_doubles(const WindowCaps& c) {
     return 2 * sky_nnz_bound(c.nv_max, c.bw_max) + 4 * n_max + 2 * (size_t)c.nv_max * 12 + (size_t)c.nr_max * RREC + (size_t)c.np_max * PREC +
            (size_t)c.ns_max * SREC + window_index_doubles(c);
 }
-// workspace mode only: the pushed updates and their per-parent sums (28 doubles per column each)
-__host__ __device__ inline size_t window_push_doubles(const WindowCaps& c) { return window_sparse_path(c) ? 56 * (size_t)c.nv_max : 0; }
+// workspace mode only: the pushed updates and their per-parent sums (28 doubles per column each), and for 8-word windows the
+// off-diagonal task list
+__host__ __device__ inline size_t window_push_doubles(const WindowCaps& c) {
+    if (!window_sparse_path(c)) return 0;
+    return 56 * (size_t)c.nv_max + (window_mask_words(c) > 1 ? ints_as_doubles(sky_nnz_bound(c.nv_max, c.bw_max) / 36) : 0);
+}
 // bytes of the small index tables that always live in LDS
 __host__ __device__ inline size_t window_table_bytes(const WindowCaps& c) {
     const size_t nv = (size_t)c.nv_max;
     if (!window_sparse_path(c)) return (4 * nv + 2) * sizeof(int);  // fb, last, boff[nv + 1], ioff[nv + 1]
     const size_t nb_max = sky_nnz_bound(c.nv_max, c.bw_max) / 36;
-    return 3 * nv * sizeof(u64) + (6 * nv + 4 + nb_max) * sizeof(int);  // rowmask, colmask, scr; perm, boff, ioff, lvl_col, lvl_blk, colorder, otask
+    if (window_mask_words(c) == 1)
+        return 3 * nv * sizeof(u64) + (6 * nv + 4 + nb_max) * sizeof(int);  // rowmask, colmask, scr; perm, boff, ioff, lvl_col, lvl_blk, colorder, otask
+    // 8-word masks: rowmask, colmask, scr [nv][8], pushw [8]; rowpre [nv][8], perm, boff, ioff, lvl_col, lvl_blk, lvl_mode, colorder
+    // (the off-diagonal task list of such windows lives in the workspace)
+    return (3 * nv * 8 + 8) * sizeof(u64) + (8 * nv + 7 * nv + 6) * sizeof(int);
 }
 
 // offset of block (i, K), K <= i, in the storage of H / L
 template <bool SP>
 __device__ __forceinline__ int blk_off(const Lds& L, int i, int K) {
-    if (SP) return L.boff[i] + 36 * __popcll(L.rowmask[i] & ((1ull << K) - 1));
+    if (SP) {
+        if (L.W == 1) return L.boff[i] + 36 * __popcll(L.rowmask[i] & ((1ull << K) - 1));
+        const int w = K >> 6;
+        return L.boff[i] + 36 * (L.rowpre[i * L.W + w] + __popcll(L.rowmask[i * L.W + w] & ((1ull << (K & 63)) - 1)));
+    }
     return L.boff[i] + 36 * (K - L.fb[i]);
 }
 // address of H/L entry (row, col), col <= row, inside row's structure
@@ -705,9 +722,307 @@ __device__ __forceinline__ int compute_sparse(Lds& L, int lane, int nv, int nv_m
     {
         u64 m = mycol;
         int k = 0;
-        while (m) { const int i = __ffsll((long long)m) - 1; m &= m - 1; L.otask[blkbase + k++] = (i << 8) | lane; }
+        while (m) { const int i = __ffsll((long long)m) - 1; m &= m - 1; L.otask[blkbase + k++] = (i << 16) | lane; }
     }
     L.nlev = nlev;
+    __syncthreads();
+    return nb;
+}
+
+// ---- structure masks of W 64-bit words per pose (W = 1: windows of <= 64 poses, masks in registers where possible;
+//      W = 8: windows of <= 512 poses, masks in LDS) -------------------------------------------------------------------------
+template <int W> __device__ __forceinline__ u64 rm_word(const Lds& L, int i, int w) { return L.rowmask[i * W + w]; }
+template <int W> __device__ __forceinline__ u64 cm_word(const Lds& L, int J, int w) { return L.colmask[J * W + w]; }
+// the bits of word w that lie below position J
+template <int W> __device__ __forceinline__ u64 below_word(int J, int w) {
+    if (W == 1) return (1ull << J) - 1;
+    const int jw = J >> 6;
+    return w < jw ? ~0ull : (w == jw ? (1ull << (J & 63)) - 1 : 0ull);
+}
+template <int W> __device__ __forceinline__ u64 push_word(const Lds& L, int w) { return W == 1 ? L.pushmask : L.pushw[w]; }
+template <int W> __device__ __forceinline__ bool pushed(const Lds& L, int K) {
+    if (W == 1) return (L.pushmask >> K) & 1ull;
+    return (L.pushw[K >> 6] >> (K & 63)) & 1ull;
+}
+template <int W> __device__ __forceinline__ bool has_pushed_child(const Lds& L, int J) {
+    u64 any = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) any |= rm_word<W>(L, J, w) & below_word<W>(J, w) & push_word<W>(L, w);
+    return any != 0;
+}
+// number of blocks of row i left of column K
+template <int W> __device__ __forceinline__ int row_rank(const Lds& L, int i, int K) {
+    if (W == 1) return __popcll(L.rowmask[i] & ((1ull << K) - 1));
+    const int w = K >> 6;
+    return L.rowpre[i * W + w] + __popcll(L.rowmask[i * W + w] & ((1ull << (K & 63)) - 1));
+}
+// number of columns K < J that rows i and J share (the length of the product sum of block (i, J))
+template <int W> __device__ __forceinline__ int common_count(const Lds& L, int i, int J) {
+    int n = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) n += __popcll(rm_word<W>(L, i, w) & rm_word<W>(L, J, w) & below_word<W>(J, w));
+    return n;
+}
+// A block whose product sum runs over at least DENSE_K earlier columns (the border of an arrowhead: BASELINE config 4's ten
+// unknown anchors see all 256 tag poses, so each anchor-anchor block is a sum of 256 6x6 products) is summed by the WHOLE
+// WAVE, lane = earlier column K, before the level's row tasks run: a row task would walk the 256 products one memory round
+// trip after the other (it did: 90 % of the factorisation time of that shape, in the skyline sweep and here alike).
+constexpr int DENSE_K = 24;
+template <int W> __device__ __forceinline__ bool block_is_presummed(const Lds& L, int i, int J) {
+    return W > 1 && common_count<W>(L, i, J) >= DENSE_K;
+}
+// P = sum_K L_iK L_JK^T over the common earlier columns, left in the (i, J) block of Ls (entry (r, c) at 6 c + r) for the row
+// tasks to pick up; for the diagonal (i == J) only r >= c is meaningful.  All lanes take part; ends with a barrier.
+template <int W>
+__device__ __forceinline__ void presum_block(const Lds& L, int lane, int i, int J) {
+    double acc[36];
+#pragma unroll
+    for (int q = 0; q < 36; ++q) acc[q] = 0.0;
+    const int rowi = L.boff[i], rowJ = L.boff[J];
+    for (int K0 = 0; K0 < J; K0 += 64) {
+        const int K = K0 + lane;
+        const int w = K >> 6;
+        // (a pushed child's update reaches its parent through the reduction step: not again here)
+        const bool has = K < J && (((L.rowmask[i * W + w] & L.rowmask[J * W + w]) >> (K & 63)) & 1ull) && !pushed<W>(L, K);
+        if (has) {
+            const double* bki = L.Ls + rowi + 36 * row_rank<W>(L, i, K);
+            const double* bkj = L.Ls + rowJ + 36 * row_rank<W>(L, J, K);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                double li[6], lj[6];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) { li[r] = bki[6 * k + r]; lj[r] = bkj[6 * k + r]; }
+#pragma unroll
+                for (int c = 0; c < 6; ++c)
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) acc[6 * c + r] = __builtin_fma(li[r], lj[c], acc[6 * c + r]);
+            }
+        }
+    }
+    double* dst = L.Ls + rowi + 36 * row_rank<W>(L, i, J);
+#pragma unroll
+    for (int q = 0; q < 36; ++q) {
+        const double tot = wave_sum(acc[q]);
+        if (lane == q) dst[q] = tot;
+    }
+    __syncthreads();
+}
+
+template <int W> __device__ __forceinline__ bool level_is_column_mode(const Lds& L, int l) {
+    return W == 1 ? ((L.colmode >> l) & 1ull) != 0 : L.lvl_mode[l] != 0;
+}
+
+// Windows of 65 .. 512 poses: the same ordering / structure / levels as compute_sparse, with W-word masks kept in LDS and
+// the poses handled in chunks of 64 (lane = pose within the chunk).  Two differences in the ordering, both for long chains
+// with a dense border (BASELINE config 4: 256 tag poses, each tied to its two neighbours and to all 10 unknown anchors):
+//   * a round takes every pose whose degree is within 1 of the minimum (the chain's interior poses have one neighbour more
+//     than its ends), and
+//   * among adjacent candidates the one whose RANK among the round's candidates (in index order) has the FEWER trailing zero
+//     bits goes first (ties: the lower rank) — every second pose of a chain in the first round, every second of the rest in
+//     the next, ...: a nested dissection, log2(n) levels for the chain instead of n / 2; the dense border vertices (huge
+//     degree) come last.
+// A round is a level (the poses of a round are an independent set, so their columns do not interact); elimination positions
+// are handed out round by round, so the columns of a level are consecutive and colorder is the identity.
+template <int W, bool PUSH>
+__device__ __forceinline__ int compute_sparse_mw(Lds& L, int lane, int nv, int nv_max, int nb_max, int nr, int ns, bool natural) {
+    u64* adj = L.scr;      // [nv][W] current adjacency, caller's labels
+    u64* st = L.rowmask;   // [nv][W] structure at elimination, caller's labels (the row masks overwrite it later)
+    const int NC = (nv + 63) >> 6;
+    for (int i = lane; i < nv * W; i += 64) adj[i] = 0;
+    __syncthreads();
+    for (int e = lane; e < nr; e += 64) {
+        const int v0 = L.r_idx[2 * e], v1 = L.r_idx[2 * e + 1];
+        if (v1 >= 0) { atomicOr(&adj[v0 * W + (v1 >> 6)], 1ull << (v1 & 63)); atomicOr(&adj[v1 * W + (v0 >> 6)], 1ull << (v0 & 63)); }
+    }
+    for (int e = lane; e < ns; e += 64) {
+        const int v0 = L.s_idx[4 * e], v1 = L.s_idx[4 * e + 1];
+        atomicOr(&adj[v0 * W + (v1 >> 6)], 1ull << (v1 & 63)); atomicOr(&adj[v1 * W + (v0 >> 6)], 1ull << (v0 & 63));
+    }
+    __syncthreads();
+    for (int v = lane; v < nv; v += 64) adj[v * W + (v >> 6)] &= ~(1ull << (v & 63));
+    __syncthreads();
+    const u64 me = 1ull << lane, below = me - 1;
+    u64 rem[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) { const int lo = 64 * w; rem[w] = nv >= lo + 64 ? ~0ull : (nv > lo ? (1ull << (nv - lo)) - 1 : 0ull); }
+    int pos = 0, round = 0;
+    for (;;) {
+        u64 any = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) any |= rem[w];
+        if (!any) break;
+        if (lane == 0) L.lvl_col[round] = pos;
+        int degs[W];
+        int mind = 1 << 30;
+#pragma unroll
+        for (int t = 0; t < W; ++t) {
+            const int v = 64 * t + lane;
+            degs[t] = 1 << 30;
+            if (t < NC && ((rem[t] >> lane) & 1ull)) {
+                int d = 0;
+#pragma unroll
+                for (int w = 0; w < W; ++w) d += __popcll(adj[v * W + w] & rem[w]);
+                degs[t] = d;
+            }
+            mind = min(mind, degs[t]);
+        }
+        mind = wave_min_i(mind);
+        u64 cand[W], S[W];
+        if (natural) {
+            bool found = false;
+#pragma unroll
+            for (int w = 0; w < W; ++w) { cand[w] = found ? 0ull : rem[w] & (~rem[w] + 1); found = found || rem[w] != 0; S[w] = cand[w]; }
+        } else {
+#pragma unroll
+            for (int t = 0; t < W; ++t) cand[t] = __ballot(degs[t] <= mind + 1);
+#pragma unroll
+            for (int t = 0; t < W; ++t) {
+                const int v = 64 * t + lane;
+                bool sel = false;
+                // priority among the candidates: by the candidate's RANK r in index order (so it does not matter how the chain
+                // is numbered: the key poses 7, 15, 23, ... of a key-frame chain alternate just like 0, 1, 2, ...) — fewer
+                // trailing zero bits of r first, then the lower rank
+                auto prio = [&](int x) {
+                    int r = 0;
+#pragma unroll
+                    for (int w = 0; w < W; ++w) r += __popcll(cand[w] & below_word<W>(x, w));
+                    return ((r ? __ffs(r) - 1 : 31) << 16) | r;
+                };
+                if (t < NC && ((cand[t] >> lane) & 1ull)) {
+                    sel = true;
+                    const int pv = prio(v);
+#pragma unroll
+                    for (int w = 0; w < W; ++w) {
+                        u64 m = adj[v * W + w] & cand[w];
+                        while (m) { const int u = (w << 6) + __ffsll((long long)m) - 1; m &= m - 1; if (prio(u) < pv) sel = false; }
+                    }
+                }
+                S[t] = __ballot(sel);
+            }
+        }
+        // elimination positions of this round, structure at elimination
+        int before = pos;
+#pragma unroll
+        for (int t = 0; t < W; ++t) {
+            const int v = 64 * t + lane;
+            if (t < NC && ((S[t] >> lane) & 1ull)) {
+                L.perm[v] = before + __popcll(S[t] & below);
+#pragma unroll
+                for (int w = 0; w < W; ++w) st[v * W + w] = adj[v * W + w] & rem[w];
+            }
+            before += __popcll(S[t]);
+        }
+        __syncthreads();
+        // the remaining neighbours of an eliminated pose become a clique
+#pragma unroll
+        for (int t = 0; t < W; ++t) {
+            const int u = 64 * t + lane;
+            if (t < NC && ((rem[t] >> lane) & 1ull) && !((S[t] >> lane) & 1ull)) {
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    u64 m = adj[u * W + w] & S[w];
+                    while (m) {
+                        const int v = (w << 6) + __ffsll((long long)m) - 1;
+                        m &= m - 1;
+#pragma unroll
+                        for (int w2 = 0; w2 < W; ++w2) adj[u * W + w2] |= st[v * W + w2];
+                    }
+                }
+                adj[u * W + t] &= ~me;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < W; ++w) rem[w] &= ~S[w];
+        pos = before;
+        ++round;
+    }
+    const int nlev = round;
+    if (lane == 0) L.lvl_col[nlev] = pos;
+    // relabel: colmask[position of v] = positions of the poses in st[v]
+    for (int i = lane; i < nv * W; i += 64) L.colmask[i] = 0;
+    __syncthreads();
+    for (int v = lane; v < nv; v += 64) {
+        const int p = L.perm[v];
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            u64 m = st[v * W + w];
+            while (m) { const int u = (w << 6) + __ffsll((long long)m) - 1; m &= m - 1; const int q = L.perm[u]; L.colmask[p * W + (q >> 6)] |= 1ull << (q & 63); }
+        }
+    }
+    __syncthreads();
+    // row masks (transpose + diagonal), prefix counts, block offsets — lane = elimination position from here on
+    int carry = 0;
+    for (int c0 = 0; c0 < nv; c0 += 64) {
+        const int i = c0 + lane;
+        int cnt = 0;
+        if (i < nv) {
+            for (int wJ = 0; wJ < W; ++wJ) {
+                u64 acc = 0;
+                const int jn = min(64, nv - 64 * wJ);
+                for (int b = 0; b < jn; ++b) acc |= ((L.colmask[(64 * wJ + b) * W + (i >> 6)] >> (i & 63)) & 1ull) << b;
+                if (wJ == (i >> 6)) acc |= 1ull << (i & 63);
+                L.rowmask[i * W + wJ] = acc;   // (st is dead: every colmask row is complete)
+                L.rowpre[i * W + wJ] = cnt;
+                cnt += __popcll(acc);
+            }
+        }
+        const int ex = wave_excl_scan_i(cnt, lane) + carry;
+        carry = __shfl(ex + cnt, 63, 64);
+        if (i < nv) L.boff[i] = 36 * ex;
+    }
+    const int nb = carry;
+    if (lane == 0) L.boff[nv] = 36 * nb;
+    __syncthreads();
+    if (nb > nb_max) return nb;
+    // levels: column mode or row mode, pushed columns; off-diagonal block tasks in level (= position) order
+    for (int w = lane; w < W; w += 64) L.pushw[w] = 0;
+    __syncthreads();
+    for (int l = 0; l < nlev; ++l) {
+        const int j0 = L.lvl_col[l], j1 = L.lvl_col[l + 1];
+        bool multi = false;
+        for (int J = j0 + lane; J < j1; J += 64) {
+            int nbc = 0;
+#pragma unroll
+            for (int w = 0; w < W; ++w) nbc += __popcll(L.colmask[J * W + w]);
+            multi = multi || nbc > 1;
+        }
+        const bool cm = __ballot(multi) == 0 || (j1 - j0) >= WIDE_LEVEL;
+        if (lane == 0) L.lvl_mode[l] = cm ? 1 : 0;
+        if (cm && PUSH) {
+            for (int J = j0 + lane; J < j1; J += 64) {
+                int nbc = 0;
+#pragma unroll
+                for (int w = 0; w < W; ++w) nbc += __popcll(L.colmask[J * W + w]);
+                if (nbc == 1) atomicOr(&L.pushw[J >> 6], 1ull << (J & 63));
+            }
+        }
+    }
+    carry = 0;
+    for (int c0 = 0; c0 < nv; c0 += 64) {
+        const int J = c0 + lane;
+        int nbc = 0;
+        if (J < nv) {
+#pragma unroll
+            for (int w = 0; w < W; ++w) nbc += __popcll(L.colmask[J * W + w]);
+        }
+        const int start = wave_excl_scan_i(nbc, lane) + carry;
+        carry = __shfl(start + nbc, 63, 64);
+        if (J < nv) {
+            L.colorder[J] = J;
+            L.ioff[J] = start;   // (ioff is free until compute_incidence: the level pointers are read from it just below)
+            int k = 0;
+            for (int w = 0; w < W; ++w) {
+                u64 m = L.colmask[J * W + w];
+                while (m) { const int i = (w << 6) + __ffsll((long long)m) - 1; m &= m - 1; L.otask[start + k++] = (i << 16) | J; }
+            }
+        }
+    }
+    __syncthreads();
+    for (int l = lane; l < nlev; l += 64) L.lvl_blk[l] = L.ioff[L.lvl_col[l]];
+    if (lane == 0) L.lvl_blk[nlev] = nb - nv;
+    L.nlev = nlev;
+    L.colmode = 0; L.pushmask = 0;
     __syncthreads();
     return nb;
 }
@@ -1042,7 +1357,7 @@ __device__ __forceinline__ bool factor_and_solve(const Lds& L, int lane, int n, 
 // re-forming the products from the 36-entry block (and, with the arrays in the HBM workspace, the sums over a parent's children
 // are formed first by a wave-parallel reduction step — one lane per (parent, entry), four loads in flight — so a key pose with
 // eight children costs two memory round trips, not eight).
-template <bool GLOBAL_A>
+template <bool GLOBAL_A, int W>
 __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, double lambda) {
     for (int l = 0; l < L.nlev; ++l) {
         const int c0 = L.lvl_col[l], ncol = L.lvl_col[l + 1] - c0;
@@ -1055,29 +1370,30 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
                 const int idx = base + lane;
                 if (idx < 27 * ncol) {
                     const int J = L.colorder[c0 + idx / 27], e = idx % 27;
-                    u64 m = L.rowmask[J] & ((1ull << J) - 1) & L.pushmask;
-                    if (m) {
-                        any = true;
-                        double acc = 0.0;
+                    bool mine = false;
+                    double acc = 0.0;
+                    for (int w = 0; w < W; ++w) {
+                        u64 m = rm_word<W>(L, J, w) & below_word<W>(J, w) & push_word<W>(L, w);
+                        mine = mine || m != 0;
                         while (m) {
                             // four children per round: the loads are independent, the sum stays in ascending order
                             double v[4];
 #pragma unroll
                             for (int u = 0; u < 4; ++u) {
                                 v[u] = 0.0;
-                                if (m) { const int K = __ffsll((long long)m) - 1; m &= m - 1; v[u] = L.Us[28 * K + e]; }
+                                if (m) { const int K = (w << 6) + __ffsll((long long)m) - 1; m &= m - 1; v[u] = L.Us[28 * K + e]; }
                             }
                             acc = ((acc + v[0]) + v[1]) + v[2];
                             acc += v[3];
                         }
-                        L.As[28 * J + e] = acc;
                     }
+                    if (mine) { any = true; L.As[28 * J + e] = acc; }
                 }
             }
             if (__ballot(any)) __syncthreads();
             LOCAMD_TOC(3);
         }
-        if ((L.colmode >> l) & 1ull) {
+        if (level_is_column_mode<W>(L, l)) {
             // COLUMN MODE: one lane does the whole column — diagonal block, its Cholesky factor, the right-hand side, the
             // off-diagonal block(s) and the pushed update — so G_J is factored once and the level costs one pass, one barrier.
             LOCAMD_TIC();
@@ -1086,9 +1402,7 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
                 const int idx = base + lane;
                 if (idx < ncol) {
                     const int J = L.colorder[c0 + idx];
-                    const u64 rmJ = L.rowmask[J], belowJ = (1ull << J) - 1;
                     const int rowJ = L.boff[J], dJ = L.boff[J + 1] - 36;
-                    const int nK = (dJ - rowJ) / 36;
                     double G[6][6], ig[6], y[6];
 #pragma unroll
                     for (int r = 0; r < 6; ++r) {
@@ -1097,7 +1411,7 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
                         G[r][r] += lambda;
                         y[r] = L.b[6 * J + r];
                     }
-                    if (GLOBAL_A && (rmJ & belowJ & L.pushmask)) {
+                    if (GLOBAL_A && has_pushed_child<W>(L, J)) {
 #pragma unroll
                         for (int r = 0; r < 6; ++r) {
 #pragma unroll
@@ -1105,12 +1419,14 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
                             y[r] -= L.As[28 * J + 21 + r];
                         }
                     }
-                    {
-                        u64 m = rmJ & belowJ;
-                        for (int kb = 0; kb < nK; ++kb) {
-                            const int K = __ffsll((long long)m) - 1;
+                    int kb = -1;
+                    for (int w = 0; w < W; ++w) {
+                        u64 m = rm_word<W>(L, J, w) & below_word<W>(J, w);
+                        while (m) {
+                            const int K = (w << 6) + __ffsll((long long)m) - 1;
                             m &= m - 1;
-                            if ((L.pushmask >> K) & 1ull) {
+                            ++kb;
+                            if (pushed<W>(L, K)) {
                                 if (!GLOBAL_A) {
 #pragma unroll
                                     for (int r = 0; r < 6; ++r) {
@@ -1174,25 +1490,24 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
                         y[c] = v * ig[c];
                         L.yrow[6 * J + c] = y[c];
                     }
-                    const u64 cmJ = L.colmask[J];
-                    const bool push = (L.pushmask >> J) & 1ull;   // exactly one off-diagonal block
-                    u64 mi = cmJ;
+                    const bool push = pushed<W>(L, J);   // exactly one off-diagonal block
+                    for (int wi = 0; wi < W; ++wi) {
+                    u64 mi = cm_word<W>(L, J, wi);
                     while (mi) {
-                        const int i = __ffsll((long long)mi) - 1;
+                        const int i = (wi << 6) + __ffsll((long long)mi) - 1;
                         mi &= mi - 1;
-                        const u64 rmi = L.rowmask[i];
                         const int rowi = L.boff[i];
-                        const int bi = rowi + 36 * __popcll(rmi & belowJ);
+                        const int bi = rowi + 36 * row_rank<W>(L, i, J);
                         double S[36];
 #pragma unroll
                         for (int q = 0; q < 36; ++q) S[q] = L.Hs[bi + q];
-                        u64 m = rmi & rmJ & belowJ;
+                        for (int w = 0; w < W; ++w) {
+                        u64 m = rm_word<W>(L, i, w) & rm_word<W>(L, J, w) & below_word<W>(J, w);
                         while (m) {
-                            const int K = __ffsll((long long)m) - 1;
+                            const int K = (w << 6) + __ffsll((long long)m) - 1;
                             m &= m - 1;
-                            const u64 belowK = (1ull << K) - 1;
-                            const double* bki = L.Ls + rowi + 36 * __popcll(rmi & belowK);
-                            const double* bkj = L.Ls + rowJ + 36 * __popcll(rmJ & belowK);
+                            const double* bki = L.Ls + rowi + 36 * row_rank<W>(L, i, K);
+                            const double* bkj = L.Ls + rowJ + 36 * row_rank<W>(L, J, K);
                             for (int k = 0; k < 6; ++k) {
                                 double li[6], lj[6];
 #pragma unroll
@@ -1202,6 +1517,7 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
 #pragma unroll
                                     for (int r = 0; r < 6; ++r) S[6 * c + r] = __builtin_fma(-li[r], lj[c], S[6 * c + r]);
                             }
+                        }
                         }
 #pragma unroll
                         for (int r = 0; r < 6; ++r) {
@@ -1232,6 +1548,7 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
                             }
                         }
                     }
+                    }
                 }
             }
             __syncthreads();
@@ -1240,6 +1557,18 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
             continue;
         }
         LOCAMD_TIC();
+        if (W > 1) {
+            // dense blocks of this level: summed cooperatively first (uniform loops: every lane sees the same pairs)
+            for (int cix = 0; cix < ncol; ++cix) {
+                const int J = L.colorder[c0 + cix];
+                if (block_is_presummed<W>(L, J, J)) presum_block<W>(L, lane, J, J);
+            }
+            for (int t = 0; t < nblk; ++t) {
+                const int code = L.otask[b0 + t];
+                const int i = code >> 16, J = code & 65535;
+                if (block_is_presummed<W>(L, i, J)) presum_block<W>(L, lane, i, J);
+            }
+        }
         for (int base = 0; base < 6 * ncol; base += 64) {
             const int idx = base + lane;
             if (idx < 6 * ncol) {
@@ -1248,16 +1577,23 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
                 double S[6];
 #pragma unroll
                 for (int c = 0; c < 6; ++c) S[c] = c <= r ? L.Hs[dJ + 6 * c + r] : 0.0;
-                const int nK = (dJ - rowJ) / 36;
-                u64 mK = L.rowmask[J] & ((1ull << J) - 1);
-                if (GLOBAL_A && (mK & L.pushmask)) {   // the pushed children's updates were summed by the reduction step
+                if (GLOBAL_A && has_pushed_child<W>(L, J)) {   // the pushed children's updates were summed by the reduction step
 #pragma unroll
                     for (int c = 0; c < 6; ++c) if (c <= r) S[c] -= L.As[28 * J + r * (r + 1) / 2 + c];
                 }
-                for (int kb = 0; kb < nK; ++kb) {
-                    const int K = __ffsll((long long)mK) - 1;
+                const bool pre = block_is_presummed<W>(L, J, J);
+                if (pre) {
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) if (c <= r) S[c] -= L.Ls[dJ + 6 * c + r];
+                }
+                int kb = -1;
+                for (int w = 0; w < W && !pre; ++w) {
+                u64 mK = rm_word<W>(L, J, w) & below_word<W>(J, w);
+                while (mK) {
+                    const int K = (w << 6) + __ffsll((long long)mK) - 1;
                     mK &= mK - 1;
-                    if ((L.pushmask >> K) & 1ull) {
+                    ++kb;
+                    if (pushed<W>(L, K)) {
                         if (!GLOBAL_A) {
 #pragma unroll
                             for (int c = 0; c < 6; ++c) if (c <= r) S[c] -= L.Us[28 * K + r * (r + 1) / 2 + c];
@@ -1275,6 +1611,7 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
                         for (int k = 0; k < 6; ++k) acc = __builtin_fma(li[k], blk[6 * k + c], acc);
                         S[c] -= acc;
                     }
+                }
                 }
 #pragma unroll
                 for (int c = 0; c < 6; ++c) {
@@ -1297,7 +1634,7 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
                 else if (idx < 6 * (ncol + nblk)) {
                     const int t = idx - 6 * ncol;
                     const int code = L.otask[b0 + t / 6];
-                    kind = 1; i = code >> 8; J = code & 255; r = t % 6;
+                    kind = 1; i = code >> 16; J = code & 65535; r = t % 6;
                 } else { kind = 2; J = L.colorder[c0 + idx - 6 * (ncol + nblk)]; i = J; r = 0; }
                 const int rowJ = L.boff[J], dJ = L.boff[J + 1] - 36;
                 // the row's own segment first (its loads overlap the factorisation below)
@@ -1306,18 +1643,22 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
                 for (int c = 0; c < 6; ++c) S[c] = 0.0;
                 int bi = 0;
                 if (kind == 1) {
-                    const u64 rmi = L.rowmask[i], rmJ = L.rowmask[J], belowJ = (1ull << J) - 1;
                     const int rowi = L.boff[i];
-                    bi = rowi + 36 * __popcll(rmi & belowJ);
+                    bi = rowi + 36 * row_rank<W>(L, i, J);
 #pragma unroll
                     for (int c = 0; c < 6; ++c) S[c] = L.Hs[bi + 6 * c + r];
-                    u64 m = rmi & rmJ & belowJ;
+                    const bool pre = block_is_presummed<W>(L, i, J);
+                    if (pre) {
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) S[c] -= L.Ls[bi + 6 * c + r];
+                    }
+                    for (int w = 0; w < W && !pre; ++w) {
+                    u64 m = rm_word<W>(L, i, w) & rm_word<W>(L, J, w) & below_word<W>(J, w);
                     while (m) {
-                        const int K = __ffsll((long long)m) - 1;
+                        const int K = (w << 6) + __ffsll((long long)m) - 1;
                         m &= m - 1;
-                        const u64 belowK = (1ull << K) - 1;
-                        const double* bki = L.Ls + rowi + 36 * __popcll(rmi & belowK);
-                        const double* bkj = L.Ls + rowJ + 36 * __popcll(rmJ & belowK);
+                        const double* bki = L.Ls + rowi + 36 * row_rank<W>(L, i, K);
+                        const double* bkj = L.Ls + rowJ + 36 * row_rank<W>(L, J, K);
                         double li[6];
 #pragma unroll
                         for (int k = 0; k < 6; ++k) li[k] = bki[6 * k + r];
@@ -1329,20 +1670,22 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
                             S[c] -= acc;
                         }
                     }
+                    }
                 } else if (kind == 2) {
 #pragma unroll
                     for (int c = 0; c < 6; ++c) S[c] = L.b[6 * J + c];
-                    u64 m = L.rowmask[J] & ((1ull << J) - 1);
-                    if (GLOBAL_A && (m & L.pushmask)) {
+                    if (GLOBAL_A && has_pushed_child<W>(L, J)) {
 #pragma unroll
                         for (int c = 0; c < 6; ++c) S[c] -= L.As[28 * J + 21 + c];
                     }
                     int kb = 0;
+                    for (int w = 0; w < W; ++w) {
+                    u64 m = rm_word<W>(L, J, w) & below_word<W>(J, w);
                     while (m) {
-                        const int K = __ffsll((long long)m) - 1;
+                        const int K = (w << 6) + __ffsll((long long)m) - 1;
                         m &= m - 1;
                         const double* bkj = L.Ls + rowJ + 36 * kb++;
-                        if ((L.pushmask >> K) & 1ull) {
+                        if (pushed<W>(L, K)) {
                             if (!GLOBAL_A) {
 #pragma unroll
                                 for (int c = 0; c < 6; ++c) S[c] -= L.Us[28 * K + 21 + c];
@@ -1359,6 +1702,7 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
                             for (int k = 0; k < 6; ++k) acc = __builtin_fma(li[k], bkj[6 * k + c], acc);
                             S[c] -= acc;
                         }
+                    }
                     }
                 }
                 // G_J from the raw diagonal block: entry (p, q), p >= q, at dJ + 6 p + q
@@ -1426,15 +1770,15 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
             if (idx < ncol) {
                 const int J = L.colorder[c0 + idx];
                 const int dJ = L.boff[J + 1] - 36;
-                const u64 belowJ = (1ull << J) - 1;
                 double t[6];
 #pragma unroll
                 for (int c = 0; c < 6; ++c) t[c] = L.yrow[6 * J + c];
-                u64 m = L.colmask[J];
+                for (int w = 0; w < W; ++w) {
+                u64 m = cm_word<W>(L, J, w);
                 while (m) {
-                    const int i = __ffsll((long long)m) - 1;
+                    const int i = (w << 6) + __ffsll((long long)m) - 1;
                     m &= m - 1;
-                    const double* bk = L.Ls + L.boff[i] + 36 * __popcll(L.rowmask[i] & belowJ);
+                    const double* bk = L.Ls + L.boff[i] + 36 * row_rank<W>(L, i, J);
                     double xi[6];
 #pragma unroll
                     for (int r = 0; r < 6; ++r) xi[r] = L.x[6 * i + r];
@@ -1445,6 +1789,7 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
                         for (int r = 0; r < 6; ++r) acc = __builtin_fma(bk[6 * c + r], xi[r], acc);
                         t[c] -= acc;
                     }
+                }
                 }
                 double xs[6];
 #pragma unroll
@@ -1469,7 +1814,7 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
 // JAC: range-edge Jacobians analytic (0) or g2o's central differences (1).  SP: SPARSE path (nv_max <= 64) or SKYLINE.
 // (launch bounds: at least two waves per SIMD, i.e. at most 256 registers — a few rarely used values spill to scratch, which
 //  costs far less than the halved occupancy a 257th register would)
-template <bool GLOBAL_A, int JAC, bool SP>
+template <bool GLOBAL_A, int JAC, bool SP, int W>
 // (experiment kept as a switch: forcing 3 or 4 waves per SIMD for the workspace-mode SPARSE kernel — 168 / 128 registers, 204 /
 //  484 values spilled to scratch — made BASELINE config 5 slower, 19.7 -> 26.0 / 33.1 ms per 16 384 windows: the extra waves do
 //  not pay for the spill traffic)
@@ -1510,21 +1855,27 @@ __global__ void __launch_bounds__(64, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 2) wi
     double* const p_index = p;  // (index tables: here, or in LDS — below)
     p += window_index_doubles(c);
     L.Us = p; L.As = p + 28 * c.nv_max;   // (only used, and only allocated, in workspace mode)
+    int* const otask_ws = reinterpret_cast<int*>(p + 56 * c.nv_max);   // 8-word windows: the off-diagonal task list
     if (GLOBAL_A) p += window_push_doubles(c);
     // the small index tables stay in LDS even when everything else is in the HBM workspace: every address in the sweep and
     // in the edge fold starts with a lookup in them, and an HBM round trip there is pure latency
     {
         double* t = GLOBAL_A ? lds : p;
+        L.W = W; L.rowpre = nullptr; L.pushw = nullptr; L.lvl_mode = nullptr;
         if (SP) {
-            L.rowmask = reinterpret_cast<u64*>(t); L.colmask = L.rowmask + c.nv_max; L.scr = L.colmask + c.nv_max;
-            int* ti = reinterpret_cast<int*>(L.scr + c.nv_max);
+            L.rowmask = reinterpret_cast<u64*>(t); L.colmask = L.rowmask + c.nv_max * W; L.scr = L.colmask + c.nv_max * W;
+            u64* tw = L.scr + c.nv_max * W;
+            if (W > 1) { L.pushw = tw; tw += W; }
+            int* ti = reinterpret_cast<int*>(tw);
+            if (W > 1) { L.rowpre = ti; ti += c.nv_max * W; }
             L.perm = ti; ti += c.nv_max;
             L.boff = ti; ti += c.nv_max + 1;
             L.ioff = ti; ti += c.nv_max + 1;
             L.lvl_col = ti; ti += c.nv_max + 1;
             L.lvl_blk = ti; ti += c.nv_max + 1;
+            if (W > 1) { L.lvl_mode = ti; ti += c.nv_max + 1; }
             L.colorder = ti; ti += c.nv_max;
-            L.otask = ti;
+            L.otask = W > 1 ? otask_ws : ti;
             L.fb = L.last = nullptr;
         } else {
             int* ti = reinterpret_cast<int*>(t);
@@ -1563,8 +1914,14 @@ __global__ void __launch_bounds__(64, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 2) wi
     double* gpose = a.poses + (size_t)inst * c.nv_max * 12;
     if (SP) {
         const int nb_max = (int)(nnz_max / 36);
-        int nb = compute_sparse<GLOBAL_A>(L, lane, nv, c.nv_max, nb_max, nr, ns, a.natural_order != 0);
-        if (nb > nb_max) { __syncthreads(); nb = compute_sparse<GLOBAL_A>(L, lane, nv, c.nv_max, nb_max, nr, ns, true); }  // (the natural order cannot exceed the envelope capacity)
+        int nb;
+        if (W == 1) {
+            nb = compute_sparse<GLOBAL_A>(L, lane, nv, c.nv_max, nb_max, nr, ns, a.natural_order != 0);
+            if (nb > nb_max) { __syncthreads(); nb = compute_sparse<GLOBAL_A>(L, lane, nv, c.nv_max, nb_max, nr, ns, true); }  // (the natural order cannot exceed the envelope capacity)
+        } else {
+            nb = compute_sparse_mw<W, GLOBAL_A>(L, lane, nv, c.nv_max, nb_max, nr, ns, a.natural_order != 0);
+            if (nb > nb_max) { __syncthreads(); nb = compute_sparse_mw<W, GLOBAL_A>(L, lane, nv, c.nv_max, nb_max, nr, ns, true); }
+        }
         // relabel: pose slots -> elimination positions
         for (int e = lane; e < nr; e += 64) {
             L.r_idx[2 * e] = L.perm[L.r_idx[2 * e]];
@@ -1627,7 +1984,7 @@ __global__ void __launch_bounds__(64, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 2) wi
 #ifdef LOCAMD_WINDOW_TIMING
             const long long locamd_tf = clock64();
 #endif
-            const bool ok2 = SP ? factor_and_solve_sparse<GLOBAL_A>(L, lane, lambda) : factor_and_solve(L, lane, n, lambda);
+            const bool ok2 = SP ? factor_and_solve_sparse<GLOBAL_A, W>(L, lane, lambda) : factor_and_solve(L, lane, n, lambda);
 #ifdef LOCAMD_WINDOW_TIMING
             if (!SP && lane == 0) L.tim[3] += clock64() - locamd_tf;  // SKYLINE: the whole sweep incl. back-substitution (slot 5)
 #endif
@@ -1704,7 +2061,7 @@ size_t window_lds_bytes(const WindowCaps& c, bool global_a) {
 }
 size_t window_workspace_doubles(const WindowCaps& c) { return window_instance_doubles(c) + window_push_doubles(c); }
 
-template <bool GLOBAL_A, int JAC, bool SP>
+template <bool GLOBAL_A, int JAC, bool SP, int W>
 static hipError_t launch_window_t(const WindowArgs& a, size_t lds, hipStream_t stream) {
     // the opt-in to more than 64 KiB of dynamic LDS is per device (and per kernel instantiation)
     static std::atomic<uint64_t> attr_set{0};
@@ -1713,12 +2070,12 @@ static hipError_t launch_window_t(const WindowArgs& a, size_t lds, hipStream_t s
     if (e != hipSuccess) return e;
     const uint64_t bit = 1ull << (dev & 63);
     if (!(attr_set.load(std::memory_order_acquire) & bit)) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&window_lm_kernel<GLOBAL_A, JAC, SP>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&window_lm_kernel<GLOBAL_A, JAC, SP, W>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);  // 288 B of static LDS on top
         if (e != hipSuccess) return e;
         attr_set.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL((window_lm_kernel<GLOBAL_A, JAC, SP>), dim3((unsigned)a.B), dim3(64), lds, stream, a);
+    hipLaunchKernelGGL((window_lm_kernel<GLOBAL_A, JAC, SP, W>), dim3((unsigned)a.B), dim3(64), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -1728,16 +2085,20 @@ hipError_t launch_window(const WindowArgs& a, hipStream_t stream) {
     const size_t lds = window_lds_bytes(a.caps, global_a);
     if (lds > 160 * 1024 - 512) return hipErrorInvalidValue;
     const bool sp = window_sparse_path(a.caps);
+    if (sp && window_mask_words(a.caps) > 1) {   // 65 .. 512 poses: 8-word masks, always in the workspace
+        if (!global_a) return hipErrorInvalidValue;
+        return a.jacobian ? launch_window_t<true, 1, true, 8>(a, lds, stream) : launch_window_t<true, 0, true, 8>(a, lds, stream);
+    }
     const int sel = (global_a ? 4 : 0) | (a.jacobian ? 2 : 0) | (sp ? 1 : 0);
     switch (sel) {
-        case 0: return launch_window_t<false, 0, false>(a, lds, stream);
-        case 1: return launch_window_t<false, 0, true>(a, lds, stream);
-        case 2: return launch_window_t<false, 1, false>(a, lds, stream);
-        case 3: return launch_window_t<false, 1, true>(a, lds, stream);
-        case 4: return launch_window_t<true, 0, false>(a, lds, stream);
-        case 5: return launch_window_t<true, 0, true>(a, lds, stream);
-        case 6: return launch_window_t<true, 1, false>(a, lds, stream);
-        default: return launch_window_t<true, 1, true>(a, lds, stream);
+        case 0: return launch_window_t<false, 0, false, 1>(a, lds, stream);
+        case 1: return launch_window_t<false, 0, true, 1>(a, lds, stream);
+        case 2: return launch_window_t<false, 1, false, 1>(a, lds, stream);
+        case 3: return launch_window_t<false, 1, true, 1>(a, lds, stream);
+        case 4: return launch_window_t<true, 0, false, 1>(a, lds, stream);
+        case 5: return launch_window_t<true, 0, true, 1>(a, lds, stream);
+        case 6: return launch_window_t<true, 1, false, 1>(a, lds, stream);
+        default: return launch_window_t<true, 1, true, 1>(a, lds, stream);
     }
 }
 

@@ -24,6 +24,9 @@ sys.path.insert(0, ROOT)
 ANCH4 = np.array([[3, -3, 0.58], [3, 3, 1.97], [-3, 3, 0.54], [-3, -3, 1.76]], dtype=float)
 
 
+POSES_OVERRIDE = None   # --poses: window length for the chain shapes (uwb_only / uwb_imu)
+
+
 def build(B, shape, seed=0):
     import localization_amd as la
     from localization_amd.synthetic import ANCHORS_8
@@ -38,6 +41,8 @@ def build(B, shape, seed=0):
         T, anchors, imu, lever, per_pose = 12, ANCH4, True, True, 1
     else:
         T, anchors, imu, lever, per_pose = 10, ANCH4, False, False, 1
+    if POSES_OVERRIDE and T > 1:
+        T = POSES_OVERRIDE
     off = np.array([0.1, 0.0, -0.05]) if lever else np.zeros(3)
     wb = la.WindowBatch(B, T, max(2 * T, per_pose), T if imu else 0, 0)
     graphs = []
@@ -167,6 +172,7 @@ def main():
     ap.add_argument("--cpu-n", type=int, default=256)
     ap.add_argument("--bw", default="auto", help="'auto' = the widest pose-pose coupling in the batch (what the node front-end passes), "
                     "'dense' = nv_max - 1, or a number")
+    ap.add_argument("--poses", type=int, default=0, help="window length for the chain shapes (default: the profile's 10 / 12)")
     ap.add_argument("--jacobian", default="analytic", choices=["analytic", "numeric"])
     ap.add_argument("--natural", action="store_true", help="windows of <= 64 poses: keep the caller's pose order (no in-kernel minimum-degree ordering)")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-window latency launches (profiling: one kernel shape only)")
@@ -176,6 +182,8 @@ def main():
                     "(profiling runs repeat the same command once per counter pass)")
     a = ap.parse_args()
     import localization_amd as la
+    global POSES_OVERRIDE
+    POSES_OVERRIDE = a.poses or None
     names = ("counts", "poses", "r_idx", "r_val", "p_idx", "p_val", "s_idx", "s_val")
     if a.cache and os.path.exists(a.cache):
         z = np.load(a.cache)
