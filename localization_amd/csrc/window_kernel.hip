@@ -523,8 +523,14 @@ __host__ __device__ inline size_t window_index_doubles(const WindowCaps& c) {
     return ints_as_doubles(window_incidences(c)) + ints_as_doubles((size_t)c.nr_max + c.ns_max + 1) +
            ints_as_doubles(2 * (size_t)c.nr_max) + ints_as_doubles((size_t)c.np_max) + ints_as_doubles(4 * (size_t)c.ns_max);
 }
-constexpr size_t INDEX_TABLES_LDS_MAX = 16 * 1024;
-__host__ __device__ inline bool window_index_in_lds(const WindowCaps& c) { return window_index_doubles(c) * 8 <= INDEX_TABLES_LDS_MAX; }
+constexpr size_t INDEX_TABLES_LDS_MAX = 16 * 1024;        // windows of <= 64 poses: keeps 8+ waves per CU
+constexpr size_t INDEX_TABLES_LDS_MAX_BIG = 72 * 1024;    // larger windows: their structure tables already limit the CU to 1-2 waves
+__host__ __device__ inline size_t window_table_bytes(const WindowCaps& c);
+__host__ __device__ inline bool window_index_in_lds(const WindowCaps& c) {
+    const size_t bytes = window_index_doubles(c) * 8;
+    if (c.nv_max <= 64) return bytes <= INDEX_TABLES_LDS_MAX;
+    return bytes <= INDEX_TABLES_LDS_MAX_BIG && bytes + window_table_bytes(c) + 1024 <= 160 * 1024 - 512;
+}
 
 // doubles of one instance's MAIN arrays (block-sparse pair, dense vectors, poses, edge records, incidence lists, a
 // writable copy of the edge index tables) — the layout the kernel carves, in LDS or in the HBM workspace
@@ -804,6 +810,44 @@ __device__ __forceinline__ void presum_block(const Lds& L, int lane, int i, int 
     for (int q = 0; q < 36; ++q) {
         const double tot = wave_sum(acc[q]);
         if (lane == q) dst[q] = tot;
+    }
+    __syncthreads();
+}
+
+// The right-hand side of a dense row likewise: u = sum_K L_JK y_K over the (non-pushed) earlier columns of row J, lane = K,
+// left in yrow[6 J ..] (free until the row's right-hand-side task overwrites it with y_J).
+template <int W> __device__ __forceinline__ bool rhs_is_presummed(const Lds& L, int J) {
+    if (W == 1) return false;
+    int n = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) n += __popcll(rm_word<W>(L, J, w) & below_word<W>(J, w));
+    return n >= DENSE_K;
+}
+template <int W>
+__device__ __forceinline__ void presum_rhs(const Lds& L, int lane, int J) {
+    double acc[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) acc[c] = 0.0;
+    const int rowJ = L.boff[J];
+    for (int K0 = 0; K0 < J; K0 += 64) {
+        const int K = K0 + lane;
+        const int w = K >> 6;
+        const bool has = K < J && ((L.rowmask[J * W + w] >> (K & 63)) & 1ull) && !pushed<W>(L, K);
+        if (has) {
+            const double* bkj = L.Ls + rowJ + 36 * row_rank<W>(L, J, K);
+            double yk[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) yk[k] = L.yrow[6 * K + k];
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+#pragma unroll
+                for (int k = 0; k < 6; ++k) acc[c] = __builtin_fma(yk[k], bkj[6 * k + c], acc[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const double tot = wave_sum(acc[c]);
+        if (lane == c) L.yrow[6 * J + c] = tot;
     }
     __syncthreads();
 }
@@ -1170,12 +1214,31 @@ __device__ __forceinline__ void build_system(const Lds& L, int lane, int n, int 
         }
         return h;
     };
-    for (int task = lane; task < (nr + ns) * 36; task += 64) {
-        const int t = task / 36, q = task - 36 * t;
+    // one lane per binary edge writes the edge's whole 6x6 block (13 loads for a range edge, then 36 stores): the index
+    // look-ups and the record are read once per edge, not once per entry
+    for (int t = lane; t < nr + ns; t += 64) {
         if (t < nr ? L.r_idx[2 * t + 1] < 0 : L.s_idx[4 * (t - nr) + 3] == 0) continue;  // range to a fixed anchor: no block; unshared SE3 edge: written already
-        int addr;
-        const double h = offdiag(t, q, addr);
-        L.Hs[addr] = h;   // (for a pair with several edges this is overwritten below)
+        if (t < nr) {
+            const int v0 = L.r_idx[2 * t], v1 = L.r_idx[2 * t + 1];
+            const double* rec = L.rrec + t * RREC;
+            double Jr[6], Jc[6];   // rows: the later-labelled pose, columns: the earlier one
+            const bool swap = v0 <= v1;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { Jr[k] = rec[swap ? 6 + k : k]; Jc[k] = rec[swap ? k : 6 + k]; }
+            const double wr = rec[12];
+            double* dst = L.Hs + (swap ? blk_off<SP>(L, v1, v0) : blk_off<SP>(L, v0, v1));
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc)
+#pragma unroll
+                for (int r = 0; r < 6; ++r) dst[6 * cc + r] = wr * Jr[r] * Jc[cc];
+        } else {
+            const int e = t - nr;
+            const int vi = L.s_idx[4 * e], vj = L.s_idx[4 * e + 1];
+            const double* src = L.srec + e * SREC + S_OFF;
+            double* dst = L.Hs + (vi > vj ? blk_off<SP>(L, vi, vj) : blk_off<SP>(L, vj, vi));
+#pragma unroll
+            for (int q = 0; q < 36; ++q) dst[q] = src[q];
+        }
     }
     __syncthreads();
     // pairs of poses with several edges: their blocks are accumulated edge by edge, in fold order
@@ -1562,6 +1625,7 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
             for (int cix = 0; cix < ncol; ++cix) {
                 const int J = L.colorder[c0 + cix];
                 if (block_is_presummed<W>(L, J, J)) presum_block<W>(L, lane, J, J);
+                if (rhs_is_presummed<W>(L, J)) presum_rhs<W>(L, lane, J);
             }
             for (int t = 0; t < nblk; ++t) {
                 const int code = L.otask[b0 + t];
@@ -1678,8 +1742,13 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
 #pragma unroll
                         for (int c = 0; c < 6; ++c) S[c] -= L.As[28 * J + 21 + c];
                     }
+                    const bool pre = rhs_is_presummed<W>(L, J);
+                    if (pre) {
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) S[c] -= L.yrow[6 * J + c];
+                    }
                     int kb = 0;
-                    for (int w = 0; w < W; ++w) {
+                    for (int w = 0; w < W && !pre; ++w) {
                     u64 m = rm_word<W>(L, J, w) & below_word<W>(J, w);
                     while (m) {
                         const int K = (w << 6) + __ffsll((long long)m) - 1;
