@@ -149,8 +149,9 @@ int loc_snapshot_timing_end(loc_snapshot* s, int32_t* n_launches, double* total_
  *   s_val  double[B][ns_max][48]  INVERSE measurement Z^-1 as R(9), t(3); information 6x6 row-major
  *   result double[B][8]           chi2() over all edges at the last evaluated state, robust chi2 of the accepted
  *                                 state, final lambda, outer iterations run, LM trials, terminated flag, 0, 0
- * The normal equations are kept in skyline form (per pose: columns from its leftmost neighbour to itself), so storage
- * and work scale with nv_max * bw_max^2, not nv_max^3: cfg/uwb_pose.yaml's 500-pose chain is 3000 rows of ~12 entries.
+ * The normal equations are kept as sparse 6x6 blocks (storage sized from the envelope bound nv_max * bw_max: per pose,
+ * columns from its leftmost neighbour to itself), so storage and work scale with nv_max * bw_max^2, not nv_max^3:
+ * cfg/uwb_pose.yaml's 500-pose chain is 3000 rows of ~12 entries.
  * Windows whose per-instance arrays fit 160 KiB keep everything in LDS (loc_window_lds_bytes tells); larger ones keep
  * them in a per-instance slice of an HBM workspace the handle allocates (a few MB for 500 poses).
  * ============================================================================================== */
@@ -176,9 +177,11 @@ int loc_window_solve_host(loc_window* w, int64_t n_instances, const int32_t* cou
 int loc_window_last_kernel_ms(loc_window* w, double* ms);
 /* LOC_JAC_ANALYTIC (default) or LOC_JAC_NUMERIC_G2O for the EdgeSE3Range factors of every later solve */
 int loc_window_set_jacobian(loc_window* w, int32_t jacobian);
-/* Windows of up to 64 poses are eliminated in a minimum-degree order the kernel computes per instance (what CHOLMOD's AMD
- * ordering does for the reference, localization.h:82-84: a key-frame star then factors without fill); natural != 0 keeps
- * the caller's pose order instead.  Larger windows always use the caller's order (loc_node_* packs them leaf-first). */
+/* Windows of up to 512 poses are eliminated in a minimum-degree order the kernel computes per instance (what CHOLMOD's AMD
+ * ordering does for the reference, localization.h:82-84: a key-frame star then factors without fill, a chain with a dense
+ * border is dissected into ~log2(n) levels); natural != 0 keeps the caller's pose order instead, and so does a window
+ * whose fill under that order would not fit the storage bw_max sized.  Larger windows (513 ... 1024 poses) always use the
+ * caller's order (loc_node_* packs them leaf-first). */
 int loc_window_set_ordering(loc_window* w, int32_t natural);
 /* Device-resident operation: upload n instances once (same host layouts as loc_window_solve_host), then run
  * loc_window_solve_resident any number of times — each launch starts from the uploaded estimates, is asynchronous on

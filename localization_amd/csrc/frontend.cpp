@@ -199,7 +199,7 @@ int pack(const loc_node* n, Packed& P) {
     if ((int)slot.size() != k) return locamd_fail(LOC_ERR_INVALID, "internal: active vertex outside every robot ring");
     if (k > c.nv_max) return locamd_fail(LOC_ERR_UNSUPPORTED, "window has more active poses than the node was sized for");
     {
-        // Oldest-first or newest-first?  Windows of more than 64 poses are factored in envelope (skyline) form in exactly
+        // Oldest-first or newest-first?  Windows of more than 512 poses are factored in envelope (skyline) form in exactly
         // this order, so take the direction with the cheaper envelope: a key-frame star (addPoseEdge: every pose hangs on
         // an OLDER key pose) packed newest-first has its leaves before their key and factors without any fill, packed
         // oldest-first every row reaches back to its key.  (Smaller windows are re-ordered by the kernel anyway.)

@@ -40,7 +40,7 @@ struct WindowArgs {
     int B;
     int iterations;
     int jacobian;       // 0: analytic range Jacobians, 1: g2o's central differences (delta = 1e-9)
-    int natural_order;  // != 0: windows of <= 64 poses are eliminated in the caller's pose order (diagnostics / tests)
+    int natural_order;  // != 0: windows of <= 512 poses are eliminated in the caller's pose order (diagnostics / tests)
     WindowCaps caps;
 };
 
