@@ -195,10 +195,23 @@ struct Lds {
 // 3 factor phase 1 (SKYLINE: the whole sweep), 4 factor phase 2, 5 back-substitution, 6 update + trial evaluation, 7 total.
 #ifdef LOCAMD_WINDOW_TIMING
 #define LOCAMD_TIC() const long long locamd_t0 = clock64()
+#if LOCAMD_WINDOW_TIMING >= 2
+// sub-phase stamps of the column mode (slots 0 loads, 1 updates from earlier columns, 2 Cholesky + right-hand side,
+// 6 off-diagonal blocks) instead of the phases that normally use those slots
+#define LOCAMD_TOC(slot) do { if (lane == 0 && (slot) != 0 && (slot) != 1 && (slot) != 2 && (slot) != 6) L.tim[slot] += clock64() - locamd_t0; } while (0)
+#define LOCAMD_SUB(slot) do { if (lane == 0 && LOCAMD_WINDOW_TIMING == 2) { const long long t = clock64(); L.tim[slot] += t - locamd_ts; locamd_ts = t; } } while (0)
+// level 3: sub-phases of the back-substitution (0 index look-ups, 1 blocks of the column, 2 triangular solve, 6 stores + barrier)
+#define LOCAMD_SUB3(slot) do { if (lane == 0 && LOCAMD_WINDOW_TIMING == 3) { const long long t = clock64(); L.tim[slot] += t - locamd_ts; locamd_ts = t; } } while (0)
+#else
 #define LOCAMD_TOC(slot) do { if (lane == 0) L.tim[slot] += clock64() - locamd_t0; } while (0)
+#define LOCAMD_SUB(slot) do {} while (0)
+#define LOCAMD_SUB3(slot) do {} while (0)
+#endif
 #else
 #define LOCAMD_TIC() do {} while (0)
 #define LOCAMD_TOC(slot) do {} while (0)
+#define LOCAMD_SUB(slot) do {} while (0)
+#define LOCAMD_SUB3(slot) do {} while (0)
 #endif
 
 #pragma clang fp contract(off)
@@ -625,8 +638,12 @@ __device__ __forceinline__ void compute_skyline(const Lds& L, int lane, int nv, 
 //   3. relabel by elimination position; rowmask / colmask of the factor; block offsets; elimination-tree levels
 //      (level(J) = 1 + max level of the columns in row J); columns and off-diagonal blocks sorted by level.
 // Returns the number of blocks of the factor (the caller checks it against the capacity).
+#ifndef LOCAMD_COLMODE_LDS
+#define LOCAMD_COLMODE_LDS 1
+#endif
+#define LOCAMD_COLMODE_LDS_OK(push) ((push) || LOCAMD_COLMODE_LDS)
 template <bool PUSH>
-__device__ __forceinline__ int compute_sparse(Lds& L, int lane, int nv, int nv_max, int nb_max, int nr, int ns, bool natural) {
+__device__ __forceinline__ int compute_sparse(Lds& L, int lane, int nv, int nv_max, int nb_max, int nr, int ns, bool natural, int& my_level) {
     if (lane < nv) L.scr[lane] = 0;
     __syncthreads();
     for (int e = lane; e < nr; e += 64) {
@@ -694,6 +711,7 @@ __device__ __forceinline__ int compute_sparse(Lds& L, int lane, int nv, int nv_m
         if (((rm >> J) & 1ull) && J != lane) lev = max(lev, lJ + 1);
     }
     const int nlev = wave_max_i(lane < nv ? lev : 0) + 1;
+    my_level = lane < nv ? lev : -1;
     int rank = 0, base = 0;
     const int nbc = __popcll(mycol);  // off-diagonal blocks in my column
     u64 colmode = 0, pushmask = 0;
@@ -704,7 +722,7 @@ __device__ __forceinline__ int compute_sparse(Lds& L, int lane, int nv, int nv_m
         if (mine) rank = base + __popcll(bl & below);
         base += __popcll(bl);
         // column mode: every column of the level has at most one off-diagonal block (trees, chains), or the level is wide
-        if (__ballot(mine && nbc > 1) == 0 || __popcll(bl) >= WIDE_LEVEL) {
+        if (LOCAMD_COLMODE_LDS_OK(PUSH) && (__ballot(mine && nbc > 1) == 0 || __popcll(bl) >= WIDE_LEVEL)) {
             colmode |= 1ull << l;
             if (PUSH) pushmask |= __ballot(mine && nbc == 1);   // (in LDS the parent re-forms the product as cheaply as it loads it)
         }
@@ -1466,6 +1484,9 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
                 if (idx < ncol) {
                     const int J = L.colorder[c0 + idx];
                     const int rowJ = L.boff[J], dJ = L.boff[J + 1] - 36;
+#if defined(LOCAMD_WINDOW_TIMING) && LOCAMD_WINDOW_TIMING >= 2
+                    long long locamd_ts = clock64();
+#endif
                     double G[6][6], ig[6], y[6];
 #pragma unroll
                     for (int r = 0; r < 6; ++r) {
@@ -1482,6 +1503,7 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
                             y[r] -= L.As[28 * J + 21 + r];
                         }
                     }
+                    LOCAMD_SUB(0);
                     int kb = -1;
                     for (int w = 0; w < W; ++w) {
                         u64 m = rm_word<W>(L, J, w) & below_word<W>(J, w);
@@ -1522,6 +1544,7 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
                             }
                         }
                     }
+                    LOCAMD_SUB(1);
 #pragma unroll
                     for (int j = 0; j < 6; ++j) {
                         double dj = G[j][j];
@@ -1553,6 +1576,7 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
                         y[c] = v * ig[c];
                         L.yrow[6 * J + c] = y[c];
                     }
+                    LOCAMD_SUB(2);
                     const bool push = pushed<W>(L, J);   // exactly one off-diagonal block
                     for (int wi = 0; wi < W; ++wi) {
                     u64 mi = cm_word<W>(L, J, wi);
@@ -1612,6 +1636,7 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
                         }
                     }
                     }
+                    LOCAMD_SUB(6);
                 }
             }
             __syncthreads();
@@ -1833,6 +1858,9 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
     LOCAMD_TIC();
     // back substitution: x_J = G_J^-T (y_J - sum_{i in column J} L_iJ^T x_i), levels downwards
     for (int l = L.nlev - 1; l >= 0; --l) {
+#if defined(LOCAMD_WINDOW_TIMING) && LOCAMD_WINDOW_TIMING >= 2
+        long long locamd_ts = clock64();
+#endif
         const int c0 = L.lvl_col[l], ncol = L.lvl_col[l + 1] - c0;
         for (int base = 0; base < ncol; base += 64) {
             const int idx = base + lane;
@@ -1842,6 +1870,7 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
                 double t[6];
 #pragma unroll
                 for (int c = 0; c < 6; ++c) t[c] = L.yrow[6 * J + c];
+                LOCAMD_SUB3(0);
                 for (int w = 0; w < W; ++w) {
                 u64 m = cm_word<W>(L, J, w);
                 while (m) {
@@ -1860,6 +1889,7 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
                     }
                 }
                 }
+                LOCAMD_SUB3(1);
                 double xs[6];
 #pragma unroll
                 for (int rr = 5; rr >= 0; --rr) {
@@ -1868,9 +1898,259 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
                     for (int s2 = rr + 1; s2 < 6; ++s2) v = __builtin_fma(-L.Ls[dJ + 6 * rr + s2], xs[s2], v);
                     xs[rr] = v * L.diagL[6 * J + rr];
                 }
+                LOCAMD_SUB3(2);
 #pragma unroll
                 for (int c = 0; c < 6; ++c) L.x[6 * J + c] = xs[c];
             }
+        }
+        __syncthreads();
+        LOCAMD_SUB3(6);
+    }
+    LOCAMD_TOC(5);
+    return true;
+}
+
+// ---- small windows: arrays in LDS, one-word masks (T = 10 ... 30 poses: the reference's own sliding windows) ------------------
+// The same factorisation, levels and storage as factor_and_solve_sparse, scheduled for LATENCY: such a window occupies a handful
+// of lanes and its time is the dependent chain per level — index look-ups, the 6x6 Cholesky, the row solves — not arithmetic
+// throughput (measured on a 10-pose chain: the one-lane-per-column mode spent 5 k cycles per level, 650 FMAs by one lane and
+// four look-up round trips; a trial solve was 49 k of the 57 k cycles of an LM trial).  Here every level is
+//   stage A (levels >= 1): all updates from earlier columns, one lane per ROW of a block / per right-hand side, one uniform
+//            code path:  out[c] = src[c] - sum_K sum_k a_K[k] L_JK[c][k]  with a_K = row r of L_iK (blocks) or y_K (rhs);
+//   stage B: one lane per row of an off-diagonal block and one per column (right-hand side, stores G): each factors its
+//            column's 6x6 diagonal block itself (right-looking, reciprocal square roots by one cubic Newton step) and solves its
+//            own row against it — again one code path;
+// and the back-substitution keeps lane = column with the column's first block address cached in registers (SmallPlan).
+#ifndef LOCAMD_SMALL_FACTOR
+#define LOCAMD_SMALL_FACTOR 1
+#endif
+struct SmallPlan {
+    int level;      // elimination-tree level of column `lane` (-1: no such column)
+    int dJ;         // offset of the diagonal block of column `lane`
+    u64 colmask;    // rows below the diagonal in column `lane`
+    int off0;       // offset of the first of them
+    u64 fused;      // bit l: every column of level l has at most FUSE_K earlier columns in its row (level 0: none)
+};
+constexpr int FUSE_K = 2;
+
+__device__ __forceinline__ SmallPlan make_small_plan(const Lds& L, int lane, int nv, int level) {
+    SmallPlan p;
+    p.level = level; p.dJ = 0; p.colmask = 0; p.off0 = 0; p.fused = 0;
+    {
+        const int nk = lane < nv ? __popcll(L.rowmask[lane]) - 1 : 0;
+        for (int l = 0; l < L.nlev; ++l)
+            if (__ballot(level == l && nk > FUSE_K) == 0) p.fused |= 1ull << l;
+    }
+    if (lane < nv) {
+        p.dJ = L.boff[lane + 1] - 36;
+        p.colmask = L.colmask[lane];
+        if (p.colmask) {
+            const int i = __ffsll((long long)p.colmask) - 1;
+            p.off0 = L.boff[i] + 36 * __popcll(L.rowmask[i] & ((1ull << lane) - 1));
+        }
+    }
+    return p;
+}
+
+// 1/sqrt(d) for a pivot d > 0: hardware seed (~2^-24) + one third-order step y (1 + e/2 + 3 e^2/8), e = 1 - d y^2: the error
+// term e^3 is far below an ulp; four dependent operations after the seed (the Goldschmidt pair + Newton used elsewhere: eight)
+__device__ __forceinline__ double pivot_rsqrt(double d) {
+    const double y = __builtin_amdgcn_rsq(d);
+    const double t = d * y;
+    const double e = __builtin_fma(-t, y, 1.0);
+    const double pq = __builtin_fma(0.375, e, 0.5);
+    const double ye = y * e;
+    return __builtin_fma(ye, pq, y);
+}
+
+__device__ __forceinline__ bool factor_and_solve_small(const Lds& L, int lane, int nv, double lambda, const SmallPlan& plan) {
+    bool ok = true;
+    for (int l = 0; l < L.nlev; ++l) {
+        const int c0 = L.lvl_col[l], ncol = L.lvl_col[l + 1] - c0;
+        const int b0 = L.lvl_blk[l], nblk = L.lvl_blk[l + 1] - b0;
+        // A level whose columns have at most FUSE_K earlier columns each is done in ONE stage: every task re-forms its
+        // column's whole diagonal block itself (126 FMAs per earlier column, redundantly in each of the column's lanes) and
+        // saves stage A's look-ups, stores and the exchange through LDS — for the chains and trees of a sliding window that is
+        // every level.
+        const bool fused = (plan.fused >> l) & 1ull;
+        if (!fused) {
+            LOCAMD_TIC();
+            const int nrow = 6 * (ncol + nblk), ntask = nrow + ncol;
+            for (int base = 0; base < ntask; base += 64) {
+                const int idx = base + lane;
+                if (idx < ntask) {
+                    const bool rhs = idx >= nrow, off = !rhs && idx >= 6 * ncol;
+                    const int* tab = rhs ? L.colorder + c0 + (idx - nrow) : off ? L.otask + b0 + (idx - 6 * ncol) / 6 : L.colorder + c0 + idx / 6;
+                    const int code = *tab;
+                    const int r = rhs ? 0 : idx % 6;
+                    const int J = code & 65535, i = off ? code >> 16 : J;
+                    const u64 rmJ = L.rowmask[J], rmi = L.rowmask[i];
+                    const int rowJ = L.boff[J], rowi = L.boff[i];
+                    const u64 belowJ = (1ull << J) - 1;
+                    const int bi = rowi + 36 * __popcll(rmi & belowJ);
+                    const double* src = rhs ? L.b + 6 * J : L.Hs + bi + r;
+                    double* dst = rhs ? L.yrow + 6 * J : L.Ls + bi + r;
+                    const int st = rhs ? 1 : 6;
+                    double out[6];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) out[c] = src[c * st];
+                    u64 m = rmi & rmJ & belowJ;
+                    while (m) {
+                        const int K = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const u64 belowK = (1ull << K) - 1;
+                        const double* ap = rhs ? L.yrow + 6 * K : L.Ls + rowi + 36 * __popcll(rmi & belowK) + r;
+                        const double* bp = L.Ls + rowJ + 36 * __popcll(rmJ & belowK);
+                        double av[6], bv[36];
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) av[k] = ap[k * st];
+#pragma unroll
+                        for (int q = 0; q < 36; ++q) bv[q] = bp[q];
+#pragma unroll
+                        for (int k = 0; k < 6; ++k)
+#pragma unroll
+                            for (int c = 0; c < 6; ++c) out[c] = __builtin_fma(-av[k], bv[6 * k + c], out[c]);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) dst[c * st] = out[c];
+                }
+            }
+            __syncthreads();
+            LOCAMD_TOC(3);
+        }
+        {
+            LOCAMD_TIC();
+            // stage B.  (The right-hand-side tasks come last: a column's block-row tasks have read its diagonal block — in the
+            // same pass or an earlier one — before its right-hand-side task overwrites that block with G.)
+            const int nrow = 6 * nblk, ntask = nrow + ncol;
+            const double* Sbase = fused ? L.Hs : L.Ls;
+            const double* ybase = fused ? L.b : L.yrow;
+            for (int base = 0; base < ntask; base += 64) {
+                const int idx = base + lane;
+                if (idx < ntask) {
+                    const bool rhs = idx >= nrow;
+                    const int* tab = rhs ? L.colorder + c0 + (idx - nrow) : L.otask + b0 + idx / 6;
+                    const int code = *tab;
+                    const int r = rhs ? 0 : idx % 6;
+                    const int J = code & 65535, i = rhs ? J : code >> 16;
+                    const int dJ = L.boff[J + 1] - 36;
+                    const u64 rmi = L.rowmask[i], rmJ = L.rowmask[J];
+                    const int rowi = L.boff[i], rowJ = L.boff[J];
+                    const u64 belowJ = (1ull << J) - 1;
+                    const int bi = rowi + 36 * __popcll(rmi & belowJ);
+                    const double* src = rhs ? ybase + 6 * J : Sbase + bi + r;
+                    double* dst = rhs ? L.yrow + 6 * J : L.Ls + bi + r;
+                    const int st = rhs ? 1 : 6;
+                    double A[6][6], s[6], ig[6];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c)
+#pragma unroll
+                        for (int rr = c; rr < 6; ++rr) A[rr][c] = Sbase[dJ + 6 * c + rr];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) s[c] = src[c * st];
+                    u64 m = fused ? rmJ & belowJ : 0ull;
+                    while (m) {
+                        const int K = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const u64 belowK = (1ull << K) - 1;
+                        const bool has = rhs || ((rmi >> K) & 1ull);   // (an off-diagonal block only has the columns its row shares)
+                        const double* ap = rhs ? L.yrow + 6 * K : L.Ls + rowi + 36 * __popcll(rmi & belowK) + r;
+                        const double* bp = L.Ls + rowJ + 36 * __popcll(rmJ & belowK);
+                        double av[6], bv[36];
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) av[k] = has ? ap[k * st] : 0.0;
+#pragma unroll
+                        for (int q = 0; q < 36; ++q) bv[q] = bp[q];
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) {
+#pragma unroll
+                            for (int c = 0; c < 6; ++c) {
+                                s[c] = __builtin_fma(-av[k], bv[6 * k + c], s[c]);
+#pragma unroll
+                                for (int rr = c; rr < 6; ++rr) A[rr][c] = __builtin_fma(-bv[6 * k + rr], bv[6 * k + c], A[rr][c]);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) A[q][q] += lambda;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        // (a pivot <= 0 or not finite turns its reciprocal square root into NaN / inf, which the sum below catches)
+                        const double g = pivot_rsqrt(A[j][j]);
+                        ig[j] = g;
+#pragma unroll
+                        for (int i2 = j + 1; i2 < 6; ++i2) A[i2][j] *= g;
+#pragma unroll
+                        for (int i2 = j + 1; i2 < 6; ++i2)
+#pragma unroll
+                            for (int c = j + 1; c <= i2; ++c) A[i2][c] = __builtin_fma(-A[i2][j], A[c][j], A[i2][c]);
+                    }
+                    double x[6];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {
+                        x[c] = s[c] * ig[c];
+#pragma unroll
+                        for (int c2 = c + 1; c2 < 6; ++c2) s[c2] = __builtin_fma(-x[c], A[c2][c], s[c2]);
+                    }
+                    ok = ok && (((ig[0] + ig[1]) + (ig[2] + ig[3])) + (ig[4] + ig[5]) < DBL_MAX);
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) dst[c * st] = x[c];
+                    if (rhs) {
+#pragma unroll
+                        for (int c = 0; c < 5; ++c)
+#pragma unroll
+                            for (int rr = c + 1; rr < 6; ++rr) L.Ls[dJ + 6 * c + rr] = A[rr][c];
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) L.diagL[6 * J + j] = ig[j];
+                    }
+                }
+            }
+            __syncthreads();
+            LOCAMD_TOC(4);
+            if (__ballot(!ok)) return false;
+        }
+    }
+    LOCAMD_TIC();
+    // back substitution, levels downwards, lane = column: x_J = G_J^-T (y_J - sum_i L_iJ^T x_i)
+    for (int l = L.nlev - 1; l >= 0; --l) {
+        if (plan.level == l) {
+            const int J = lane, dJ = plan.dJ;
+            double t[6], G[6][6], ig[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) t[c] = L.yrow[6 * J + c];
+#pragma unroll
+            for (int c = 0; c < 5; ++c)
+#pragma unroll
+                for (int rr = c + 1; rr < 6; ++rr) G[rr][c] = L.Ls[dJ + 6 * c + rr];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) ig[c] = L.diagL[6 * J + c];
+            u64 m = plan.colmask;
+            bool first = true;
+            while (m) {
+                const int i = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const int off = first ? plan.off0 : L.boff[i] + 36 * __popcll(L.rowmask[i] & ((1ull << J) - 1));
+                first = false;
+                const double* bk = L.Ls + off;
+                double bv[36], xi[6];
+#pragma unroll
+                for (int q = 0; q < 36; ++q) bv[q] = bk[q];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) xi[r] = L.x[6 * i + r];
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) t[c] = __builtin_fma(-bv[6 * c + r], xi[r], t[c]);
+            }
+            double xs[6];
+#pragma unroll
+            for (int rr = 5; rr >= 0; --rr) {
+                xs[rr] = t[rr] * ig[rr];
+#pragma unroll
+                for (int q = 0; q < rr; ++q) t[q] = __builtin_fma(-G[rr][q], xs[rr], t[q]);
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) L.x[6 * J + c] = xs[c];
         }
         __syncthreads();
     }
@@ -1900,6 +2180,10 @@ __global__ void __launch_bounds__(64, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 2) wi
     const int n_max = 6 * c.nv_max;
     const size_t nnz_max = sky_nnz_bound(c.nv_max, c.bw_max);
     Lds L;
+    // small windows (arrays in LDS, one-word masks): the latency-scheduled factorisation (factor_and_solve_small)
+    constexpr bool SMALL = SP && !GLOBAL_A && W == 1 && LOCAMD_SMALL_FACTOR;
+    SmallPlan plan;
+    plan.level = -1; plan.dJ = 0; plan.colmask = 0; plan.off0 = 0; plan.fused = 0;
     __shared__ double s_blk[36];
 #ifdef LOCAMD_WINDOW_TIMING
     __shared__ long long s_tim[8];
@@ -1985,8 +2269,8 @@ __global__ void __launch_bounds__(64, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 2) wi
         const int nb_max = (int)(nnz_max / 36);
         int nb;
         if (W == 1) {
-            nb = compute_sparse<GLOBAL_A>(L, lane, nv, c.nv_max, nb_max, nr, ns, a.natural_order != 0);
-            if (nb > nb_max) { __syncthreads(); nb = compute_sparse<GLOBAL_A>(L, lane, nv, c.nv_max, nb_max, nr, ns, true); }  // (the natural order cannot exceed the envelope capacity)
+            nb = compute_sparse<GLOBAL_A>(L, lane, nv, c.nv_max, nb_max, nr, ns, a.natural_order != 0, plan.level);
+            if (nb > nb_max) { __syncthreads(); nb = compute_sparse<GLOBAL_A>(L, lane, nv, c.nv_max, nb_max, nr, ns, true, plan.level); }  // (the natural order cannot exceed the envelope capacity)
         } else {
             nb = compute_sparse_mw<W, GLOBAL_A>(L, lane, nv, c.nv_max, nb_max, nr, ns, a.natural_order != 0);
             if (nb > nb_max) { __syncthreads(); nb = compute_sparse_mw<W, GLOBAL_A>(L, lane, nv, c.nv_max, nb_max, nr, ns, true); }
@@ -2005,13 +2289,14 @@ __global__ void __launch_bounds__(64, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 2) wi
         for (int i = lane; i < nv * 12; i += 64) L.pose[i] = gpose_in[i];
     }
     __syncthreads();
+    if (SMALL) plan = make_small_plan(L, lane, nv, plan.level);
     compute_incidence<SP>(L, lane, nv, nr, np, ns);
 
     constexpr double tau = 1e-5, good_lo = 1.0 / 3.0, good_hi = 2.0 / 3.0;
     constexpr int max_trials = 10;
     double lambda = 0.0, ni = 2.0, cur_chi = 0.0, last_plain = 0.0;
 #ifdef LOCAMD_WINDOW_TIMING
-    if (lane == 0) L.tim[0] += clock64() - t_start;
+    if (lane == 0 && LOCAMD_WINDOW_TIMING < 2) L.tim[0] += clock64() - t_start;
 #endif
     int it = 0, trials = 0, terminated = 0;
     const bool empty = (nv <= 0) || (nr + np + ns <= 0);
@@ -2053,7 +2338,8 @@ __global__ void __launch_bounds__(64, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 2) wi
 #ifdef LOCAMD_WINDOW_TIMING
             const long long locamd_tf = clock64();
 #endif
-            const bool ok2 = SP ? factor_and_solve_sparse<GLOBAL_A, W>(L, lane, lambda) : factor_and_solve(L, lane, n, lambda);
+            const bool ok2 = !SP ? factor_and_solve(L, lane, n, lambda)
+                             : (SMALL ? factor_and_solve_small(L, lane, nv, lambda, plan) : factor_and_solve_sparse<GLOBAL_A, W>(L, lane, lambda));
 #ifdef LOCAMD_WINDOW_TIMING
             if (!SP && lane == 0) L.tim[3] += clock64() - locamd_tf;  // SKYLINE: the whole sweep incl. back-substitution (slot 5)
 #endif

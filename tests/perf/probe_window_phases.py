@@ -31,6 +31,12 @@ s.solve(wb)
 r = wb.result.mean(axis=0)
 names = ["set-up (ordering, structure, incidence)", "linearise", "build H, b", "factor phase 1 (SKYLINE: whole sweep)", "factor phase 2",
          "back-substitution", "update + trial evaluation", "TOTAL"]
+if "--sub" in sys.argv:   # library built with `make timing TIMING_LEVEL=2`
+    names[0], names[1], names[2], names[6] = ("column mode: index + loads", "column mode: updates from earlier columns",
+                                              "column mode: 6x6 Cholesky + right-hand side", "column mode: off-diagonal blocks")
+if "--sub3" in sys.argv:   # library built with `make timing TIMING_LEVEL=3`
+    names[0], names[1], names[2], names[6] = ("back-substitution: index look-ups + y", "back-substitution: blocks of the column",
+                                              "back-substitution: triangular solve", "back-substitution: stores + barrier")
 print(f"{shape} x {NB}{' natural order' if natural else ''}: cycles per solve (lane-0 stamps)")
 for i, nm in enumerate(names):
     print(f"  {nm:45s} {r[i]:12.0f}  {100 * r[i] / r[7]:5.1f} %")
