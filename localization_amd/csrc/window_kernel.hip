@@ -158,6 +158,14 @@ __device__ __forceinline__ void quat_right_jac(const double* q, double sgn, doub
 
 typedef unsigned long long u64;
 
+// Stage-A record: out[entry] = in[entry] - sum_k a[k] b[k] for one earlier column K.  dst = index of the block / vector being
+// formed (its source, H or b, lies a fixed distance below), a / b = indices of L_iK (or y_K) and L_JK; ctl bit 0 = the record has
+// a K at all, bits 8.. = index of the record of the next K of the same block (0 = none).
+struct alignas(16) RecA { int dst, a, b, ctl; };
+// Stage-B record: dJ = offset of the column's diagonal block in H / L, rb = offset of the off-diagonal block (block jobs) or of
+// the column's 6 entries in the vectors (column jobs).
+struct alignas(8) RecB { int dJ, rb; };
+
 struct Lds {
     double *Hs, *Ls;  // block-sparse H (lower) and its Cholesky factor (LDS, or an HBM workspace slice for large windows)
     double *diagL, *b, *x, *yrow, *pose, *bak, *rrec, *prec, *srec;
@@ -182,6 +190,12 @@ struct Lds {
     int *ioff, *ilist;      // per pose: its incident edges in fold order (CSR), entry = kind << 28 | role << 27 | edge
     int *shared;            // [0] = count, then the binary edges (range e, or nr + SE3 e) whose pair of poses has another edge, in fold order
     double* blk; // 6x6 scratch: the diagonal block being factored (SKYLINE path)
+    // small windows (arrays in LDS, one-word masks): pre-decoded task records of the factorisation (build_small_tables)
+    double* base;            //   the instance's LDS arrays as one array (record fields are indices into it)
+    struct RecA* recA;       //   stage A: per (block, earlier column) pair
+    struct RecB* recB;       //   stage B: per off-diagonal block, then per column
+    int* rec_count;          //   records handed out so far
+    int recA_cap;
 #ifdef LOCAMD_WINDOW_TIMING
     long long* tim;  // diagnostic build: cycles in (a) segments, (b) block exchange+factor, (c) row finish, back-substitution
 #endif
@@ -568,6 +582,18 @@ __host__ __device__ inline size_t window_table_bytes(const WindowCaps& c) {
     // 8-word masks: rowmask, colmask, scr [nv][8], pushw [8]; rowpre [nv][8], perm, boff, ioff, lvl_col, lvl_blk, lvl_mode, colorder
     // (the off-diagonal task list of such windows lives in the workspace)
     return (3 * nv * 8 + 8) * sizeof(u64) + (8 * nv + 7 * nv + 6) * sizeof(int);
+}
+
+// small windows: records of the pre-decoded factorisation schedule — first-level stage-A records (two per column, one per
+// off-diagonal block), continuation records for further earlier columns (capacity: one per block; a window that needs more
+// runs the generic look-ups), stage-B records (one per block), the hand-out counter
+__host__ __device__ inline size_t small_recA_capacity(const WindowCaps& c) {
+    const size_t nb_max = sky_nnz_bound(c.nv_max, c.bw_max) / 36;
+    return (size_t)c.nv_max + 2 * nb_max;
+}
+__host__ __device__ inline size_t small_table_doubles(const WindowCaps& c) {
+    if (!window_sparse_path(c) || window_mask_words(c) != 1) return 0;
+    return 2 * small_recA_capacity(c) + sky_nnz_bound(c.nv_max, c.bw_max) / 36 + 2;
 }
 
 // offset of block (i, K), K <= i, in the storage of H / L
@@ -1924,23 +1950,20 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
 #ifndef LOCAMD_SMALL_FACTOR
 #define LOCAMD_SMALL_FACTOR 1
 #endif
+
 struct SmallPlan {
     int level;      // elimination-tree level of column `lane` (-1: no such column)
     int dJ;         // offset of the diagonal block of column `lane`
     u64 colmask;    // rows below the diagonal in column `lane`
     int off0;       // offset of the first of them
-    u64 fused;      // bit l: every column of level l has at most FUSE_K earlier columns in its row (level 0: none)
+    bool tables;    // the schedule records fit (build_small_tables); else the window runs the generic factor_and_solve_sparse
 };
-constexpr int FUSE_K = 2;
 
+__device__ __forceinline__ bool build_small_tables(const Lds& L, int lane, int nv);
 __device__ __forceinline__ SmallPlan make_small_plan(const Lds& L, int lane, int nv, int level) {
     SmallPlan p;
-    p.level = level; p.dJ = 0; p.colmask = 0; p.off0 = 0; p.fused = 0;
-    {
-        const int nk = lane < nv ? __popcll(L.rowmask[lane]) - 1 : 0;
-        for (int l = 0; l < L.nlev; ++l)
-            if (__ballot(level == l && nk > FUSE_K) == 0) p.fused |= 1ull << l;
-    }
+    p.level = level; p.dJ = 0; p.colmask = 0; p.off0 = 0;
+    p.tables = build_small_tables(L, lane, nv);
     if (lane < nv) {
         p.dJ = L.boff[lane + 1] - 36;
         p.colmask = L.colmask[lane];
@@ -1963,56 +1986,114 @@ __device__ __forceinline__ double pivot_rsqrt(double d) {
     return __builtin_fma(ye, pq, y);
 }
 
+// The schedule of factor_and_solve_small, decoded once per launch: which block, which rows of the factor, where the result goes.
+// (Without it every task of every LM trial walked the structure masks again — 64-bit mask arithmetic, population counts and
+// two dependent look-ups before its first useful load: 57 % of the VALU instructions of a 10-pose window.)
+// Record order of a level l: two per column (diagonal block, right-hand side) in colorder order, then one per off-diagonal
+// block in otask order; the first record of level l is 2 lvl_col[l] + lvl_blk[l].  Returns false (uniformly) when a window has
+// more (block, earlier column) pairs than the continuation records hold.
+__device__ __forceinline__ bool build_small_tables(const Lds& L, int lane, int nv) {
+    const int nb = L.boff[nv] / 36, noff = nb - nv;
+    const int iLs = (int)(L.Ls - L.base), iY = (int)(L.yrow - L.base);
+    if (lane == 0) *L.rec_count = nv + nb;
+    __syncthreads();
+    bool overflow = false;
+    for (int p = lane; p < nv + noff; p += 64) {
+        const bool col = p < nv;
+        const int q = p - nv;
+        int l = 0;
+        for (int k = 1; k < L.nlev; ++k) l += col ? (p >= L.lvl_col[k]) : (q >= L.lvl_blk[k]);
+        const int code = col ? L.colorder[p] : L.otask[q];
+        const int J = code & 65535, i = col ? J : code >> 16;
+        const u64 rmJ = L.rowmask[J], rmi = L.rowmask[i], belowJ = (1ull << J) - 1;
+        const int rowJ = L.boff[J], rowi = L.boff[i], dJ = L.boff[J + 1] - 36;
+        const int bi = rowi + 36 * __popcll(rmi & belowJ);
+        // stage B: block jobs first (otask order), column jobs after them (colorder order)
+        RecB rb;
+        rb.dJ = dJ; rb.rb = col ? 6 * J : bi;
+        L.recB[col ? noff + p : q] = rb;
+        // stage A
+        int slot = col ? 2 * L.lvl_col[l] + L.lvl_blk[l] + 2 * (p - L.lvl_col[l]) : 2 * L.lvl_col[l + 1] + q;
+        RecA d, r;   // (r: the right-hand side's record, columns only)
+        d.dst = iLs + bi; d.a = 0; d.b = 0; d.ctl = 0;
+        r.dst = iY + 6 * J; r.a = 0; r.b = 0; r.ctl = 0;
+        u64 m = rmi & rmJ & belowJ;
+        bool first = true;
+        int prev = slot;
+        if (!m) { L.recA[slot] = d; if (col) L.recA[slot + 1] = r; }
+        while (m) {
+            const int K = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const u64 belowK = (1ull << K) - 1;
+            d.a = iLs + rowi + 36 * __popcll(rmi & belowK);
+            d.b = iLs + rowJ + 36 * __popcll(rmJ & belowK);
+            d.ctl = 1;
+            r.a = iY + 6 * K; r.b = d.b; r.ctl = 1;
+            int pos = slot;
+            if (!first) {
+                pos = atomicAdd(L.rec_count, col ? 2 : 1);
+                if (pos + (col ? 2 : 1) > L.recA_cap) { overflow = true; break; }
+                L.recA[prev].ctl |= pos << 8;
+                if (col) L.recA[prev + 1].ctl |= (pos + 1) << 8;
+            }
+            L.recA[pos] = d;
+            if (col) L.recA[pos + 1] = r;
+            prev = pos;
+            first = false;
+        }
+    }
+    __syncthreads();
+    return __ballot(overflow) == 0;
+}
+
 __device__ __forceinline__ bool factor_and_solve_small(const Lds& L, int lane, int nv, double lambda, const SmallPlan& plan) {
     bool ok = true;
+    const int noff = L.boff[nv] / 36 - nv;
+    const int dLH = (int)(L.Ls - L.Hs), dYB = (int)(L.yrow - L.b);
     for (int l = 0; l < L.nlev; ++l) {
         const int c0 = L.lvl_col[l], ncol = L.lvl_col[l + 1] - c0;
         const int b0 = L.lvl_blk[l], nblk = L.lvl_blk[l + 1] - b0;
-        // A level whose columns have at most FUSE_K earlier columns each is done in ONE stage: every task re-forms its
-        // column's whole diagonal block itself (126 FMAs per earlier column, redundantly in each of the column's lanes) and
-        // saves stage A's look-ups, stores and the exchange through LDS — for the chains and trees of a sliding window that is
-        // every level.
-        const bool fused = (plan.fused >> l) & 1ull;
-        if (!fused) {
+        // stage A (levels >= 1; a column of level 0 has no earlier column in its row): ONE LANE PER ENTRY.  A wave instruction
+        // costs the same whether 2 or 60 lanes are active (and an f64 FMA twice as much as anything else: 8 cycles,
+        // tools/lat_probe2.hip), so the updates are spread as thin as they go: per column 21 lanes for the lower triangle of the
+        // diagonal block and 6 for the right-hand side (a 32-lane slot), per off-diagonal block 36 — six FMAs per earlier
+        // column each, where a lane per block row issued 36 and a lane per column 162.
+        if (l > 0) {
             LOCAMD_TIC();
-            const int nrow = 6 * (ncol + nblk), ntask = nrow + ncol;
+            const int ncs = 32 * ncol, ntask = ncs + 36 * nblk, sb = 2 * c0 + b0;
             for (int base = 0; base < ntask; base += 64) {
                 const int idx = base + lane;
-                if (idx < ntask) {
-                    const bool rhs = idx >= nrow, off = !rhs && idx >= 6 * ncol;
-                    const int* tab = rhs ? L.colorder + c0 + (idx - nrow) : off ? L.otask + b0 + (idx - 6 * ncol) / 6 : L.colorder + c0 + idx / 6;
-                    const int code = *tab;
-                    const int r = rhs ? 0 : idx % 6;
-                    const int J = code & 65535, i = off ? code >> 16 : J;
-                    const u64 rmJ = L.rowmask[J], rmi = L.rowmask[i];
-                    const int rowJ = L.boff[J], rowi = L.boff[i];
-                    const u64 belowJ = (1ull << J) - 1;
-                    const int bi = rowi + 36 * __popcll(rmi & belowJ);
-                    const double* src = rhs ? L.b + 6 * J : L.Hs + bi + r;
-                    double* dst = rhs ? L.yrow + 6 * J : L.Ls + bi + r;
-                    const int st = rhs ? 1 : 6;
-                    double out[6];
+                const bool off = idx >= ncs;
+                const int t = idx - ncs, bq = t / 36;
+                const int e = off ? t - 36 * bq : idx & 31;
+                if (idx < ntask && (off || e < 27)) {
+                    const bool rhs = !off && e >= 21;
+                    RecA rec = L.recA[sb + (off ? 2 * ncol + bq : 2 * (idx >> 5) + (rhs ? 1 : 0))];
+                    // entry e of the packed lower triangle (column-major) -> (r, c), three bits each
+                    constexpr u64 RT = 0ull | (0ull << 0) | (1ull << 3) | (2ull << 6) | (3ull << 9) | (4ull << 12) | (5ull << 15) | (1ull << 18) |
+                                       (2ull << 21) | (3ull << 24) | (4ull << 27) | (5ull << 30) | (2ull << 33) | (3ull << 36) | (4ull << 39) |
+                                       (5ull << 42) | (3ull << 45) | (4ull << 48) | (5ull << 51) | (4ull << 54) | (5ull << 57) | (5ull << 60);
+                    constexpr u64 CT = 0ull | (1ull << 18) | (1ull << 21) | (1ull << 24) | (1ull << 27) | (1ull << 30) | (2ull << 33) | (2ull << 36) |
+                                       (2ull << 39) | (2ull << 42) | (3ull << 45) | (3ull << 48) | (3ull << 51) | (4ull << 54) | (4ull << 57) | (5ull << 60);
+                    const int ec = off ? e / 6 : (rhs ? e - 21 : (int)((CT >> (3 * e)) & 7));
+                    const int er = off ? e - 6 * ec : (rhs ? 0 : (int)((RT >> (3 * e)) & 7));
+                    const int eo = rhs ? ec : 6 * ec + er;
+                    double* dst = L.base + rec.dst + eo;
+                    double out = dst[-(rhs ? dYB : dLH)];
+                    const int ast = rhs ? 1 : 6, ao = rhs ? 0 : er;
+                    while (rec.ctl & 1) {
+                        const double* ap = L.base + rec.a + ao;
+                        const double* bp = L.base + rec.b + ec;
+                        double av[6], bv[6];
 #pragma unroll
-                    for (int c = 0; c < 6; ++c) out[c] = src[c * st];
-                    u64 m = rmi & rmJ & belowJ;
-                    while (m) {
-                        const int K = __ffsll((long long)m) - 1;
-                        m &= m - 1;
-                        const u64 belowK = (1ull << K) - 1;
-                        const double* ap = rhs ? L.yrow + 6 * K : L.Ls + rowi + 36 * __popcll(rmi & belowK) + r;
-                        const double* bp = L.Ls + rowJ + 36 * __popcll(rmJ & belowK);
-                        double av[6], bv[36];
+                        for (int k = 0; k < 6; ++k) { av[k] = ap[k * ast]; bv[k] = bp[6 * k]; }
 #pragma unroll
-                        for (int k = 0; k < 6; ++k) av[k] = ap[k * st];
-#pragma unroll
-                        for (int q = 0; q < 36; ++q) bv[q] = bp[q];
-#pragma unroll
-                        for (int k = 0; k < 6; ++k)
-#pragma unroll
-                            for (int c = 0; c < 6; ++c) out[c] = __builtin_fma(-av[k], bv[6 * k + c], out[c]);
+                        for (int k = 0; k < 6; ++k) out = __builtin_fma(-av[k], bv[k], out);
+                        const int next = rec.ctl >> 8;
+                        if (next == 0) break;
+                        rec = L.recA[next];
                     }
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) dst[c * st] = out[c];
+                    *dst = out;
                 }
             }
             __syncthreads();
@@ -2023,54 +2104,26 @@ __device__ __forceinline__ bool factor_and_solve_small(const Lds& L, int lane, i
             // stage B.  (The right-hand-side tasks come last: a column's block-row tasks have read its diagonal block — in the
             // same pass or an earlier one — before its right-hand-side task overwrites that block with G.)
             const int nrow = 6 * nblk, ntask = nrow + ncol;
-            const double* Sbase = fused ? L.Hs : L.Ls;
-            const double* ybase = fused ? L.b : L.yrow;
+            const double* Sbase = l == 0 ? L.Hs : L.Ls;
+            const double* ybase = l == 0 ? L.b : L.yrow;
             for (int base = 0; base < ntask; base += 64) {
                 const int idx = base + lane;
                 if (idx < ntask) {
                     const bool rhs = idx >= nrow;
-                    const int* tab = rhs ? L.colorder + c0 + (idx - nrow) : L.otask + b0 + idx / 6;
-                    const int code = *tab;
-                    const int r = rhs ? 0 : idx % 6;
-                    const int J = code & 65535, i = rhs ? J : code >> 16;
-                    const int dJ = L.boff[J + 1] - 36;
-                    const u64 rmi = L.rowmask[i], rmJ = L.rowmask[J];
-                    const int rowi = L.boff[i], rowJ = L.boff[J];
-                    const u64 belowJ = (1ull << J) - 1;
-                    const int bi = rowi + 36 * __popcll(rmi & belowJ);
-                    const double* src = rhs ? ybase + 6 * J : Sbase + bi + r;
-                    double* dst = rhs ? L.yrow + 6 * J : L.Ls + bi + r;
+                    const int bq = idx / 6;
+                    const int r = rhs ? 0 : idx - 6 * bq;
+                    const RecB rb = L.recB[rhs ? noff + c0 + (idx - nrow) : b0 + bq];
+                    const double* src = rhs ? ybase + rb.rb : Sbase + rb.rb + r;
+                    double* dst = rhs ? L.yrow + rb.rb : L.Ls + rb.rb + r;
                     const int st = rhs ? 1 : 6;
+                    const double* Sd = Sbase + rb.dJ;
                     double A[6][6], s[6], ig[6];
 #pragma unroll
                     for (int c = 0; c < 6; ++c)
 #pragma unroll
-                        for (int rr = c; rr < 6; ++rr) A[rr][c] = Sbase[dJ + 6 * c + rr];
+                        for (int rr = c; rr < 6; ++rr) A[rr][c] = Sd[6 * c + rr];
 #pragma unroll
                     for (int c = 0; c < 6; ++c) s[c] = src[c * st];
-                    u64 m = fused ? rmJ & belowJ : 0ull;
-                    while (m) {
-                        const int K = __ffsll((long long)m) - 1;
-                        m &= m - 1;
-                        const u64 belowK = (1ull << K) - 1;
-                        const bool has = rhs || ((rmi >> K) & 1ull);   // (an off-diagonal block only has the columns its row shares)
-                        const double* ap = rhs ? L.yrow + 6 * K : L.Ls + rowi + 36 * __popcll(rmi & belowK) + r;
-                        const double* bp = L.Ls + rowJ + 36 * __popcll(rmJ & belowK);
-                        double av[6], bv[36];
-#pragma unroll
-                        for (int k = 0; k < 6; ++k) av[k] = has ? ap[k * st] : 0.0;
-#pragma unroll
-                        for (int q = 0; q < 36; ++q) bv[q] = bp[q];
-#pragma unroll
-                        for (int k = 0; k < 6; ++k) {
-#pragma unroll
-                            for (int c = 0; c < 6; ++c) {
-                                s[c] = __builtin_fma(-av[k], bv[6 * k + c], s[c]);
-#pragma unroll
-                                for (int rr = c; rr < 6; ++rr) A[rr][c] = __builtin_fma(-bv[6 * k + rr], bv[6 * k + c], A[rr][c]);
-                            }
-                        }
-                    }
 #pragma unroll
                     for (int q = 0; q < 6; ++q) A[q][q] += lambda;
 #pragma unroll
@@ -2096,12 +2149,13 @@ __device__ __forceinline__ bool factor_and_solve_small(const Lds& L, int lane, i
 #pragma unroll
                     for (int c = 0; c < 6; ++c) dst[c * st] = x[c];
                     if (rhs) {
+                        double* Gd = L.Ls + rb.dJ;
 #pragma unroll
                         for (int c = 0; c < 5; ++c)
 #pragma unroll
-                            for (int rr = c + 1; rr < 6; ++rr) L.Ls[dJ + 6 * c + rr] = A[rr][c];
+                            for (int rr = c + 1; rr < 6; ++rr) Gd[6 * c + rr] = A[rr][c];
 #pragma unroll
-                        for (int j = 0; j < 6; ++j) L.diagL[6 * J + j] = ig[j];
+                        for (int j = 0; j < 6; ++j) L.diagL[rb.rb + j] = ig[j];
                     }
                 }
             }
@@ -2180,10 +2234,11 @@ __global__ void __launch_bounds__(64, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 2) wi
     const int n_max = 6 * c.nv_max;
     const size_t nnz_max = sky_nnz_bound(c.nv_max, c.bw_max);
     Lds L;
+    L.base = lds; L.recA = nullptr; L.recB = nullptr; L.rec_count = nullptr; L.recA_cap = 0;
     // small windows (arrays in LDS, one-word masks): the latency-scheduled factorisation (factor_and_solve_small)
     constexpr bool SMALL = SP && !GLOBAL_A && W == 1 && LOCAMD_SMALL_FACTOR;
     SmallPlan plan;
-    plan.level = -1; plan.dJ = 0; plan.colmask = 0; plan.off0 = 0; plan.fused = 0;
+    plan.level = -1; plan.dJ = 0; plan.colmask = 0; plan.off0 = 0; plan.tables = false;
     __shared__ double s_blk[36];
 #ifdef LOCAMD_WINDOW_TIMING
     __shared__ long long s_tim[8];
@@ -2256,8 +2311,15 @@ __global__ void __launch_bounds__(64, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 2) wi
     } else {
         double* st_rval = p; p += c.nr_max * 5;
         double* st_pval = p; p += c.np_max * 18;
-        double* st_sval = p;
+        double* st_sval = p; p += c.ns_max * 48;
         L.r_val = st_rval; L.p_val = st_pval; L.s_val = st_sval;
+        if (SMALL) {
+            p += (p - lds) & 1;   // 16-byte records
+            L.recA_cap = (int)small_recA_capacity(c);
+            L.recA = reinterpret_cast<RecA*>(p); p += 2 * L.recA_cap;
+            L.recB = reinterpret_cast<RecB*>(p); p += nnz_max / 36;
+            L.rec_count = reinterpret_cast<int*>(p);
+        }
         for (int i = lane; i < nr * 5; i += 64) st_rval[i] = a.r_val[(size_t)inst * c.nr_max * 5 + i];
         for (int i = lane; i < np * 18; i += 64) st_pval[i] = a.p_val[(size_t)inst * c.np_max * 18 + i];
         for (int i = lane; i < ns * 48; i += 64) st_sval[i] = a.s_val[(size_t)inst * c.ns_max * 48 + i];
@@ -2339,7 +2401,8 @@ __global__ void __launch_bounds__(64, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 2) wi
             const long long locamd_tf = clock64();
 #endif
             const bool ok2 = !SP ? factor_and_solve(L, lane, n, lambda)
-                             : (SMALL ? factor_and_solve_small(L, lane, nv, lambda, plan) : factor_and_solve_sparse<GLOBAL_A, W>(L, lane, lambda));
+                             : (SMALL && plan.tables ? factor_and_solve_small(L, lane, nv, lambda, plan)
+                                                     : factor_and_solve_sparse<GLOBAL_A, W>(L, lane, lambda));
 #ifdef LOCAMD_WINDOW_TIMING
             if (!SP && lane == 0) L.tim[3] += clock64() - locamd_tf;  // SKYLINE: the whole sweep incl. back-substitution (slot 5)
 #endif
@@ -2412,7 +2475,7 @@ size_t window_lds_bytes(const WindowCaps& c, bool global_a) {
     // (+ the static 6x6 exchange block)
     if (global_a) return (window_table_bytes(c) + 7) / 8 * 8 + (window_index_in_lds(c) ? window_index_doubles(c) * 8 : 0);
     const size_t staged = (size_t)c.nr_max * 5 + (size_t)c.np_max * 18 + (size_t)c.ns_max * 48;
-    return (window_instance_doubles(c) + (window_table_bytes(c) + 7) / 8 + staged) * sizeof(double);
+    return (window_instance_doubles(c) + (window_table_bytes(c) + 7) / 8 + staged + small_table_doubles(c)) * sizeof(double);
 }
 size_t window_workspace_doubles(const WindowCaps& c) { return window_instance_doubles(c) + window_push_doubles(c); }
 
