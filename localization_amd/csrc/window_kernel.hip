@@ -80,6 +80,58 @@ __device__ __forceinline__ double wave_max(double v) {  // for non-negative inpu
     return read_lane63(v);
 }
 
+// ---- several waves per window (NW > 1: windows of 65 .. 512 poses, whose structure tables fill a CU's LDS so that ONE window
+//      runs per CU — with one wave it used a quarter of one SIMD pair's issue slots and left three SIMDs idle) ------------------
+// SOLO: a section executed by wave 0 alone (the set-up) orders its own memory operations without the workgroup barrier.
+template <bool SOLO>
+__device__ __forceinline__ void sync_() {
+    if (SOLO) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    } else {
+        __syncthreads();
+    }
+}
+// Reductions over the NW waves of a window through `red` (NW doubles of LDS): every thread gets the same bits (the waves'
+// partial results are combined in wave order).  Two barriers each; all threads must call.
+template <int NW>
+__device__ __forceinline__ double block_sum(double v, double* red, int tid) {
+    const double w = wave_sum(v);
+    if (NW == 1) return w;
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = w;
+    __syncthreads();
+    double t = red[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) t += red[i];
+    return t;
+}
+template <int NW>
+__device__ __forceinline__ double block_max(double v, double* red, int tid) {  // non-negative inputs
+    const double w = wave_max(v);
+    if (NW == 1) return w;
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = w;
+    __syncthreads();
+    double t = red[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) t = fmax(t, red[i]);
+    return t;
+}
+template <int NW>
+__device__ __forceinline__ bool block_any(bool pred, double* red, int tid) {
+    const bool w = __ballot(pred) != 0;
+    if (NW == 1) return w;
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = w ? 1.0 : 0.0;
+    __syncthreads();
+    bool t = false;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) t = t || red[i] != 0.0;
+    return t;
+}
+
 // ---- small SE3 algebra (row-major 3x3) -------------------------------------------------------------------------
 __device__ __forceinline__ void mat_mul(const double* A, const double* B, double* C) {
 #pragma unroll
@@ -190,6 +242,9 @@ struct Lds {
     int *ioff, *ilist;      // per pose: its incident edges in fold order (CSR), entry = kind << 28 | role << 27 | edge
     int *shared;            // [0] = count, then the binary edges (range e, or nr + SE3 e) whose pair of poses has another edge, in fold order
     double* blk; // 6x6 scratch: the diagonal block being factored (SKYLINE path)
+    int *dense, *dense_off;  // 8-word windows: the cooperatively summed (dense) blocks / right-hand sides, by level (compute_sparse_mw)
+    int dense_cap, dense_ok; //   capacity; 0 = the list overflowed: nothing is summed cooperatively
+    double* red; // several waves per window: NW doubles for the block-wide reductions, then NW x 36 for the cooperative sums
     // small windows (arrays in LDS, one-word masks): pre-decoded task records of the factorisation (build_small_tables)
     double* base;            //   the instance's LDS arrays as one array (record fields are indices into it)
     struct RecA* recA;       //   stage A: per (block, earlier column) pair
@@ -213,6 +268,9 @@ struct Lds {
 // sub-phase stamps of the column mode (slots 0 loads, 1 updates from earlier columns, 2 Cholesky + right-hand side,
 // 6 off-diagonal blocks) instead of the phases that normally use those slots
 #define LOCAMD_TOC(slot) do { if (lane == 0 && (slot) != 0 && (slot) != 1 && (slot) != 2 && (slot) != 6) L.tim[slot] += clock64() - locamd_t0; } while (0)
+// level 4: the factorisation by class of level: 0 column-mode levels, 1 row-mode levels without dense blocks, 2 / 6 phase 1 / 2 of
+// the levels with cooperatively summed (dense) blocks
+#define LOCAMD_TOC4(slot) do { if (lane == 0 && LOCAMD_WINDOW_TIMING == 4) L.tim[slot] += clock64() - locamd_t0; } while (0)
 #define LOCAMD_SUB(slot) do { if (lane == 0 && LOCAMD_WINDOW_TIMING == 2) { const long long t = clock64(); L.tim[slot] += t - locamd_ts; locamd_ts = t; } } while (0)
 // level 3: sub-phases of the back-substitution (0 index look-ups, 1 blocks of the column, 2 triangular solve, 6 stores + barrier)
 #define LOCAMD_SUB3(slot) do { if (lane == 0 && LOCAMD_WINDOW_TIMING == 3) { const long long t = clock64(); L.tim[slot] += t - locamd_ts; locamd_ts = t; } } while (0)
@@ -220,12 +278,14 @@ struct Lds {
 #define LOCAMD_TOC(slot) do { if (lane == 0) L.tim[slot] += clock64() - locamd_t0; } while (0)
 #define LOCAMD_SUB(slot) do {} while (0)
 #define LOCAMD_SUB3(slot) do {} while (0)
+#define LOCAMD_TOC4(slot) do {} while (0)
 #endif
 #else
 #define LOCAMD_TIC() do {} while (0)
 #define LOCAMD_TOC(slot) do {} while (0)
 #define LOCAMD_SUB(slot) do {} while (0)
 #define LOCAMD_SUB3(slot) do {} while (0)
+#define LOCAMD_TOC4(slot) do {} while (0)
 #endif
 
 #pragma clang fp contract(off)
@@ -259,13 +319,14 @@ __device__ __forceinline__ int blk_off(const Lds& L, int i, int K);
 // Evaluate every edge at the current poses: errors + chi sums always, Jacobian/weight records when FULL.
 // (FULL: the caller has zeroed H; an SE3 edge that is alone on its pair of poses — s_idx[4 e + 3] == 0, set once per solve —
 //  writes its off-diagonal block straight into H, the others leave it in their record for the ordered accumulation.)
-template <bool FULL, int JAC, bool SP>
+template <bool FULL, int JAC, bool SP, int NW>
 __device__ __forceinline__ void evaluate_edges(const WindowArgs& a, const Lds& L, int inst, int lane, int nr, int np, int ns,
                                double& robust_chi, double& plain_chi) {
     (void)inst;
+    constexpr int NT = 64 * NW;   // (`lane` is the thread's index in its window's workgroup: 0 .. NT - 1)
     double rsum = 0.0, csum = 0.0;
     // ---- range edges ------------------------------------------------------------------------------------------
-    for (int e = lane; e < nr; e += 64) {
+    for (int e = lane; e < nr; e += NT) {
         const int32_t* idx = L.r_idx + e * 2;
         const double* val = L.r_val + e * 5;
         const int v0 = idx[0], v1 = idx[1];
@@ -322,7 +383,7 @@ __device__ __forceinline__ void evaluate_edges(const WindowArgs& a, const Lds& L
         }
     }
     // ---- unary priors -------------------------------------------------------------------------------------------
-    for (int e = lane; e < np; e += 64) {
+    for (int e = lane; e < np; e += NT) {
         const int v = L.p_idx[e];
         const double* val = L.p_val + e * 18;
         const double* X = L.pose + v * 12;
@@ -370,7 +431,7 @@ __device__ __forceinline__ void evaluate_edges(const WindowArgs& a, const Lds& L
         }
     }
     // ---- binary SE3 edges ---------------------------------------------------------------------------------------
-    for (int e = lane; e < ns; e += 64) {
+    for (int e = lane; e < ns; e += NT) {
         const int32_t* idx = L.s_idx + e * 4;
         const double* val = L.s_val + e * 48;
         const int vi = idx[0], vj = idx[1], robust = idx[2];
@@ -519,8 +580,8 @@ __device__ __forceinline__ void evaluate_edges(const WindowArgs& a, const Lds& L
 #undef LOCAMD_J0_HI
         }
     }
-    robust_chi = wave_sum(rsum);
-    plain_chi = wave_sum(csum);
+    robust_chi = block_sum<NW>(rsum, L.red, lane);
+    plain_chi = block_sum<NW>(csum, L.red, lane);
 }
 
 // ---- storage ---------------------------------------------------------------------------------------------------------
@@ -581,7 +642,8 @@ __host__ __device__ inline size_t window_table_bytes(const WindowCaps& c) {
         return 3 * nv * sizeof(u64) + (6 * nv + 4 + nb_max) * sizeof(int);  // rowmask, colmask, scr; perm, boff, ioff, lvl_col, lvl_blk, colorder, otask
     // 8-word masks: rowmask, colmask, scr [nv][8], pushw [8]; rowpre [nv][8], perm, boff, ioff, lvl_col, lvl_blk, lvl_mode, colorder
     // (the off-diagonal task list of such windows lives in the workspace)
-    return (3 * nv * 8 + 8) * sizeof(u64) + (8 * nv + 7 * nv + 6) * sizeof(int);
+    // + dense_off [nv + 2], dense [2 nv]
+    return (3 * nv * 8 + 8) * sizeof(u64) + (8 * nv + 7 * nv + 6 + 3 * nv + 2) * sizeof(int);
 }
 
 // small windows: records of the pre-decoded factorisation schedule — first-level stage-A records (two per column, one per
@@ -819,12 +881,13 @@ template <int W> __device__ __forceinline__ int common_count(const Lds& L, int i
 // trip after the other (it did: 90 % of the factorisation time of that shape, in the skyline sweep and here alike).
 constexpr int DENSE_K = 24;
 template <int W> __device__ __forceinline__ bool block_is_presummed(const Lds& L, int i, int J) {
-    return W > 1 && common_count<W>(L, i, J) >= DENSE_K;
+    return W > 1 && L.dense_ok && common_count<W>(L, i, J) >= DENSE_K;
 }
 // P = sum_K L_iK L_JK^T over the common earlier columns, left in the (i, J) block of Ls (entry (r, c) at 6 c + r) for the row
-// tasks to pick up; for the diagonal (i == J) only r >= c is meaningful.  All lanes take part; ends with a barrier.
+// tasks to pick up; for the diagonal (i == J) only r >= c is meaningful.  One WAVE per block (the dense blocks of a level are
+// independent: with several waves per window each wave takes its own); the caller's barrier follows the level's last block.
 template <int W>
-__device__ __forceinline__ void presum_block(const Lds& L, int lane, int i, int J) {
+__device__ __forceinline__ void presum_block(const Lds& L, int lane, int i, int J) {   // lane: 0 .. 63 within the wave
     double acc[36];
 #pragma unroll
     for (int q = 0; q < 36; ++q) acc[q] = 0.0;
@@ -855,20 +918,19 @@ __device__ __forceinline__ void presum_block(const Lds& L, int lane, int i, int 
         const double tot = wave_sum(acc[q]);
         if (lane == q) dst[q] = tot;
     }
-    __syncthreads();
 }
 
 // The right-hand side of a dense row likewise: u = sum_K L_JK y_K over the (non-pushed) earlier columns of row J, lane = K,
 // left in yrow[6 J ..] (free until the row's right-hand-side task overwrites it with y_J).
 template <int W> __device__ __forceinline__ bool rhs_is_presummed(const Lds& L, int J) {
-    if (W == 1) return false;
+    if (W == 1 || !L.dense_ok) return false;
     int n = 0;
 #pragma unroll
     for (int w = 0; w < W; ++w) n += __popcll(rm_word<W>(L, J, w) & below_word<W>(J, w));
     return n >= DENSE_K;
 }
 template <int W>
-__device__ __forceinline__ void presum_rhs(const Lds& L, int lane, int J) {
+__device__ __forceinline__ void presum_rhs(const Lds& L, int lane, int J) {   // lane: 0 .. 63 within the wave
     double acc[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) acc[c] = 0.0;
@@ -893,7 +955,6 @@ __device__ __forceinline__ void presum_rhs(const Lds& L, int lane, int J) {
         const double tot = wave_sum(acc[c]);
         if (lane == c) L.yrow[6 * J + c] = tot;
     }
-    __syncthreads();
 }
 
 template <int W> __device__ __forceinline__ bool level_is_column_mode(const Lds& L, int l) {
@@ -911,13 +972,13 @@ template <int W> __device__ __forceinline__ bool level_is_column_mode(const Lds&
 //     degree) come last.
 // A round is a level (the poses of a round are an independent set, so their columns do not interact); elimination positions
 // are handed out round by round, so the columns of a level are consecutive and colorder is the identity.
-template <int W, bool PUSH>
+template <int W, bool PUSH, bool SOLO>
 __device__ __forceinline__ int compute_sparse_mw(Lds& L, int lane, int nv, int nv_max, int nb_max, int nr, int ns, bool natural) {
     u64* adj = L.scr;      // [nv][W] current adjacency, caller's labels
     u64* st = L.rowmask;   // [nv][W] structure at elimination, caller's labels (the row masks overwrite it later)
     const int NC = (nv + 63) >> 6;
     for (int i = lane; i < nv * W; i += 64) adj[i] = 0;
-    __syncthreads();
+    sync_<SOLO>();
     for (int e = lane; e < nr; e += 64) {
         const int v0 = L.r_idx[2 * e], v1 = L.r_idx[2 * e + 1];
         if (v1 >= 0) { atomicOr(&adj[v0 * W + (v1 >> 6)], 1ull << (v1 & 63)); atomicOr(&adj[v1 * W + (v0 >> 6)], 1ull << (v0 & 63)); }
@@ -926,9 +987,9 @@ __device__ __forceinline__ int compute_sparse_mw(Lds& L, int lane, int nv, int n
         const int v0 = L.s_idx[4 * e], v1 = L.s_idx[4 * e + 1];
         atomicOr(&adj[v0 * W + (v1 >> 6)], 1ull << (v1 & 63)); atomicOr(&adj[v1 * W + (v0 >> 6)], 1ull << (v0 & 63));
     }
-    __syncthreads();
+    sync_<SOLO>();
     for (int v = lane; v < nv; v += 64) adj[v * W + (v >> 6)] &= ~(1ull << (v & 63));
-    __syncthreads();
+    sync_<SOLO>();
     const u64 me = 1ull << lane, below = me - 1;
     u64 rem[W];
 #pragma unroll
@@ -1000,7 +1061,7 @@ __device__ __forceinline__ int compute_sparse_mw(Lds& L, int lane, int nv, int n
             }
             before += __popcll(S[t]);
         }
-        __syncthreads();
+        sync_<SOLO>();
         // the remaining neighbours of an eliminated pose become a clique
 #pragma unroll
         for (int t = 0; t < W; ++t) {
@@ -1019,7 +1080,7 @@ __device__ __forceinline__ int compute_sparse_mw(Lds& L, int lane, int nv, int n
                 adj[u * W + t] &= ~me;
             }
         }
-        __syncthreads();
+        sync_<SOLO>();
 #pragma unroll
         for (int w = 0; w < W; ++w) rem[w] &= ~S[w];
         pos = before;
@@ -1029,7 +1090,7 @@ __device__ __forceinline__ int compute_sparse_mw(Lds& L, int lane, int nv, int n
     if (lane == 0) L.lvl_col[nlev] = pos;
     // relabel: colmask[position of v] = positions of the poses in st[v]
     for (int i = lane; i < nv * W; i += 64) L.colmask[i] = 0;
-    __syncthreads();
+    sync_<SOLO>();
     for (int v = lane; v < nv; v += 64) {
         const int p = L.perm[v];
 #pragma unroll
@@ -1038,7 +1099,7 @@ __device__ __forceinline__ int compute_sparse_mw(Lds& L, int lane, int nv, int n
             while (m) { const int u = (w << 6) + __ffsll((long long)m) - 1; m &= m - 1; const int q = L.perm[u]; L.colmask[p * W + (q >> 6)] |= 1ull << (q & 63); }
         }
     }
-    __syncthreads();
+    sync_<SOLO>();
     // row masks (transpose + diagonal), prefix counts, block offsets — lane = elimination position from here on
     int carry = 0;
     for (int c0 = 0; c0 < nv; c0 += 64) {
@@ -1061,21 +1122,25 @@ __device__ __forceinline__ int compute_sparse_mw(Lds& L, int lane, int nv, int n
     }
     const int nb = carry;
     if (lane == 0) L.boff[nv] = 36 * nb;
-    __syncthreads();
+    sync_<SOLO>();
     if (nb > nb_max) return nb;
     // levels: column mode or row mode, pushed columns; off-diagonal block tasks in level (= position) order
     for (int w = lane; w < W; w += 64) L.pushw[w] = 0;
-    __syncthreads();
+    sync_<SOLO>();
     for (int l = 0; l < nlev; ++l) {
         const int j0 = L.lvl_col[l], j1 = L.lvl_col[l + 1];
         bool multi = false;
         for (int J = j0 + lane; J < j1; J += 64) {
-            int nbc = 0;
+            int nbc = 0, nk = 0;
 #pragma unroll
-            for (int w = 0; w < W; ++w) nbc += __popcll(L.colmask[J * W + w]);
-            multi = multi || nbc > 1;
+            for (int w = 0; w < W; ++w) { nbc += __popcll(L.colmask[J * W + w]); nk += __popcll(L.rowmask[J * W + w] & below_word<W>(J, w)); }
+            // (a column with a dense row — many earlier columns — wants the cooperative sums of the row mode: one lane walking
+            //  an unknown anchor's 264 earlier columns of BASELINE config 4 was a sixth of that solve)
+            multi = multi || nbc > 1 || nk >= DENSE_K;
         }
-        const bool cm = __ballot(multi) == 0 || (j1 - j0) >= WIDE_LEVEL;
+        // (with several waves per window a wide level is better off as row tasks over all of them: a lane per column leaves
+        //  most of them idle — BASELINE config 4's first four levels took a third of the solve that way)
+        const bool cm = __ballot(multi) == 0 || (!SOLO && (j1 - j0) >= WIDE_LEVEL);
         if (lane == 0) L.lvl_mode[l] = cm ? 1 : 0;
         if (cm && PUSH) {
             for (int J = j0 + lane; J < j1; J += 64) {
@@ -1106,12 +1171,47 @@ __device__ __forceinline__ int compute_sparse_mw(Lds& L, int lane, int nv, int n
             }
         }
     }
-    __syncthreads();
+    sync_<SOLO>();
     for (int l = lane; l < nlev; l += 64) L.lvl_blk[l] = L.ioff[L.lvl_col[l]];
     if (lane == 0) L.lvl_blk[nlev] = nb - nv;
     L.nlev = nlev;
     L.colmode = 0; L.pushmask = 0;
-    __syncthreads();
+    sync_<SOLO>();
+    // the cooperatively summed (dense) blocks and right-hand sides, listed by level: block (i << 16 | J), right-hand side
+    // (1 << 31 | J).  (The factorisation used to find them again on every level of every LM trial, one uniform look-up in the
+    // task list — which lives in the HBM workspace — per block: a full memory round trip each.)
+    {
+        L.dense_ok = 1;
+        int dcount = 0;
+        for (int l = 0; l < nlev; ++l) {
+            if (lane == 0) L.dense_off[l] = dcount;
+            const int j0 = L.lvl_col[l], j1 = L.lvl_col[l + 1];
+            for (int c0 = j0; c0 < j1; c0 += 64) {
+                const int J = c0 + lane;
+                const bool d = J < j1 && block_is_presummed<W>(L, J, J), r = J < j1 && rhs_is_presummed<W>(L, J);
+                const u64 bd = __ballot(d), br = __ballot(r);
+                const int pd = dcount + __popcll(bd & below);
+                if (d && pd < L.dense_cap) L.dense[pd] = (J << 16) | J;
+                dcount += __popcll(bd);
+                const int pr = dcount + __popcll(br & below);
+                if (r && pr < L.dense_cap) L.dense[pr] = (int)(0x80000000u | (unsigned)J);
+                dcount += __popcll(br);
+            }
+            const int t1 = L.lvl_blk[l + 1];
+            for (int t0 = L.lvl_blk[l]; t0 < t1; t0 += 64) {
+                const int t = t0 + lane;
+                const int code = t < t1 ? L.otask[t] : 0;
+                const bool d = t < t1 && block_is_presummed<W>(L, code >> 16, code & 65535);
+                const u64 bd = __ballot(d);
+                const int pd = dcount + __popcll(bd & below);
+                if (d && pd < L.dense_cap) L.dense[pd] = code;
+                dcount += __popcll(bd);
+            }
+        }
+        if (lane == 0) L.dense_off[nlev] = dcount;
+        if (dcount > L.dense_cap) L.dense_ok = 0;
+        sync_<SOLO>();
+    }
     return nb;
 }
 
@@ -1124,7 +1224,7 @@ __device__ __forceinline__ int compute_sparse_mw(Lds& L, int lane, int nv, int n
 //                     (second entry = -1); the edges of flagged pairs then take the minimum of their stamps (atomic min on
 //                     the bit patterns of positive doubles), which names the pair's first edge; the flagged edges are
 //                     listed in fold order by ballot compaction.
-template <bool SP>
+template <bool SP, bool SOLO>
 __device__ __forceinline__ void compute_incidence(const Lds& L, int lane, int nv, int nr, int np, int ns) {
     for (int v0 = 0; v0 < nv; v0 += 64) {
         const int v = v0 + lane;
@@ -1134,19 +1234,19 @@ __device__ __forceinline__ void compute_incidence(const Lds& L, int lane, int nv
         for (int e = 0; e < ns; ++e) cnt += (L.s_idx[4 * e] == v) + (L.s_idx[4 * e + 1] == v);
         if (v < nv) L.ioff[v + 1] = cnt;
     }
-    __syncthreads();
+    sync_<SOLO>();
     int carry = 0;
     for (int v0 = 0; v0 < nv; v0 += 64) {
         const int v = v0 + lane;
         const int c = v < nv ? L.ioff[v + 1] : 0;
         const int ex = wave_excl_scan_i(c, lane) + carry;
         carry = __shfl(ex + c, 63, 64);
-        __syncthreads();
+        sync_<SOLO>();
         if (v < nv) L.ioff[v] = ex;
-        __syncthreads();
+        sync_<SOLO>();
     }
     if (lane == 0) L.ioff[nv] = carry;
-    __syncthreads();
+    sync_<SOLO>();
     for (int v0 = 0; v0 < nv; v0 += 64) {
         const int v = v0 + lane;
         int cur = v < nv ? L.ioff[v] : 0;
@@ -1160,7 +1260,7 @@ __device__ __forceinline__ void compute_incidence(const Lds& L, int lane, int nv
             if (L.s_idx[4 * e + 1] == v) L.ilist[cur++] = (2 << INC_KIND_SHIFT) | (1 << INC_ROLE_SHIFT) | e;
         }
     }
-    __syncthreads();
+    sync_<SOLO>();
     auto block_entry = [&](int t) {
         const bool is_r = t < nr;
         const int va = is_r ? L.r_idx[2 * t] : L.s_idx[4 * (t - nr)], vb = is_r ? L.r_idx[2 * t + 1] : L.s_idx[4 * (t - nr) + 1];
@@ -1168,14 +1268,14 @@ __device__ __forceinline__ void compute_incidence(const Lds& L, int lane, int nv
     };
     const int nbin = nr + ns;
     for (int t = lane; t < nbin; t += 64) { const int a0 = block_entry(t); if (a0 >= 0) { L.Hs[a0] = (double)(t + 1); L.Hs[a0 + 1] = 0.0; } }
-    __syncthreads();
+    sync_<SOLO>();
     for (int t = lane; t < nbin; t += 64) { const int a0 = block_entry(t); if (a0 >= 0 && L.Hs[a0] != (double)(t + 1)) L.Hs[a0 + 1] = -1.0; }
-    __syncthreads();
+    sync_<SOLO>();
     for (int t = lane; t < nbin; t += 64) {
         const int a0 = block_entry(t);
         if (a0 >= 0 && L.Hs[a0 + 1] == -1.0) atomicMin(reinterpret_cast<u64*>(L.Hs + a0), (u64)__double_as_longlong((double)(t + 1)));
     }
-    __syncthreads();
+    sync_<SOLO>();
     int cnt = 0;
     for (int t0 = 0; t0 < nbin; t0 += 64) {
         const int t = t0 + lane;
@@ -1188,7 +1288,7 @@ __device__ __forceinline__ void compute_incidence(const Lds& L, int lane, int nv
         cnt += __popcll(bal);
     }
     if (lane == 0) L.shared[0] = cnt;
-    __syncthreads();
+    sync_<SOLO>();
 }
 
 // Fold the edge records into H (skyline lower triangle) and b: H_vv = sum J_v^T (rho' Omega) J_v etc., every entry summed
@@ -1197,13 +1297,14 @@ __device__ __forceinline__ void compute_incidence(const Lds& L, int lane, int nv
 // the end; an off-diagonal block that belongs to one edge is written by it; the few pairs of poses with several edges
 // (a key-frame pose edge landing on the previous pose next to the smoothness edge) are accumulated edge by edge at the
 // end.  No read-modify-write chains through memory for the bulk, all tasks independent.
-template <bool SP>
+template <bool SP, int NW>
 __device__ __forceinline__ void build_system(const Lds& L, int lane, int n, int nr, int ns) {
+    constexpr int NT = 64 * NW;
     const int nv = n / 6;
     // (H was zeroed before the linearisation, which has already written the off-diagonal blocks of the unshared SE3 edges)
     // diagonal blocks and b: one lane per pose, its 21 + 6 sums in registers, ONE pass over the pose's incidence list — the
     // 27 loads of an incidence are independent of each other, so a list costs one memory round trip per edge, not per entry
-    for (int v = lane; v < nv; v += 64) {
+    for (int v = lane; v < nv; v += NT) {
         double acc[27];
 #pragma unroll
         for (int k = 0; k < 27; ++k) acc[k] = 0.0;
@@ -1260,7 +1361,7 @@ __device__ __forceinline__ void build_system(const Lds& L, int lane, int n, int 
     };
     // one lane per binary edge writes the edge's whole 6x6 block (13 loads for a range edge, then 36 stores): the index
     // look-ups and the record are read once per edge, not once per entry
-    for (int t = lane; t < nr + ns; t += 64) {
+    for (int t = lane; t < nr + ns; t += NT) {
         if (t < nr ? L.r_idx[2 * t + 1] < 0 : L.s_idx[4 * (t - nr) + 3] == 0) continue;  // range to a fixed anchor: no block; unshared SE3 edge: written already
         if (t < nr) {
             const int v0 = L.r_idx[2 * t], v1 = L.r_idx[2 * t + 1];
@@ -1464,8 +1565,9 @@ __device__ __forceinline__ bool factor_and_solve(const Lds& L, int lane, int n, 
 // re-forming the products from the 36-entry block (and, with the arrays in the HBM workspace, the sums over a parent's children
 // are formed first by a wave-parallel reduction step — one lane per (parent, entry), four loads in flight — so a key pose with
 // eight children costs two memory round trips, not eight).
-template <bool GLOBAL_A, int W>
+template <bool GLOBAL_A, int W, int NW>
 __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, double lambda) {
+    constexpr int NT = 64 * NW;   // (`lane` is the thread's index in its window's workgroup)
     for (int l = 0; l < L.nlev; ++l) {
         const int c0 = L.lvl_col[l], ncol = L.lvl_col[l + 1] - c0;
         const int b0 = L.lvl_blk[l], nblk = L.lvl_blk[l + 1] - b0;
@@ -1473,7 +1575,7 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
             // reduction step: As[J] = sum over J's pushed children K (ascending) of Us[K], for the columns of this level
             LOCAMD_TIC();
             bool any = false;
-            for (int base = 0; base < 27 * ncol; base += 64) {
+            for (int base = 0; base < 27 * ncol; base += NT) {
                 const int idx = base + lane;
                 if (idx < 27 * ncol) {
                     const int J = L.colorder[c0 + idx / 27], e = idx % 27;
@@ -1497,7 +1599,7 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
                     if (mine) { any = true; L.As[28 * J + e] = acc; }
                 }
             }
-            if (__ballot(any)) __syncthreads();
+            if (NW > 1 || __ballot(any)) __syncthreads();
             LOCAMD_TOC(3);
         }
         if (level_is_column_mode<W>(L, l)) {
@@ -1505,7 +1607,7 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
             // off-diagonal block(s) and the pushed update — so G_J is factored once and the level costs one pass, one barrier.
             LOCAMD_TIC();
             bool okw = true;
-            for (int base = 0; base < ncol; base += 64) {
+            for (int base = 0; base < ncol; base += NT) {
                 const int idx = base + lane;
                 if (idx < ncol) {
                     const int J = L.colorder[c0 + idx];
@@ -1667,24 +1769,29 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
             }
             __syncthreads();
             LOCAMD_TOC(4);
-            if (__ballot(!okw)) return false;
+            LOCAMD_TOC4(0);
+            if (block_any<NW>(!okw, L.red, lane)) return false;
             continue;
         }
         LOCAMD_TIC();
-        if (W > 1) {
-            // dense blocks of this level: summed cooperatively first (uniform loops: every lane sees the same pairs)
-            for (int cix = 0; cix < ncol; ++cix) {
-                const int J = L.colorder[c0 + cix];
-                if (block_is_presummed<W>(L, J, J)) presum_block<W>(L, lane, J, J);
-                if (rhs_is_presummed<W>(L, J)) presum_rhs<W>(L, lane, J);
+        bool dense_level = false;
+        (void)dense_level;
+        if (W > 1 && L.dense_ok) {
+            // dense blocks / right-hand sides of this level (listed once per solve): summed cooperatively first, one wave each
+            const int d0 = L.dense_off[l], d1 = L.dense_off[l + 1];
+            dense_level = d1 > d0;
+            for (int e0 = d0; e0 < d1; e0 += NW) {
+                const int e = e0 + (lane >> 6);
+                if (e < d1) {
+                    const int code = L.dense[e];
+                    const int J = code & 65535, i = (code >> 16) & 32767;
+                    if (code < 0) presum_rhs<W>(L, lane & 63, J);
+                    else presum_block<W>(L, lane & 63, i, J);
+                }
             }
-            for (int t = 0; t < nblk; ++t) {
-                const int code = L.otask[b0 + t];
-                const int i = code >> 16, J = code & 65535;
-                if (block_is_presummed<W>(L, i, J)) presum_block<W>(L, lane, i, J);
-            }
+            if (dense_level) __syncthreads();
         }
-        for (int base = 0; base < 6 * ncol; base += 64) {
+        for (int base = 0; base < 6 * ncol; base += NT) {
             const int idx = base + lane;
             if (idx < 6 * ncol) {
                 const int J = L.colorder[c0 + idx / 6], r = idx % 6;
@@ -1737,11 +1844,12 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
         }
         __syncthreads();
         LOCAMD_TOC(3);
+        LOCAMD_TOC4(dense_level ? 2 : 1);
         const int ntask = 7 * ncol + 6 * nblk;
         bool ok = true;
         const long long locamd_t1 = clock64();
         (void)locamd_t1;
-        for (int base = 0; base < ntask; base += 64) {
+        for (int base = 0; base < ntask; base += NT) {
             const int idx = base + lane;
             if (idx < ntask) {
                 int kind, i, J, r;  // 0: row r of the diagonal block of J; 1: row r of block (i, J); 2: right-hand side of column J
@@ -1878,8 +1986,9 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
         __syncthreads();
 #ifdef LOCAMD_WINDOW_TIMING
         if (lane == 0) L.tim[4] += clock64() - locamd_t1;
+        if (lane == 0 && LOCAMD_WINDOW_TIMING == 4) L.tim[dense_level ? 6 : 1] += clock64() - locamd_t1;
 #endif
-        if (__ballot(!ok)) return false;
+        if (block_any<NW>(!ok, L.red, lane)) return false;
     }
     LOCAMD_TIC();
     // back substitution: x_J = G_J^-T (y_J - sum_{i in column J} L_iJ^T x_i), levels downwards
@@ -1888,7 +1997,7 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
         long long locamd_ts = clock64();
 #endif
         const int c0 = L.lvl_col[l], ncol = L.lvl_col[l + 1] - c0;
-        for (int base = 0; base < ncol; base += 64) {
+        for (int base = 0; base < ncol; base += NT) {
             const int idx = base + lane;
             if (idx < ncol) {
                 const int J = L.colorder[c0 + idx];
@@ -2217,16 +2326,20 @@ __device__ __forceinline__ bool factor_and_solve_small(const Lds& L, int lane, i
 // JAC: range-edge Jacobians analytic (0) or g2o's central differences (1).  SP: SPARSE path (nv_max <= 64) or SKYLINE.
 // (launch bounds: at least two waves per SIMD, i.e. at most 256 registers — a few rarely used values spill to scratch, which
 //  costs far less than the halved occupancy a 257th register would)
-template <bool GLOBAL_A, int JAC, bool SP, int W>
+template <bool GLOBAL_A, int JAC, bool SP, int W, int NW>
 // (experiment kept as a switch: forcing 3 or 4 waves per SIMD for the workspace-mode SPARSE kernel — 168 / 128 registers, 204 /
 //  484 values spilled to scratch — made BASELINE config 5 slower, 19.7 -> 26.0 / 33.1 ms per 16 384 windows: the extra waves do
 //  not pay for the spill traffic)
 #ifndef LOCAMD_WS_WAVES
 #define LOCAMD_WS_WAVES 2
 #endif
-__global__ void __launch_bounds__(64, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 2) window_lm_kernel(const WindowArgs a) {
+__global__ void __launch_bounds__(64 * NW, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 2) window_lm_kernel(const WindowArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int inst = blockIdx.x;
+    // NW waves per window (NW > 1: windows of 65 .. 512 poses): `lane` is the thread's index in the window's workgroup; the
+    // set-up below runs on wave 0 alone (SOLO), the LM loop on all NT threads
+    constexpr int NT = 64 * NW;
+    constexpr bool SOLO = NW > 1;
     const int lane = threadIdx.x;
     const WindowCaps& c = a.caps;
     const int nv = a.counts[inst * 4 + 0], nr = a.counts[inst * 4 + 1], np = a.counts[inst * 4 + 2], ns = a.counts[inst * 4 + 3];
@@ -2235,11 +2348,15 @@ __global__ void __launch_bounds__(64, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 2) wi
     const size_t nnz_max = sky_nnz_bound(c.nv_max, c.bw_max);
     Lds L;
     L.base = lds; L.recA = nullptr; L.recB = nullptr; L.rec_count = nullptr; L.recA_cap = 0;
+    L.dense = nullptr; L.dense_off = nullptr; L.dense_cap = 0; L.dense_ok = 0;
     // small windows (arrays in LDS, one-word masks): the latency-scheduled factorisation (factor_and_solve_small)
     constexpr bool SMALL = SP && !GLOBAL_A && W == 1 && LOCAMD_SMALL_FACTOR;
     SmallPlan plan;
     plan.level = -1; plan.dJ = 0; plan.colmask = 0; plan.off0 = 0; plan.tables = false;
     __shared__ double s_blk[36];
+    __shared__ double s_red[NW > 1 ? NW * 37 : 1];
+    __shared__ int s_meta[2];
+    L.red = s_red;
 #ifdef LOCAMD_WINDOW_TIMING
     __shared__ long long s_tim[8];
     if (lane < 8) s_tim[lane] = 0;
@@ -2283,6 +2400,7 @@ __global__ void __launch_bounds__(64, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 2) wi
             L.lvl_blk = ti; ti += c.nv_max + 1;
             if (W > 1) { L.lvl_mode = ti; ti += c.nv_max + 1; }
             L.colorder = ti; ti += c.nv_max;
+            if (W > 1) { L.dense_off = ti; ti += c.nv_max + 2; L.dense = ti; L.dense_cap = 2 * c.nv_max; ti += L.dense_cap; }
             L.otask = W > 1 ? otask_ws : ti;
             L.fb = L.last = nullptr;
         } else {
@@ -2299,16 +2417,20 @@ __global__ void __launch_bounds__(64, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 2) wi
         if (!GLOBAL_A) p += (window_table_bytes(c) + 7) / 8;
     }
     L.nlev = 0;
+    if (GLOBAL_A) {
+        L.r_val = a.r_val + (size_t)inst * c.nr_max * 5;
+        L.p_val = a.p_val + (size_t)inst * c.np_max * 18;
+        L.s_val = a.s_val + (size_t)inst * c.ns_max * 48;
+    }
+    const double* gpose_in = a.poses_in + (size_t)inst * c.nv_max * 12;
+    double* gpose = a.poses + (size_t)inst * c.nv_max * 12;
+    if (!SOLO || lane < 64) {
     // edge tables: the values are staged into LDS for small windows and read in place for large ones; the index tables
     // always get a private writable copy (the SPARSE path relabels them)
     for (int i = lane; i < nr * 2; i += 64) L.r_idx[i] = a.r_idx[(size_t)inst * c.nr_max * 2 + i];
     for (int i = lane; i < np; i += 64) L.p_idx[i] = a.p_idx[(size_t)inst * c.np_max + i];
     for (int i = lane; i < ns * 4; i += 64) L.s_idx[i] = a.s_idx[(size_t)inst * c.ns_max * 4 + i];
-    if (GLOBAL_A) {
-        L.r_val = a.r_val + (size_t)inst * c.nr_max * 5;
-        L.p_val = a.p_val + (size_t)inst * c.np_max * 18;
-        L.s_val = a.s_val + (size_t)inst * c.ns_max * 48;
-    } else {
+    if (!GLOBAL_A) {
         double* st_rval = p; p += c.nr_max * 5;
         double* st_pval = p; p += c.np_max * 18;
         double* st_sval = p; p += c.ns_max * 48;
@@ -2324,9 +2446,7 @@ __global__ void __launch_bounds__(64, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 2) wi
         for (int i = lane; i < np * 18; i += 64) st_pval[i] = a.p_val[(size_t)inst * c.np_max * 18 + i];
         for (int i = lane; i < ns * 48; i += 64) st_sval[i] = a.s_val[(size_t)inst * c.ns_max * 48 + i];
     }
-    __syncthreads();
-    const double* gpose_in = a.poses_in + (size_t)inst * c.nv_max * 12;
-    double* gpose = a.poses + (size_t)inst * c.nv_max * 12;
+    sync_<SOLO>();
     if (SP) {
         const int nb_max = (int)(nnz_max / 36);
         int nb;
@@ -2334,8 +2454,8 @@ __global__ void __launch_bounds__(64, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 2) wi
             nb = compute_sparse<GLOBAL_A>(L, lane, nv, c.nv_max, nb_max, nr, ns, a.natural_order != 0, plan.level);
             if (nb > nb_max) { __syncthreads(); nb = compute_sparse<GLOBAL_A>(L, lane, nv, c.nv_max, nb_max, nr, ns, true, plan.level); }  // (the natural order cannot exceed the envelope capacity)
         } else {
-            nb = compute_sparse_mw<W, GLOBAL_A>(L, lane, nv, c.nv_max, nb_max, nr, ns, a.natural_order != 0);
-            if (nb > nb_max) { __syncthreads(); nb = compute_sparse_mw<W, GLOBAL_A>(L, lane, nv, c.nv_max, nb_max, nr, ns, true); }
+            nb = compute_sparse_mw<W, GLOBAL_A, SOLO>(L, lane, nv, c.nv_max, nb_max, nr, ns, a.natural_order != 0);
+            if (nb > nb_max) { sync_<SOLO>(); nb = compute_sparse_mw<W, GLOBAL_A, SOLO>(L, lane, nv, c.nv_max, nb_max, nr, ns, true); }
         }
         // relabel: pose slots -> elimination positions
         for (int e = lane; e < nr; e += 64) {
@@ -2350,9 +2470,16 @@ __global__ void __launch_bounds__(64, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 2) wi
         compute_skyline(L, lane, nv, nr, ns);
         for (int i = lane; i < nv * 12; i += 64) L.pose[i] = gpose_in[i];
     }
-    __syncthreads();
+    sync_<SOLO>();
     if (SMALL) plan = make_small_plan(L, lane, nv, plan.level);
-    compute_incidence<SP>(L, lane, nv, nr, np, ns);
+    compute_incidence<SP, SOLO>(L, lane, nv, nr, np, ns);
+    }
+    if (SOLO) {   // the other waves join: the structure is in LDS / the workspace, the level count in wave 0's registers
+        if (lane == 0) { s_meta[0] = L.nlev; s_meta[1] = L.dense_ok; }
+        __syncthreads();
+        L.nlev = s_meta[0]; L.dense_ok = s_meta[1];
+        L.colmode = 0; L.pushmask = 0;
+    }
 
     constexpr double tau = 1e-5, good_lo = 1.0 / 3.0, good_hi = 2.0 / 3.0;
     constexpr int max_trials = 10;
@@ -2363,7 +2490,7 @@ __global__ void __launch_bounds__(64, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 2) wi
     int it = 0, trials = 0, terminated = 0;
     const bool empty = (nv <= 0) || (nr + np + ns <= 0);
 
-    for (int i = lane; i < n; i += 64) L.x[i] = 0.0;  // the solver's x of a fresh optimize() call
+    for (int i = lane; i < n; i += NT) L.x[i] = 0.0;  // the solver's x of a fresh optimize() call
     __syncthreads();
     bool ok = !empty;
     for (it = 0; it < a.iterations && ok; ++it) {
@@ -2371,38 +2498,38 @@ __global__ void __launch_bounds__(64, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 2) wi
         {
             LOCAMD_TIC();
             const int nnz = L.boff[nv];
-            for (int i = lane; i < nnz; i += 64) L.Hs[i] = 0.0;
+            for (int i = lane; i < nnz; i += NT) L.Hs[i] = 0.0;
             __syncthreads();
             LOCAMD_TOC(2);
         }
         {
             LOCAMD_TIC();
-            evaluate_edges<true, JAC, SP>(a, L, inst, lane, nr, np, ns, cur_chi, plain);  // computeActiveErrors + linearize
+            evaluate_edges<true, JAC, SP, NW>(a, L, inst, lane, nr, np, ns, cur_chi, plain);  // computeActiveErrors + linearize
             last_plain = plain;
             __syncthreads();
             LOCAMD_TOC(1);
         }
         {
             LOCAMD_TIC();
-            build_system<SP>(L, lane, n, nr, ns);
+            build_system<SP, NW>(L, lane, n, nr, ns);
             LOCAMD_TOC(2);
         }
         if (it == 0) {  // computeLambdaInit
             double md = 0.0;
-            for (int j = lane; j < n; j += 64) md = fmax(md, fabs(L.Hs[sky<SP>(L, j, j)]));
-            lambda = tau * wave_max(md);
+            for (int j = lane; j < n; j += NT) md = fmax(md, fabs(L.Hs[sky<SP>(L, j, j)]));
+            lambda = tau * block_max<NW>(md, L.red, lane);
             ni = 2.0;
         }
         double rho = 0.0;
         int q = 0;
         do {
-            for (int i = lane; i < nv * 12; i += 64) L.bak[i] = L.pose[i];  // push
+            for (int i = lane; i < nv * 12; i += NT) L.bak[i] = L.pose[i];  // push
 #ifdef LOCAMD_WINDOW_TIMING
             const long long locamd_tf = clock64();
 #endif
             const bool ok2 = !SP ? factor_and_solve(L, lane, n, lambda)
                              : (SMALL && plan.tables ? factor_and_solve_small(L, lane, nv, lambda, plan)
-                                                     : factor_and_solve_sparse<GLOBAL_A, W>(L, lane, lambda));
+                                                     : factor_and_solve_sparse<GLOBAL_A, W, NW>(L, lane, lambda));
 #ifdef LOCAMD_WINDOW_TIMING
             if (!SP && lane == 0) L.tim[3] += clock64() - locamd_tf;  // SKYLINE: the whole sweep incl. back-substitution (slot 5)
 #endif
@@ -2412,7 +2539,7 @@ __global__ void __launch_bounds__(64, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 2) wi
             // the trial tempChi = max double and pops the step.  Mirrored as is: L.x is only written by a successful
             // back-substitution.
             // update: X <- X * fromVectorMQT(dx), one pose per lane
-            for (int v = lane; v < nv; v += 64) {
+            for (int v = lane; v < nv; v += NT) {
                 const double* dx = L.x + v * 6;
                 double* X = L.pose + v * 12;
                 double Rd[9];
@@ -2429,13 +2556,13 @@ __global__ void __launch_bounds__(64, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 2) wi
             __syncthreads();
             ++trials;
             double temp_chi, plain2;
-            evaluate_edges<false, JAC, SP>(a, L, inst, lane, nr, np, ns, temp_chi, plain2);
+            evaluate_edges<false, JAC, SP, NW>(a, L, inst, lane, nr, np, ns, temp_chi, plain2);
             LOCAMD_TOC(6);
             last_plain = plain2;
             if (!ok2) temp_chi = DBL_MAX;
             double sc = 0.0;
-            for (int j = lane; j < n; j += 64) sc += L.x[j] * (lambda * L.x[j] + L.b[j]);  // computeScale
-            const double scale = wave_sum(sc) + 1e-3;
+            for (int j = lane; j < n; j += NT) sc += L.x[j] * (lambda * L.x[j] + L.b[j]);  // computeScale
+            const double scale = block_sum<NW>(sc, L.red, lane) + 1e-3;
             rho = (cur_chi - temp_chi) / scale;
             if (rho > 0.0 && fabs(temp_chi) <= DBL_MAX) {  // g2o: rho > 0 && isfinite(tempChi)
                 const double r21 = 2.0 * rho - 1.0;
@@ -2448,7 +2575,7 @@ __global__ void __launch_bounds__(64, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 2) wi
                 lambda *= ni;
                 ni *= 2.0;
                 __syncthreads();
-                for (int i = lane; i < nv * 12; i += 64) L.pose[i] = L.bak[i];  // pop
+                for (int i = lane; i < nv * 12; i += NT) L.pose[i] = L.bak[i];  // pop
             }
             __syncthreads();
             ++q;
@@ -2456,8 +2583,8 @@ __global__ void __launch_bounds__(64, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 2) wi
         if (q == max_trials || rho == 0.0) { ok = false; terminated = 1; }
     }
 
-    if (SP) { for (int i = lane; i < nv * 12; i += 64) gpose[i] = L.pose[L.perm[i / 12] * 12 + i % 12]; }
-    else { for (int i = lane; i < nv * 12; i += 64) gpose[i] = L.pose[i]; }
+    if (SP) { for (int i = lane; i < nv * 12; i += NT) gpose[i] = L.pose[L.perm[i / 12] * 12 + i % 12]; }
+    else { for (int i = lane; i < nv * 12; i += NT) gpose[i] = L.pose[i]; }
     if (lane == 0) {
         double* res = a.result + (size_t)inst * 8;
         res[0] = last_plain; res[1] = cur_chi; res[2] = lambda; res[3] = (double)it; res[4] = (double)trials;
@@ -2478,8 +2605,10 @@ size_t window_lds_bytes(const WindowCaps& c, bool global_a) {
     return (window_instance_doubles(c) + (window_table_bytes(c) + 7) / 8 + staged + small_table_doubles(c)) * sizeof(double);
 }
 size_t window_workspace_doubles(const WindowCaps& c) { return window_instance_doubles(c) + window_push_doubles(c); }
+constexpr int WIDE_WAVES = 8;   // waves per window of 65 .. 512 poses (two per SIMD)
+constexpr size_t WIDE_STATIC_LDS = 4096;   // >= the static LDS of the several-waves kernel (reduction scratch: 2.4 KB)
 
-template <bool GLOBAL_A, int JAC, bool SP, int W>
+template <bool GLOBAL_A, int JAC, bool SP, int W, int NW = 1>
 static hipError_t launch_window_t(const WindowArgs& a, size_t lds, hipStream_t stream) {
     // the opt-in to more than 64 KiB of dynamic LDS is per device (and per kernel instantiation)
     static std::atomic<uint64_t> attr_set{0};
@@ -2488,12 +2617,12 @@ static hipError_t launch_window_t(const WindowArgs& a, size_t lds, hipStream_t s
     if (e != hipSuccess) return e;
     const uint64_t bit = 1ull << (dev & 63);
     if (!(attr_set.load(std::memory_order_acquire) & bit)) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&window_lm_kernel<GLOBAL_A, JAC, SP, W>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);  // 288 B of static LDS on top
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&window_lm_kernel<GLOBAL_A, JAC, SP, W, NW>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (NW > 1 ? WIDE_STATIC_LDS : 512));  // static LDS on top
         if (e != hipSuccess) return e;
         attr_set.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL((window_lm_kernel<GLOBAL_A, JAC, SP, W>), dim3((unsigned)a.B), dim3(64), lds, stream, a);
+    hipLaunchKernelGGL((window_lm_kernel<GLOBAL_A, JAC, SP, W, NW>), dim3((unsigned)a.B), dim3(64 * NW), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -2505,7 +2634,11 @@ hipError_t launch_window(const WindowArgs& a, hipStream_t stream) {
     const bool sp = window_sparse_path(a.caps);
     if (sp && window_mask_words(a.caps) > 1) {   // 65 .. 512 poses: 8-word masks, always in the workspace
         if (!global_a) return hipErrorInvalidValue;
-        return a.jacobian ? launch_window_t<true, 1, true, 8>(a, lds, stream) : launch_window_t<true, 0, true, 8>(a, lds, stream);
+        // Their structure tables fill a CU's LDS, so one such window runs per CU: it gets the CU's four SIMDs (WIDE_WAVES
+        // waves); LOCAMD_WINDOW_WAVES=1 in the environment keeps the one-wave kernel (for comparison).
+        static const bool one_wave = [] { const char* v = getenv("LOCAMD_WINDOW_WAVES"); return v && v[0] == '1' && v[1] == 0; }();
+        if (one_wave || lds > 160 * 1024 - WIDE_STATIC_LDS) return a.jacobian ? launch_window_t<true, 1, true, 8>(a, lds, stream) : launch_window_t<true, 0, true, 8>(a, lds, stream);
+        return a.jacobian ? launch_window_t<true, 1, true, 8, WIDE_WAVES>(a, lds, stream) : launch_window_t<true, 0, true, 8, WIDE_WAVES>(a, lds, stream);
     }
     const int sel = (global_a ? 4 : 0) | (a.jacobian ? 2 : 0) | (sp ? 1 : 0);
     switch (sel) {

@@ -37,6 +37,9 @@ if "--sub" in sys.argv:   # library built with `make timing TIMING_LEVEL=2`
 if "--sub3" in sys.argv:   # library built with `make timing TIMING_LEVEL=3`
     names[0], names[1], names[2], names[6] = ("back-substitution: index look-ups + y", "back-substitution: blocks of the column",
                                               "back-substitution: triangular solve", "back-substitution: stores + barrier")
+if "--sub4" in sys.argv:   # library built with `make timing TIMING_LEVEL=4`
+    names[0], names[1], names[2], names[6] = ("factor: column-mode levels", "factor: row-mode levels without dense blocks",
+                                              "factor: dense levels, phase 1 (cooperative sums)", "factor: dense levels, phase 2")
 print(f"{shape} x {NB}{' natural order' if natural else ''}: cycles per solve (lane-0 stamps)")
 for i, nm in enumerate(names):
     print(f"  {nm:45s} {r[i]:12.0f}  {100 * r[i] / r[7]:5.1f} %")
