@@ -271,6 +271,9 @@ struct Lds {
 // level 4: the factorisation by class of level: 0 column-mode levels, 1 row-mode levels without dense blocks, 2 / 6 phase 1 / 2 of
 // the levels with cooperatively summed (dense) blocks
 #define LOCAMD_TOC4(slot) do { if (lane == 0 && LOCAMD_WINDOW_TIMING == 4) L.tim[slot] += clock64() - locamd_t0; } while (0)
+// level 5: the set-up: 0 ordering rounds, 1 relabelling + structure + levels + dense list, 2 incidence lists + shared pairs, 6 the rest
+#define LOCAMD_STAMP5(slot) do { if (lane == 0 && LOCAMD_WINDOW_TIMING == 5) { const long long t = clock64(); L.tim[slot] += t - locamd_t5; locamd_t5 = t; } } while (0)
+#define LOCAMD_T5_DECL long long locamd_t5 = clock64()
 #define LOCAMD_SUB(slot) do { if (lane == 0 && LOCAMD_WINDOW_TIMING == 2) { const long long t = clock64(); L.tim[slot] += t - locamd_ts; locamd_ts = t; } } while (0)
 // level 3: sub-phases of the back-substitution (0 index look-ups, 1 blocks of the column, 2 triangular solve, 6 stores + barrier)
 #define LOCAMD_SUB3(slot) do { if (lane == 0 && LOCAMD_WINDOW_TIMING == 3) { const long long t = clock64(); L.tim[slot] += t - locamd_ts; locamd_ts = t; } } while (0)
@@ -279,6 +282,8 @@ struct Lds {
 #define LOCAMD_SUB(slot) do {} while (0)
 #define LOCAMD_SUB3(slot) do {} while (0)
 #define LOCAMD_TOC4(slot) do {} while (0)
+#define LOCAMD_STAMP5(slot) do {} while (0)
+#define LOCAMD_T5_DECL do {} while (0)
 #endif
 #else
 #define LOCAMD_TIC() do {} while (0)
@@ -286,6 +291,8 @@ struct Lds {
 #define LOCAMD_SUB(slot) do {} while (0)
 #define LOCAMD_SUB3(slot) do {} while (0)
 #define LOCAMD_TOC4(slot) do {} while (0)
+#define LOCAMD_STAMP5(slot) do {} while (0)
+#define LOCAMD_T5_DECL do {} while (0)
 #endif
 
 #pragma clang fp contract(off)
@@ -977,6 +984,7 @@ __device__ __forceinline__ int compute_sparse_mw(Lds& L, int lane, int nv, int n
     u64* adj = L.scr;      // [nv][W] current adjacency, caller's labels
     u64* st = L.rowmask;   // [nv][W] structure at elimination, caller's labels (the row masks overwrite it later)
     const int NC = (nv + 63) >> 6;
+    LOCAMD_T5_DECL;
     for (int i = lane; i < nv * W; i += 64) adj[i] = 0;
     sync_<SOLO>();
     for (int e = lane; e < nr; e += 64) {
@@ -1087,6 +1095,7 @@ __device__ __forceinline__ int compute_sparse_mw(Lds& L, int lane, int nv, int n
         ++round;
     }
     const int nlev = round;
+    LOCAMD_STAMP5(0);
     if (lane == 0) L.lvl_col[nlev] = pos;
     // relabel: colmask[position of v] = positions of the poses in st[v]
     for (int i = lane; i < nv * W; i += 64) L.colmask[i] = 0;
@@ -1212,6 +1221,7 @@ __device__ __forceinline__ int compute_sparse_mw(Lds& L, int lane, int nv, int n
         if (dcount > L.dense_cap) L.dense_ok = 0;
         sync_<SOLO>();
     }
+    LOCAMD_STAMP5(1);
     return nb;
 }
 
@@ -1226,6 +1236,7 @@ __device__ __forceinline__ int compute_sparse_mw(Lds& L, int lane, int nv, int n
 //                     listed in fold order by ballot compaction.
 template <bool SP, bool SOLO>
 __device__ __forceinline__ void compute_incidence(const Lds& L, int lane, int nv, int nr, int np, int ns) {
+    LOCAMD_T5_DECL;
     for (int v0 = 0; v0 < nv; v0 += 64) {
         const int v = v0 + lane;
         int cnt = 0;
@@ -1289,6 +1300,100 @@ __device__ __forceinline__ void compute_incidence(const Lds& L, int lane, int nv
     }
     if (lane == 0) L.shared[0] = cnt;
     sync_<SOLO>();
+    LOCAMD_STAMP5(2);
+}
+
+// The incidence lists of a window that runs on several waves (NW > 1; called by ALL threads, real barriers): edge-parallel.
+// One lane per pose walking every edge table twice (compute_incidence) is 2 x (poses / 64) x edges dependent look-ups on one
+// wave — 15 % of a BASELINE config 4 solve (2815 range edges, 266 poses, the edge tables in the HBM workspace).  Here
+//   counts      every edge bumps its endpoints' counters (LDS atomics), wave 0 scans them;
+//   filling     every edge takes the next free slot of its endpoints' lists (atomic cursor: arbitrary order) in a scratch copy
+//               (the edge-record region, unused until the first linearisation) and notes the owner next to it;
+//   fold order  every entry ranks itself inside its own list by (kind, edge number) — exactly the order the one-lane-per-pose
+//               walk produces — and moves to its place: the sums over a pose's edges stay bit-reproducible.
+template <bool SP, int NW>
+__device__ __forceinline__ void compute_incidence_wide(const Lds& L, int tid, int nv, int nr, int np, int ns) {
+    constexpr int NT = 64 * NW;
+    LOCAMD_T5_DECL;
+    const int lane = tid;   // (the timing macros)
+    int* cur = reinterpret_cast<int*>(L.scr);        // nv cursors (the ordering's scratch is free)
+    int* tmp = reinterpret_cast<int*>(L.rrec);       // [ninc] codes, then [ninc] owners
+    for (int v = tid; v <= nv; v += NT) L.ioff[v] = 0;
+    __syncthreads();
+    for (int e = tid; e < nr; e += NT) {
+        atomicAdd(&L.ioff[L.r_idx[2 * e] + 1], 1);
+        const int v1 = L.r_idx[2 * e + 1];
+        if (v1 >= 0) atomicAdd(&L.ioff[v1 + 1], 1);
+    }
+    for (int e = tid; e < np; e += NT) atomicAdd(&L.ioff[L.p_idx[e] + 1], 1);
+    for (int e = tid; e < ns; e += NT) { atomicAdd(&L.ioff[L.s_idx[4 * e] + 1], 1); atomicAdd(&L.ioff[L.s_idx[4 * e + 1] + 1], 1); }
+    __syncthreads();
+    if (tid < 64) {   // exclusive scan, wave 0
+        int carry = 0;
+        for (int v0 = 0; v0 < nv; v0 += 64) {
+            const int v = v0 + tid;
+            const int c = v < nv ? L.ioff[v + 1] : 0;
+            const int ex = wave_excl_scan_i(c, tid) + carry;
+            carry = __shfl(ex + c, 63, 64);
+            sync_<true>();
+            if (v < nv) { L.ioff[v] = ex; cur[v] = ex; }
+            sync_<true>();
+        }
+        if (tid == 0) L.ioff[nv] = carry;
+    }
+    __syncthreads();
+    const int ninc = L.ioff[nv];
+    auto put = [&](int v, int code) { const int p = atomicAdd(&cur[v], 1); tmp[p] = code; tmp[ninc + p] = v; };
+    for (int e = tid; e < nr; e += NT) {
+        put(L.r_idx[2 * e], e);
+        const int v1 = L.r_idx[2 * e + 1];
+        if (v1 >= 0) put(v1, (1 << INC_ROLE_SHIFT) | e);
+    }
+    for (int e = tid; e < np; e += NT) put(L.p_idx[e], (1 << INC_KIND_SHIFT) | e);
+    for (int e = tid; e < ns; e += NT) { put(L.s_idx[4 * e], (2 << INC_KIND_SHIFT) | e); put(L.s_idx[4 * e + 1], (2 << INC_KIND_SHIFT) | (1 << INC_ROLE_SHIFT) | e); }
+    __syncthreads();
+    constexpr int KEY = ~(1 << INC_ROLE_SHIFT);
+    for (int p = tid; p < ninc; p += NT) {
+        const int code = tmp[p], v = tmp[ninc + p];
+        const int key = code & KEY;
+        const int q0 = L.ioff[v], q1 = L.ioff[v + 1];
+        int rank = 0;
+        for (int q = q0; q < q1; ++q) rank += (tmp[q] & KEY) < key;
+        L.ilist[q0 + rank] = code;
+    }
+    __syncthreads();
+    LOCAMD_STAMP5(2);
+    // binary edges that share their pair of poses with another edge (see compute_incidence)
+    auto block_entry = [&](int t) {
+        const bool is_r = t < nr;
+        const int va = is_r ? L.r_idx[2 * t] : L.s_idx[4 * (t - nr)], vb = is_r ? L.r_idx[2 * t + 1] : L.s_idx[4 * (t - nr) + 1];
+        return vb >= 0 ? blk_off<SP>(L, max(va, vb), min(va, vb)) : -1;
+    };
+    const int nbin = nr + ns;
+    for (int t = tid; t < nbin; t += NT) { const int a0 = block_entry(t); if (a0 >= 0) { L.Hs[a0] = (double)(t + 1); L.Hs[a0 + 1] = 0.0; } }
+    __syncthreads();
+    for (int t = tid; t < nbin; t += NT) { const int a0 = block_entry(t); if (a0 >= 0 && L.Hs[a0] != (double)(t + 1)) L.Hs[a0 + 1] = -1.0; }
+    __syncthreads();
+    for (int t = tid; t < nbin; t += NT) {
+        const int a0 = block_entry(t);
+        if (a0 >= 0 && L.Hs[a0 + 1] == -1.0) atomicMin(reinterpret_cast<u64*>(L.Hs + a0), (u64)__double_as_longlong((double)(t + 1)));
+    }
+    __syncthreads();
+    if (tid < 64) {   // compaction in fold order, wave 0
+        int cnt = 0;
+        for (int t0 = 0; t0 < nbin; t0 += 64) {
+            const int t = t0 + tid;
+            const int a0 = t < nbin ? block_entry(t) : -1;
+            const bool sh = a0 >= 0 && L.Hs[a0 + 1] == -1.0;
+            const bool first = sh && L.Hs[a0] == (double)(t + 1);
+            const u64 bal = __ballot(sh);
+            if (sh) L.shared[1 + cnt + __popcll(bal & ((1ull << tid) - 1))] = (first ? (1 << INC_KIND_SHIFT) : 0) | t;
+            if (t >= nr && t < nbin) L.s_idx[4 * (t - nr) + 3] = sh ? 1 : 0;
+            cnt += __popcll(bal);
+        }
+        if (tid == 0) L.shared[0] = cnt;
+    }
+    __syncthreads();
 }
 
 // Fold the edge records into H (skyline lower triangle) and b: H_vv = sum J_v^T (rho' Omega) J_v etc., every entry summed
@@ -2472,13 +2577,14 @@ __global__ void __launch_bounds__(64 * NW, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 
     }
     sync_<SOLO>();
     if (SMALL) plan = make_small_plan(L, lane, nv, plan.level);
-    compute_incidence<SP, SOLO>(L, lane, nv, nr, np, ns);
+    if (!SOLO) compute_incidence<SP, SOLO>(L, lane, nv, nr, np, ns);
     }
     if (SOLO) {   // the other waves join: the structure is in LDS / the workspace, the level count in wave 0's registers
         if (lane == 0) { s_meta[0] = L.nlev; s_meta[1] = L.dense_ok; }
         __syncthreads();
         L.nlev = s_meta[0]; L.dense_ok = s_meta[1];
         L.colmode = 0; L.pushmask = 0;
+        compute_incidence_wide<SP, NW>(L, lane, nv, nr, np, ns);
     }
 
     constexpr double tau = 1e-5, good_lo = 1.0 / 3.0, good_hi = 2.0 / 3.0;
@@ -2486,6 +2592,7 @@ __global__ void __launch_bounds__(64 * NW, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 
     double lambda = 0.0, ni = 2.0, cur_chi = 0.0, last_plain = 0.0;
 #ifdef LOCAMD_WINDOW_TIMING
     if (lane == 0 && LOCAMD_WINDOW_TIMING < 2) L.tim[0] += clock64() - t_start;
+    if (lane == 0 && LOCAMD_WINDOW_TIMING == 5) L.tim[6] += clock64() - t_start - L.tim[0] - L.tim[1] - L.tim[2];
 #endif
     int it = 0, trials = 0, terminated = 0;
     const bool empty = (nv <= 0) || (nr + np + ns <= 0);

@@ -40,6 +40,9 @@ if "--sub3" in sys.argv:   # library built with `make timing TIMING_LEVEL=3`
 if "--sub4" in sys.argv:   # library built with `make timing TIMING_LEVEL=4`
     names[0], names[1], names[2], names[6] = ("factor: column-mode levels", "factor: row-mode levels without dense blocks",
                                               "factor: dense levels, phase 1 (cooperative sums)", "factor: dense levels, phase 2")
+if "--sub5" in sys.argv:   # library built with `make timing TIMING_LEVEL=5`
+    names[0], names[1], names[2], names[6] = ("set-up: ordering rounds", "set-up: relabelling, structure, levels, dense list",
+                                              "set-up: incidence lists + shared pairs", "set-up: staging, edge relabelling")
 print(f"{shape} x {NB}{' natural order' if natural else ''}: cycles per solve (lane-0 stamps)")
 for i, nm in enumerate(names):
     print(f"  {nm:45s} {r[i]:12.0f}  {100 * r[i] / r[7]:5.1f} %")
