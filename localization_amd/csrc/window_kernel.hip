@@ -605,6 +605,14 @@ __host__ __device__ inline size_t sky_nnz_bound(int nv, int bw) {
     return s;
 }
 __host__ __device__ inline bool window_sparse_path(const WindowCaps& c) { return c.nv_max <= 512; }
+// Capacity of H / L in entries.  Windows of 65 .. 512 poses keep them in the HBM workspace, where room is cheap: they get the
+// envelope of a band of at least 3, so that a nested-dissection order of a long chain (one fill block per eliminated pose:
+// 3 n blocks where the natural order has 2 n) fits and the window factors in ~log2(n) levels instead of n (a 500-pose chain
+// of cfg/uwb_pose.yaml's length: 500 levels, 71 ms per solve with the caller's band of 1).
+__host__ __device__ inline size_t window_nnz_capacity(const WindowCaps& c) {
+    const int bw = (c.nv_max > 64 && c.nv_max <= 512 && c.bw_max < 3) ? (c.nv_max > 3 ? 3 : c.nv_max - 1) : c.bw_max;
+    return sky_nnz_bound(c.nv_max, bw);
+}
 __host__ __device__ inline int window_mask_words(const WindowCaps& c) { return c.nv_max <= 64 ? 1 : 8; }
 
 // entries of the per-pose incidence lists: every edge once per moving endpoint
@@ -631,20 +639,20 @@ __host__ __device__ inline bool window_index_in_lds(const WindowCaps& c) {
 // writable copy of the edge index tables) — the layout the kernel carves, in LDS or in the HBM workspace
 __host__ __device__ inline size_t window_instance_doubles(const WindowCaps& c) {
     const size_t n_max = 6 * (size_t)c.nv_max;
-    return 2 * sky_nnz_bound(c.nv_max, c.bw_max) + 4 * n_max + 2 * (size_t)c.nv_max * 12 + (size_t)c.nr_max * RREC + (size_t)c.np_max * PREC +
+    return 2 * window_nnz_capacity(c) + 4 * n_max + 2 * (size_t)c.nv_max * 12 + (size_t)c.nr_max * RREC + (size_t)c.np_max * PREC +
            (size_t)c.ns_max * SREC + window_index_doubles(c);
 }
 // workspace mode only: the pushed updates and their per-parent sums (28 doubles per column each), and for 8-word windows the
 // off-diagonal task list
 __host__ __device__ inline size_t window_push_doubles(const WindowCaps& c) {
     if (!window_sparse_path(c)) return 0;
-    return 56 * (size_t)c.nv_max + (window_mask_words(c) > 1 ? ints_as_doubles(sky_nnz_bound(c.nv_max, c.bw_max) / 36) : 0);
+    return 56 * (size_t)c.nv_max + (window_mask_words(c) > 1 ? ints_as_doubles(window_nnz_capacity(c) / 36) : 0);
 }
 // bytes of the small index tables that always live in LDS
 __host__ __device__ inline size_t window_table_bytes(const WindowCaps& c) {
     const size_t nv = (size_t)c.nv_max;
     if (!window_sparse_path(c)) return (4 * nv + 2) * sizeof(int);  // fb, last, boff[nv + 1], ioff[nv + 1]
-    const size_t nb_max = sky_nnz_bound(c.nv_max, c.bw_max) / 36;
+    const size_t nb_max = window_nnz_capacity(c) / 36;
     if (window_mask_words(c) == 1)
         return 3 * nv * sizeof(u64) + (6 * nv + 4 + nb_max) * sizeof(int);  // rowmask, colmask, scr; perm, boff, ioff, lvl_col, lvl_blk, colorder, otask
     // 8-word masks: rowmask, colmask, scr [nv][8], pushw [8]; rowpre [nv][8], perm, boff, ioff, lvl_col, lvl_blk, lvl_mode, colorder
@@ -657,12 +665,12 @@ __host__ __device__ inline size_t window_table_bytes(const WindowCaps& c) {
 // off-diagonal block), continuation records for further earlier columns (capacity: one per block; a window that needs more
 // runs the generic look-ups), stage-B records (one per block), the hand-out counter
 __host__ __device__ inline size_t small_recA_capacity(const WindowCaps& c) {
-    const size_t nb_max = sky_nnz_bound(c.nv_max, c.bw_max) / 36;
+    const size_t nb_max = window_nnz_capacity(c) / 36;
     return (size_t)c.nv_max + 2 * nb_max;
 }
 __host__ __device__ inline size_t small_table_doubles(const WindowCaps& c) {
     if (!window_sparse_path(c) || window_mask_words(c) != 1) return 0;
-    return 2 * small_recA_capacity(c) + sky_nnz_bound(c.nv_max, c.bw_max) / 36 + 2;
+    return 2 * small_recA_capacity(c) + window_nnz_capacity(c) / 36 + 2;
 }
 
 // offset of block (i, K), K <= i, in the storage of H / L
@@ -2450,7 +2458,7 @@ __global__ void __launch_bounds__(64 * NW, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 
     const int nv = a.counts[inst * 4 + 0], nr = a.counts[inst * 4 + 1], np = a.counts[inst * 4 + 2], ns = a.counts[inst * 4 + 3];
     const int n = 6 * nv;
     const int n_max = 6 * c.nv_max;
-    const size_t nnz_max = sky_nnz_bound(c.nv_max, c.bw_max);
+    const size_t nnz_max = window_nnz_capacity(c);
     Lds L;
     L.base = lds; L.recA = nullptr; L.recB = nullptr; L.rec_count = nullptr; L.recA_cap = 0;
     L.dense = nullptr; L.dense_off = nullptr; L.dense_cap = 0; L.dense_ok = 0;
