@@ -392,3 +392,44 @@ def test_several_edges_on_one_pair_of_poses(gpu):
     assert (res[::2, 6] == 2 * (T - 1)).all() and (res[1::2, 6] == 3 * (T - 1)).all()   # every binary edge is on a shared pair
     d = np.abs(wb.poses[:, :, 9:] - want_t)
     assert np.isfinite(wb.poses).all() and d.max() < 1e-7 and np.median(d) < 1e-9, (d.max(), np.median(d))
+
+
+def test_wide_windows_ragged_batch(gpu):
+    """Windows of 65 .. 512 poses run on eight waves each (set-up on wave 0, LM loop on all 512 threads, block-wide
+    reductions): a batch sized for 96 poses whose instances use 0, 1, 1, 5, 70 and 96 of them — no pose at all, a pose
+    without edges, the snapshot shape, small and full windows with IMU priors, key-frame pose factors and a lever arm — and
+    one whose every range has zero information (the failed-Cholesky path with all waves)."""
+    import localization_amd as la
+    from _oracle_window import oracle_solve_instance
+    rng = np.random.default_rng(4242)
+    sizes = [0, 1, 1, 5, 70, 96, 3]
+    B, T = len(sizes), 96
+    wb = la.WindowBatch(B, T, 2 * T, T, T)
+    for i, Ti in enumerate(sizes):
+        if Ti == 0:
+            continue
+        if i == 1:
+            wb.add_pose(i, [1.0, 2.0, 3.0])
+            continue
+        est_t, est_R, off, ranges, smooth, priors, se3 = _random_window(rng, Ti, True, Ti > 1, True)
+        for k in range(Ti):
+            assert wb.add_pose(i, est_t[k], est_R[k]) == k
+        singular = i == 6
+        for (k, a, d, info) in ranges: wb.add_range(i, k, a, d, 0.0 if singular else info, off, anchor=True)
+        if singular:
+            continue
+        for (k0, k1, d, info) in smooth: wb.add_range(i, k0, k1, d, info)
+        for (k, t, R, dg) in priors: wb.add_prior(i, k, t, R, dg)
+        for (ki, kj, t, R, info) in se3: wb.add_se3(i, ki, kj, t, R, info, True)
+    before = wb.poses.copy()
+    want = [oracle_solve_instance(wb, i, ANCH) for i in range(B)]
+    solver = la.WindowSolver(ANCH, B, T, 2 * T, T, T)
+    res = solver.solve(wb)
+    solver.close()
+    assert np.array_equal(wb.poses[0], before[0]) and np.array_equal(wb.poses[1], before[1]) and res[0, 4] == 0 and res[1, 4] == 0
+    assert np.array_equal(wb.poses[6], before[6]) and res[6, 5] == 1 and res[6, 4] == 10 and res[6, 3] == 1
+    for i in (2, 3, 4, 5):
+        poses, chi, st = want[i]
+        d = np.abs(wb.poses[i, :sizes[i]] - poses).max()
+        assert d < 1e-7, (i, d)
+        assert abs(res[i, 0] - chi) <= 1e-6 * max(1.0, abs(chi)), (i, res[i, 0], chi)
