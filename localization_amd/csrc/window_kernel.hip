@@ -242,6 +242,8 @@ struct Lds {
     int *ioff, *ilist;      // per pose: its incident edges in fold order (CSR), entry = kind << 28 | role << 27 | edge
     int *shared;            // [0] = count, then the binary edges (range e, or nr + SE3 e) whose pair of poses has another edge, in fold order
     double* blk; // 6x6 scratch: the diagonal block being factored (SKYLINE path)
+    double* root;            // 8-word windows: LDS scratch of the dense root supernode ((6 m + 1) x 6 m doubles), or nullptr
+    int root_level;          //   first level of the root supernode (nlev: none)
     int *dense, *dense_off;  // 8-word windows: the cooperatively summed (dense) blocks / right-hand sides, by level (compute_sparse_mw)
     int dense_cap, dense_ok; //   capacity; 0 = the list overflowed: nothing is summed cooperatively
     double* red; // several waves per window: NW doubles for the block-wide reductions, then NW x 36 for the cooperative sums
@@ -635,6 +637,16 @@ __host__ __device__ inline bool window_index_in_lds(const WindowCaps& c) {
     return bytes <= INDEX_TABLES_LDS_MAX_BIG && bytes + window_table_bytes(c) + 1024 <= 160 * 1024 - 512;
 }
 
+// 8-word windows: the trailing clique of the elimination order (BASELINE config 4's ten unknown anchors; the last separator of
+// a nested dissection in general) is factored as ONE dense supernode of up to ROOT_MAX poses in LDS — when the LDS has room
+constexpr int ROOT_MAX = 10;
+__host__ __device__ inline size_t window_root_lds_doubles(const WindowCaps& c) {
+    if (!window_sparse_path(c) || window_mask_words(c) == 1) return 0;
+    const size_t need = (size_t)(6 * ROOT_MAX + 1) * (6 * ROOT_MAX);
+    const size_t used = (window_table_bytes(c) + 7) / 8 * 8 + (window_index_in_lds(c) ? window_index_doubles(c) * 8 : 0);
+    return used + need * 8 <= 160 * 1024 - 4096 ? need : 0;
+}
+
 // doubles of one instance's MAIN arrays (block-sparse pair, dense vectors, poses, edge records, incidence lists, a
 // writable copy of the edge index tables) — the layout the kernel carves, in LDS or in the HBM workspace
 __host__ __device__ inline size_t window_instance_doubles(const WindowCaps& c) {
@@ -902,16 +914,16 @@ template <int W> __device__ __forceinline__ bool block_is_presummed(const Lds& L
 // tasks to pick up; for the diagonal (i == J) only r >= c is meaningful.  One WAVE per block (the dense blocks of a level are
 // independent: with several waves per window each wave takes its own); the caller's barrier follows the level's last block.
 template <int W>
-__device__ __forceinline__ void presum_block(const Lds& L, int lane, int i, int J) {   // lane: 0 .. 63 within the wave
+__device__ __forceinline__ void presum_block(const Lds& L, int lane, int i, int J, int Kend) {   // lane: 0 .. 63 within the wave; columns K < Kend <= J
     double acc[36];
 #pragma unroll
     for (int q = 0; q < 36; ++q) acc[q] = 0.0;
     const int rowi = L.boff[i], rowJ = L.boff[J];
-    for (int K0 = 0; K0 < J; K0 += 64) {
+    for (int K0 = 0; K0 < Kend; K0 += 64) {
         const int K = K0 + lane;
         const int w = K >> 6;
         // (a pushed child's update reaches its parent through the reduction step: not again here)
-        const bool has = K < J && (((L.rowmask[i * W + w] & L.rowmask[J * W + w]) >> (K & 63)) & 1ull) && !pushed<W>(L, K);
+        const bool has = K < Kend && (((L.rowmask[i * W + w] & L.rowmask[J * W + w]) >> (K & 63)) & 1ull) && !pushed<W>(L, K);
         if (has) {
             const double* bki = L.Ls + rowi + 36 * row_rank<W>(L, i, K);
             const double* bkj = L.Ls + rowJ + 36 * row_rank<W>(L, J, K);
@@ -945,15 +957,15 @@ template <int W> __device__ __forceinline__ bool rhs_is_presummed(const Lds& L, 
     return n >= DENSE_K;
 }
 template <int W>
-__device__ __forceinline__ void presum_rhs(const Lds& L, int lane, int J) {   // lane: 0 .. 63 within the wave
+__device__ __forceinline__ void presum_rhs(const Lds& L, int lane, int J, int Kend) {   // lane: 0 .. 63 within the wave; columns K < Kend <= J
     double acc[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) acc[c] = 0.0;
     const int rowJ = L.boff[J];
-    for (int K0 = 0; K0 < J; K0 += 64) {
+    for (int K0 = 0; K0 < Kend; K0 += 64) {
         const int K = K0 + lane;
         const int w = K >> 6;
-        const bool has = K < J && ((L.rowmask[J * W + w] >> (K & 63)) & 1ull) && !pushed<W>(L, K);
+        const bool has = K < Kend && ((L.rowmask[J * W + w] >> (K & 63)) & 1ull) && !pushed<W>(L, K);
         if (has) {
             const double* bkj = L.Ls + rowJ + 36 * row_rank<W>(L, J, K);
             double yk[6];
@@ -970,6 +982,17 @@ __device__ __forceinline__ void presum_rhs(const Lds& L, int lane, int J) {   //
         const double tot = wave_sum(acc[c]);
         if (lane == c) L.yrow[6 * J + c] = tot;
     }
+}
+
+// 1/sqrt(d) for a pivot d > 0: hardware seed (~2^-24) + one third-order step y (1 + e/2 + 3 e^2/8), e = 1 - d y^2: the error
+// term e^3 is far below an ulp; four dependent operations after the seed (the Goldschmidt pair + Newton used elsewhere: eight)
+__device__ __forceinline__ double pivot_rsqrt(double d) {
+    const double y = __builtin_amdgcn_rsq(d);
+    const double t = d * y;
+    const double e = __builtin_fma(-t, y, 1.0);
+    const double pq = __builtin_fma(0.375, e, 0.5);
+    const double ye = y * e;
+    return __builtin_fma(ye, pq, y);
 }
 
 template <int W> __device__ __forceinline__ bool level_is_column_mode(const Lds& L, int l) {
@@ -1228,6 +1251,34 @@ __device__ __forceinline__ int compute_sparse_mw(Lds& L, int lane, int nv, int n
         if (lane == 0) L.dense_off[nlev] = dcount;
         if (dcount > L.dense_cap) L.dense_ok = 0;
         sync_<SOLO>();
+    }
+    // root supernode: the trailing run of single-column levels whose columns hold ALL later poses (a clique: the ten unknown
+    // anchors of BASELINE config 4 — and the last tag pose, which the ordering eliminates among them —, the top separator of a
+    // nested dissection), at most ROOT_MAX of them, none with a pushed child (whose update arrives by the reduction step)
+    {
+        int lr = nlev;
+        if (L.root != nullptr && L.dense_ok) {
+            while (lr > 0 && nlev - (lr - 1) <= ROOT_MAX) {
+                const int l = lr - 1;
+                if (L.lvl_col[l + 1] - L.lvl_col[l] != 1) break;
+                const int J = L.lvl_col[l];
+                int cnt = 0;
+#pragma unroll
+                for (int w = 0; w < W; ++w) cnt += __popcll(L.colmask[J * W + w]);
+                if (cnt != nv - 1 - J) break;
+                lr = l;
+            }
+            const int jr = lr < nlev ? L.lvl_col[lr] : nv, m = nv - jr;
+            bool good = m >= 2;
+            for (int a = 0; a < m && good; ++a) {
+                u64 pushed_children = 0;
+#pragma unroll
+                for (int w = 0; w < W; ++w) pushed_children |= L.rowmask[(jr + a) * W + w] & below_word<W>(jr, w) & L.pushw[w];
+                good = pushed_children == 0;
+            }
+            if (!good) lr = nlev;
+        }
+        L.root_level = lr;
     }
     LOCAMD_STAMP5(1);
     return nb;
@@ -1663,6 +1714,114 @@ __device__ __forceinline__ bool factor_and_solve(const Lds& L, int lane, int n, 
     return true;
 }
 
+// The root supernode (see compute_sparse_mw): the trailing clique of m <= ROOT_MAX poses as ONE dense (6 m) x (6 m) system in
+// LDS — S = H_root + lambda I - sum over the columns BEFORE the root of L L^T (the cooperative sums, one wave per block, all
+// blocks in one batch), a right-looking Cholesky with every thread of the workgroup on the trailing update (the right-hand
+// side rides along as one more row), the back-substitution, x_root.  As eleven sequential levels of one column each (their
+// sums, a diagonal-row phase, a row-task phase, three barriers and a handful of lanes per level) the ten anchors of BASELINE
+// config 4 were a third of its solve.
+template <int W, int NW>
+__device__ __forceinline__ bool root_factor_and_solve(const Lds& L, int tid, int nv, double lambda) {
+    constexpr int NT = 64 * NW;
+    const int jr = L.lvl_col[L.root_level], m = nv - jr, n = 6 * m;
+    double* S = L.root;   // rows 0 .. n - 1: the lower triangle; row n: the right-hand side; row-major, n per row
+    const int npair = m * (m + 1) / 2, nent = npair + m;
+    auto pair_of = [&](int e, int& a, int& b) { a = 0; while ((a + 1) * (a + 2) / 2 <= e) ++a; b = e - a * (a + 1) / 2; };
+    const int lane = tid;   // (the timing macros)
+    (void)lane;
+    LOCAMD_TIC();
+    for (int e0 = 0; e0 < nent; e0 += NW) {
+        const int e = e0 + (tid >> 6);
+        if (e < nent) {
+            if (e < npair) { int a, b; pair_of(e, a, b); presum_block<W>(L, tid & 63, jr + a, jr + b, jr); }
+            else presum_rhs<W>(L, tid & 63, jr + (e - npair), jr);
+        }
+    }
+    __syncthreads();
+    LOCAMD_TOC4(0);
+    for (int q = tid; q < npair * 36 + n; q += NT) {
+        if (q < npair * 36) {
+            int a, b;
+            pair_of(q / 36, a, b);
+            const int k = q % 36, r = k % 6, c = k / 6;
+            if (a == b && r < c) continue;
+            const int off = blk_off<true>(L, jr + a, jr + b) + k;
+            double v = L.Hs[off] - L.Ls[off];
+            if (a == b && r == c) v += lambda;
+            S[(6 * a + r) * n + 6 * b + c] = v;
+        } else {
+            const int k = q - npair * 36;
+            S[n * n + k] = L.b[6 * jr + k] - L.yrow[6 * jr + k];
+        }
+    }
+    __syncthreads();
+    bool ok = true;
+    // blocked right-looking Cholesky, 6 columns per step, two barriers per step: every thread factors the step's diagonal
+    // block itself (registers), the rows below it (and the right-hand side, row n) are solved one per thread, the trailing
+    // update is a wave per row and a lane per column
+    for (int bj = 0; bj < m; ++bj) {
+        const int j0 = 6 * bj;
+        double A[6][6], ig[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+#pragma unroll
+            for (int r = c; r < 6; ++r) A[r][c] = S[(j0 + r) * n + j0 + c];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const double g = pivot_rsqrt(A[j][j]);
+            ig[j] = g;
+#pragma unroll
+            for (int i2 = j + 1; i2 < 6; ++i2) A[i2][j] *= g;
+#pragma unroll
+            for (int i2 = j + 1; i2 < 6; ++i2)
+#pragma unroll
+                for (int c = j + 1; c <= i2; ++c) A[i2][c] = __builtin_fma(-A[i2][j], A[c][j], A[i2][c]);
+        }
+        ok = ok && (((ig[0] + ig[1]) + (ig[2] + ig[3])) + (ig[4] + ig[5]) < DBL_MAX);   // (a pivot <= 0 or not finite: NaN / inf)
+        const int i = j0 + 6 + tid;   // rows below the block, the right-hand side last
+        if (i <= n) {
+            double sv[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) sv[c] = S[i * n + j0 + c];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                sv[c] *= ig[c];
+#pragma unroll
+                for (int c2 = c + 1; c2 < 6; ++c2) sv[c2] = __builtin_fma(-sv[c], A[c2][c], sv[c2]);
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) S[i * n + j0 + c] = sv[c];
+        }
+        __syncthreads();
+        if (tid == 0) {   // (nobody reads the diagonal block any more: its factor and the inverse pivots, for the back-substitution)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                S[(j0 + c) * n + j0 + c] = ig[c];
+#pragma unroll
+                for (int r = c + 1; r < 6; ++r) S[(j0 + r) * n + j0 + c] = A[r][c];
+            }
+        }
+        const int c = j0 + 6 + (tid & 63);
+        for (int i2 = j0 + 6 + (tid >> 6); i2 <= n; i2 += NW) {
+            if (c <= i2 && c < n) {
+                double acc = S[i2 * n + c];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) acc = __builtin_fma(-S[i2 * n + j0 + k], S[c * n + j0 + k], acc);
+                S[i2 * n + c] = acc;
+            }
+        }
+        __syncthreads();
+    }
+    if (block_any<NW>(!ok, L.red, tid)) return false;
+    for (int j = n - 1; j >= 0; --j) {
+        const double xj = S[n * n + j] * S[j * n + j];
+        if (tid < j) S[n * n + tid] = __builtin_fma(-S[j * n + tid], xj, S[n * n + tid]);
+        if (tid == 0) L.x[6 * jr + j] = xj;
+        __syncthreads();
+    }
+    return true;
+}
+
 // SPARSE path: (H + lambda I) x = b, level by level over the elimination tree.  Per level (its block columns J are
 // mutually independent):
 //   phase 1  the six rows of every diagonal block form S_JJ = H_JJ + lambda I - sum_K L_JK L_JK^T and publish it RAW into
@@ -1681,7 +1840,9 @@ __device__ __forceinline__ bool factor_and_solve(const Lds& L, int lane, int n, 
 template <bool GLOBAL_A, int W, int NW>
 __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, double lambda) {
     constexpr int NT = 64 * NW;   // (`lane` is the thread's index in its window's workgroup)
-    for (int l = 0; l < L.nlev; ++l) {
+    // (8-word windows: the levels from root_level on are the root supernode, factored densely in LDS after the others)
+    const int lr = (W > 1 && GLOBAL_A) ? L.root_level : L.nlev;
+    for (int l = 0; l < lr; ++l) {
         const int c0 = L.lvl_col[l], ncol = L.lvl_col[l + 1] - c0;
         const int b0 = L.lvl_blk[l], nblk = L.lvl_blk[l + 1] - b0;
         if (GLOBAL_A) {
@@ -1898,8 +2059,8 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
                 if (e < d1) {
                     const int code = L.dense[e];
                     const int J = code & 65535, i = (code >> 16) & 32767;
-                    if (code < 0) presum_rhs<W>(L, lane & 63, J);
-                    else presum_block<W>(L, lane & 63, i, J);
+                    if (code < 0) presum_rhs<W>(L, lane & 63, J, J);
+                    else presum_block<W>(L, lane & 63, i, J, J);
                 }
             }
             if (dense_level) __syncthreads();
@@ -2103,9 +2264,16 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
 #endif
         if (block_any<NW>(!ok, L.red, lane)) return false;
     }
+    if (W > 1 && GLOBAL_A && lr < L.nlev) {
+        LOCAMD_TIC();
+        const bool okr = root_factor_and_solve<W, NW>(L, lane, L.lvl_col[L.nlev], lambda);
+        LOCAMD_TOC(3);
+        LOCAMD_TOC4(2);
+        if (!okr) return false;
+    }
     LOCAMD_TIC();
     // back substitution: x_J = G_J^-T (y_J - sum_{i in column J} L_iJ^T x_i), levels downwards
-    for (int l = L.nlev - 1; l >= 0; --l) {
+    for (int l = lr - 1; l >= 0; --l) {
 #if defined(LOCAMD_WINDOW_TIMING) && LOCAMD_WINDOW_TIMING >= 2
         long long locamd_ts = clock64();
 #endif
@@ -2195,17 +2363,6 @@ __device__ __forceinline__ SmallPlan make_small_plan(const Lds& L, int lane, int
         }
     }
     return p;
-}
-
-// 1/sqrt(d) for a pivot d > 0: hardware seed (~2^-24) + one third-order step y (1 + e/2 + 3 e^2/8), e = 1 - d y^2: the error
-// term e^3 is far below an ulp; four dependent operations after the seed (the Goldschmidt pair + Newton used elsewhere: eight)
-__device__ __forceinline__ double pivot_rsqrt(double d) {
-    const double y = __builtin_amdgcn_rsq(d);
-    const double t = d * y;
-    const double e = __builtin_fma(-t, y, 1.0);
-    const double pq = __builtin_fma(0.375, e, 0.5);
-    const double ye = y * e;
-    return __builtin_fma(ye, pq, y);
 }
 
 // The schedule of factor_and_solve_small, decoded once per launch: which block, which rows of the factor, where the result goes.
@@ -2461,14 +2618,14 @@ __global__ void __launch_bounds__(64 * NW, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 
     const size_t nnz_max = window_nnz_capacity(c);
     Lds L;
     L.base = lds; L.recA = nullptr; L.recB = nullptr; L.rec_count = nullptr; L.recA_cap = 0;
-    L.dense = nullptr; L.dense_off = nullptr; L.dense_cap = 0; L.dense_ok = 0;
+    L.dense = nullptr; L.dense_off = nullptr; L.dense_cap = 0; L.dense_ok = 0; L.root = nullptr; L.root_level = 0;
     // small windows (arrays in LDS, one-word masks): the latency-scheduled factorisation (factor_and_solve_small)
     constexpr bool SMALL = SP && !GLOBAL_A && W == 1 && LOCAMD_SMALL_FACTOR;
     SmallPlan plan;
     plan.level = -1; plan.dJ = 0; plan.colmask = 0; plan.off0 = 0; plan.tables = false;
     __shared__ double s_blk[36];
     __shared__ double s_red[NW > 1 ? NW * 37 : 1];
-    __shared__ int s_meta[2];
+    __shared__ int s_meta[4];
     L.red = s_red;
 #ifdef LOCAMD_WINDOW_TIMING
     __shared__ long long s_tim[8];
@@ -2527,6 +2684,8 @@ __global__ void __launch_bounds__(64 * NW, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 
         L.r_idx = reinterpret_cast<int32_t*>(q); q += ints_as_doubles(2 * (size_t)c.nr_max);
         L.p_idx = reinterpret_cast<int32_t*>(q); q += ints_as_doubles((size_t)c.np_max);
         L.s_idx = reinterpret_cast<int32_t*>(q);
+        L.root = GLOBAL_A && W > 1 && window_root_lds_doubles(c) != 0
+                     ? lds + (window_table_bytes(c) + 7) / 8 + (window_index_in_lds(c) ? window_index_doubles(c) : 0) : nullptr;
         if (!GLOBAL_A) p += (window_table_bytes(c) + 7) / 8;
     }
     L.nlev = 0;
@@ -2588,9 +2747,9 @@ __global__ void __launch_bounds__(64 * NW, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 
     if (!SOLO) compute_incidence<SP, SOLO>(L, lane, nv, nr, np, ns);
     }
     if (SOLO) {   // the other waves join: the structure is in LDS / the workspace, the level count in wave 0's registers
-        if (lane == 0) { s_meta[0] = L.nlev; s_meta[1] = L.dense_ok; }
+        if (lane == 0) { s_meta[0] = L.nlev; s_meta[1] = L.dense_ok; s_meta[2] = L.root_level; }
         __syncthreads();
-        L.nlev = s_meta[0]; L.dense_ok = s_meta[1];
+        L.nlev = s_meta[0]; L.dense_ok = s_meta[1]; L.root_level = s_meta[2];
         L.colmode = 0; L.pushmask = 0;
         compute_incidence_wide<SP, NW>(L, lane, nv, nr, np, ns);
     }
@@ -2703,7 +2862,7 @@ __global__ void __launch_bounds__(64 * NW, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 
     if (lane == 0) {
         double* res = a.result + (size_t)inst * 8;
         res[0] = last_plain; res[1] = cur_chi; res[2] = lambda; res[3] = (double)it; res[4] = (double)trials;
-        res[5] = (double)terminated; res[6] = (double)L.shared[0]; res[7] = SP ? (double)(L.nlev * 65536 + L.boff[nv] / 36) : 0.0;
+        res[5] = (double)terminated; res[6] = (double)L.shared[0]; res[7] = SP ? (double)(L.nlev * 65536 + L.boff[nv] / 36) + ((W > 1 && GLOBAL_A && L.root_level < L.nlev) ? (nv - L.lvl_col[L.root_level]) / 16.0 : 0.0) : 0.0;   // (+ poses in the root supernode / 16)
 #ifdef LOCAMD_WINDOW_TIMING
         L.tim[7] = clock64() - t_start;
         for (int i = 0; i < 8; ++i) res[i] = (double)L.tim[i];
@@ -2715,7 +2874,7 @@ __global__ void __launch_bounds__(64 * NW, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 
 
 size_t window_lds_bytes(const WindowCaps& c, bool global_a) {
     // (+ the static 6x6 exchange block)
-    if (global_a) return (window_table_bytes(c) + 7) / 8 * 8 + (window_index_in_lds(c) ? window_index_doubles(c) * 8 : 0);
+    if (global_a) return (window_table_bytes(c) + 7) / 8 * 8 + (window_index_in_lds(c) ? window_index_doubles(c) * 8 : 0) + window_root_lds_doubles(c) * 8;
     const size_t staged = (size_t)c.nr_max * 5 + (size_t)c.np_max * 18 + (size_t)c.ns_max * 48;
     return (window_instance_doubles(c) + (window_table_bytes(c) + 7) / 8 + staged + small_table_doubles(c)) * sizeof(double);
 }

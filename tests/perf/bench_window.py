@@ -250,7 +250,8 @@ def main():
         "gpu_single_window_latency_ms_incl_pcie": float(np.median(lat)), "gpu_single_window_kernel_ms": s1.last_kernel_ms(),
         "cpu_oracle_windows_per_s_1core": len(cpu_t) / cpu_s, "cpu_ms_per_window": cpu_s / len(cpu_t) * 1e3,
         "mean_lm_trials": float(wb.result[:, 4].mean()), "jacobian": a.jacobian, "natural_order": bool(a.natural),
-        "elimination_levels": float(wb.result[0, 7] // 65536), "factor_blocks": float(wb.result[0, 7] % 65536),
+        "elimination_levels": float(wb.result[0, 7] // 65536), "factor_blocks": float(int(wb.result[0, 7]) % 65536),
+        "root_supernode_poses": float(round((wb.result[0, 7] % 1.0) * 16)),
         "max_abs_diff_vs_oracle_numeric_m": diff}))
 
 
