@@ -394,7 +394,8 @@ def test_several_edges_on_one_pair_of_poses(gpu):
     assert np.isfinite(wb.poses).all() and d.max() < 1e-7 and np.median(d) < 1e-9, (d.max(), np.median(d))
 
 
-def test_wide_windows_ragged_batch(gpu):
+@pytest.mark.parametrize("jac", ["analytic", "numeric"])
+def test_wide_windows_ragged_batch(gpu, jac):
     """Windows of 65 .. 512 poses run on eight waves each (set-up on wave 0, LM loop on all 512 threads, block-wide
     reductions): a batch sized for 96 poses whose instances use 0, 1, 1, 5, 70 and 96 of them — no pose at all, a pose
     without edges, the snapshot shape, small and full windows with IMU priors, key-frame pose factors and a lever arm — and
@@ -422,8 +423,9 @@ def test_wide_windows_ragged_batch(gpu):
         for (k, t, R, dg) in priors: wb.add_prior(i, k, t, R, dg)
         for (ki, kj, t, R, info) in se3: wb.add_se3(i, ki, kj, t, R, info, True)
     before = wb.poses.copy()
-    want = [oracle_solve_instance(wb, i, ANCH) for i in range(B)]
-    solver = la.WindowSolver(ANCH, B, T, 2 * T, T, T)
+    from oracle import oracle as O
+    want = [oracle_solve_instance(wb, i, ANCH, jac_mode=O.JAC_ANALYTIC if jac == "analytic" else O.JAC_NUMERIC_G2O) for i in range(B)]
+    solver = la.WindowSolver(ANCH, B, T, 2 * T, T, T, jacobian=jac)
     res = solver.solve(wb)
     solver.close()
     assert np.array_equal(wb.poses[0], before[0]) and np.array_equal(wb.poses[1], before[1]) and res[0, 4] == 0 and res[1, 4] == 0
@@ -431,5 +433,6 @@ def test_wide_windows_ragged_batch(gpu):
     for i in (2, 3, 4, 5):
         poses, chi, st = want[i]
         d = np.abs(wb.poses[i, :sizes[i]] - poses).max()
-        assert d < 1e-7, (i, d)
-        assert abs(res[i, 0] - chi) <= 1e-6 * max(1.0, abs(chi)), (i, res[i, 0], chi)
+        # (numeric vs numeric: the central differences amplify the last bits of the summation order, as in the other numeric tests)
+        assert d < (1e-7 if jac == "analytic" else 1e-5), (i, d)
+        assert abs(res[i, 0] - chi) <= (1e-6 if jac == "analytic" else 1e-4) * max(1.0, abs(chi)), (i, res[i, 0], chi)
