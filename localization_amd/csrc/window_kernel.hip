@@ -1207,7 +1207,14 @@ __device__ __forceinline__ int compute_sparse_mw(Lds& L, int lane, int nv, int n
             int k = 0;
             for (int w = 0; w < W; ++w) {
                 u64 m = L.colmask[J * W + w];
-                while (m) { const int i = (w << 6) + __ffsll((long long)m) - 1; m &= m - 1; L.otask[start + k++] = (i << 16) | J; }
+                // (bits 25 .. 31: the number of earlier columns rows i and J share, capped at 127 — the row task of the block then
+                //  knows without walking the eight mask words twice whether it has a product sum at all, and whether it is dense)
+                while (m) {
+                    const int i = (w << 6) + __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const int nc = min(common_count<W>(L, i, J), 127);
+                    L.otask[start + k++] = (int)(((unsigned)nc << 25) | (unsigned)(i << 16) | (unsigned)J);
+                }
             }
         }
     }
@@ -1241,10 +1248,10 @@ __device__ __forceinline__ int compute_sparse_mw(Lds& L, int lane, int nv, int n
             for (int t0 = L.lvl_blk[l]; t0 < t1; t0 += 64) {
                 const int t = t0 + lane;
                 const int code = t < t1 ? L.otask[t] : 0;
-                const bool d = t < t1 && block_is_presummed<W>(L, code >> 16, code & 65535);
+                const bool d = t < t1 && block_is_presummed<W>(L, (code >> 16) & 511, code & 65535);
                 const u64 bd = __ballot(d);
                 const int pd = dcount + __popcll(bd & below);
-                if (d && pd < L.dense_cap) L.dense[pd] = code;
+                if (d && pd < L.dense_cap) L.dense[pd] = code & 0x01FFFFFF;   // (without the count bits: bit 31 marks right-hand sides)
                 dcount += __popcll(bd);
             }
         }
@@ -2058,7 +2065,7 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
                 const int e = e0 + (lane >> 6);
                 if (e < d1) {
                     const int code = L.dense[e];
-                    const int J = code & 65535, i = (code >> 16) & 32767;
+                    const int J = code & 65535, i = (code >> 16) & 511;
                     if (code < 0) presum_rhs<W>(L, lane & 63, J, J);
                     else presum_block<W>(L, lane & 63, i, J, J);
                 }
@@ -2097,14 +2104,16 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
                         continue;
                     }
                     const double* blk = L.Ls + rowJ + 36 * kb;
-                    double li[6];
+                    double li[6], bj[36];   // (all loads first; the row's own entries by address: r is not a compile-time index)
 #pragma unroll
                     for (int k = 0; k < 6; ++k) li[k] = blk[6 * k + r];
+#pragma unroll
+                    for (int q = 0; q < 36; ++q) bj[q] = W > 1 ? blk[q] : 0.0;   // (one-word windows: the products read in place, as measured best there)
 #pragma unroll
                     for (int c = 0; c < 6; ++c) {
                         double acc = 0.0;
 #pragma unroll
-                        for (int k = 0; k < 6; ++k) acc = __builtin_fma(li[k], blk[6 * k + c], acc);
+                        for (int k = 0; k < 6; ++k) acc = __builtin_fma(li[k], W > 1 ? bj[6 * k + c] : blk[6 * k + c], acc);
                         S[c] -= acc;
                     }
                 }
@@ -2126,12 +2135,13 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
         for (int base = 0; base < ntask; base += NT) {
             const int idx = base + lane;
             if (idx < ntask) {
-                int kind, i, J, r;  // 0: row r of the diagonal block of J; 1: row r of block (i, J); 2: right-hand side of column J
+                int kind, i, J, r, nc = -1;  // 0: row r of the diagonal block of J; 1: row r of block (i, J); 2: right-hand side of column J
                 if (idx < 6 * ncol) { kind = 0; J = L.colorder[c0 + idx / 6]; i = J; r = idx % 6; }
                 else if (idx < 6 * (ncol + nblk)) {
                     const int t = idx - 6 * ncol;
                     const int code = L.otask[b0 + t / 6];
-                    kind = 1; i = code >> 16; J = code & 65535; r = t % 6;
+                    kind = 1; i = (code >> 16) & 511; J = code & 65535; r = t % 6;
+                    nc = W > 1 ? (int)((unsigned)code >> 25) : -1;   // (8-word windows: the common earlier columns were counted once)
                 } else { kind = 2; J = L.colorder[c0 + idx - 6 * (ncol + nblk)]; i = J; r = 0; }
                 const int rowJ = L.boff[J], dJ = L.boff[J + 1] - 36;
                 // the row's own segment first (its loads overlap the factorisation below)
@@ -2144,26 +2154,30 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
                     bi = rowi + 36 * row_rank<W>(L, i, J);
 #pragma unroll
                     for (int c = 0; c < 6; ++c) S[c] = L.Hs[bi + 6 * c + r];
-                    const bool pre = block_is_presummed<W>(L, i, J);
+                    const bool pre = nc >= 0 ? (L.dense_ok && nc >= DENSE_K) : block_is_presummed<W>(L, i, J);
                     if (pre) {
 #pragma unroll
                         for (int c = 0; c < 6; ++c) S[c] -= L.Ls[bi + 6 * c + r];
                     }
-                    for (int w = 0; w < W && !pre; ++w) {
+                    int left = nc >= 0 && nc < 127 ? nc : 1 << 30;   // products still to find (8-word windows stop looking then)
+                    for (int w = 0; w < W && !pre && left > 0; ++w) {
                     u64 m = rm_word<W>(L, i, w) & rm_word<W>(L, J, w) & below_word<W>(J, w);
                     while (m) {
                         const int K = (w << 6) + __ffsll((long long)m) - 1;
                         m &= m - 1;
+                        --left;
                         const double* bki = L.Ls + rowi + 36 * row_rank<W>(L, i, K);
                         const double* bkj = L.Ls + rowJ + 36 * row_rank<W>(L, J, K);
-                        double li[6];
+                        double li[6], bj[36];   // (all loads first: from the workspace every wait is a memory round trip)
 #pragma unroll
                         for (int k = 0; k < 6; ++k) li[k] = bki[6 * k + r];
+#pragma unroll
+                        for (int q = 0; q < 36; ++q) bj[q] = W > 1 ? bkj[q] : 0.0;
 #pragma unroll
                         for (int c = 0; c < 6; ++c) {
                             double acc = 0.0;
 #pragma unroll
-                            for (int k = 0; k < 6; ++k) acc = __builtin_fma(li[k], bkj[6 * k + c], acc);
+                            for (int k = 0; k < 6; ++k) acc = __builtin_fma(li[k], W > 1 ? bj[6 * k + c] : bkj[6 * k + c], acc);
                             S[c] -= acc;
                         }
                     }
@@ -2194,14 +2208,16 @@ __device__ __forceinline__ bool factor_and_solve_sparse(const Lds& L, int lane, 
                             }
                             continue;
                         }
-                        double li[6];
+                        double li[6], bj[36];
 #pragma unroll
                         for (int k = 0; k < 6; ++k) li[k] = L.yrow[6 * K + k];
+#pragma unroll
+                        for (int q = 0; q < 36; ++q) bj[q] = W > 1 ? bkj[q] : 0.0;
 #pragma unroll
                         for (int c = 0; c < 6; ++c) {
                             double acc = 0.0;
 #pragma unroll
-                            for (int k = 0; k < 6; ++k) acc = __builtin_fma(li[k], bkj[6 * k + c], acc);
+                            for (int k = 0; k < 6; ++k) acc = __builtin_fma(li[k], W > 1 ? bj[6 * k + c] : bkj[6 * k + c], acc);
                             S[c] -= acc;
                         }
                     }
