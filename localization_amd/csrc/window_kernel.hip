@@ -1735,33 +1735,105 @@ __device__ __forceinline__ bool root_factor_and_solve(const Lds& L, int tid, int
     const int npair = m * (m + 1) / 2, nent = npair + m;
     auto pair_of = [&](int e, int& a, int& b) { a = 0; while ((a + 1) * (a + 2) / 2 <= e) ++a; b = e - a * (a + 1) / 2; };
     const int lane = tid;   // (the timing macros)
-    (void)lane;
+    (void)lane; (void)nent; (void)pair_of;
     LOCAMD_TIC();
-    for (int e0 = 0; e0 < nent; e0 += NW) {
-        const int e = e0 + (tid >> 6);
-        if (e < nent) {
-            if (e < npair) { int a, b; pair_of(e, a, b); presum_block<W>(L, tid & 63, jr + a, jr + b, jr); }
-            else presum_rhs<W>(L, tid & 63, jr + (e - npair), jr);
-        }
-    }
-    __syncthreads();
-    LOCAMD_TOC4(0);
+    // S = H_root + lambda I (lower triangle), right-hand side row = b_root
     for (int q = tid; q < npair * 36 + n; q += NT) {
         if (q < npair * 36) {
             int a, b;
             pair_of(q / 36, a, b);
             const int k = q % 36, r = k % 6, c = k / 6;
             if (a == b && r < c) continue;
-            const int off = blk_off<true>(L, jr + a, jr + b) + k;
-            double v = L.Hs[off] - L.Ls[off];
+            double v = L.Hs[blk_off<true>(L, jr + a, jr + b) + k];
             if (a == b && r == c) v += lambda;
             S[(6 * a + r) * n + 6 * b + c] = v;
         } else {
             const int k = q - npair * 36;
-            S[n * n + k] = L.b[6 * jr + k] - L.yrow[6 * jr + k];
+            S[n * n + k] = L.b[6 * jr + k];
         }
     }
-    __syncthreads();
+    // U = sum over the columns K before the root of M_K M_K^T, M_K = the (n + 1) x 6 slab [L_aK (a in the root); y_K^T]: a
+    // (n + 1) x (6 jr) x (n + 1) GEMM — on the f64 matrix cores.  v_mfma_f64_16x16x4_f64 (layout found with
+    // tools/mfma_f64_probe.hip): lane l supplies A[l % 16][l / 16] and B[l / 16][l % 16], and holds D[(l / 16) + 4 v][l % 16],
+    // v = 0 .. 3.  The rows are cut into four tiles of 16; a tile's A fragment IS its B fragment (U is M M^T), so a (K, slice
+    // of four k) costs four gathers and ten MFMAs for the lower triangle of tiles.  The waves split the columns K and subtract
+    // their partial U from S one after the other (wave order: bit-reproducible).
+    {
+        typedef double v4f64 __attribute__((ext_vector_type(4)));
+        const int wv = tid >> 6, l = tid & 63, li = l & 15, lk = l >> 4;
+        int frow[4], foff[4];   // per tile: the root pose's row of blocks (or -1: right-hand side / -2: padding), the row inside the block
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) {
+            const int R = 16 * ti + li;
+            frow[ti] = R < n ? jr + R / 6 : (R == n ? -1 : -2);
+            foff[ti] = R < n ? R % 6 : 0;
+        }
+        v4f64 acc[10];
+#pragma unroll
+        for (int t = 0; t < 10; ++t) acc[t] = v4f64{0.0, 0.0, 0.0, 0.0};
+        constexpr int KU = 4;   // columns per step: their 32 gathers are in flight together (a step is one memory round trip)
+        for (int K0 = KU * wv; K0 < jr; K0 += KU * NW) {
+            int boffs[KU][4];   // offset of block (root pose, K) + row; -2: the right-hand side's y_K; -1: nothing
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                const int K = K0 + u;
+#pragma unroll
+                for (int ti = 0; ti < 4; ++ti) {
+                    const int a = frow[ti];
+                    boffs[u][ti] = -1;
+                    if (K < jr) {
+                        if (a >= 0) {
+                            if ((L.rowmask[a * W + (K >> 6)] >> (K & 63)) & 1ull) boffs[u][ti] = L.boff[a] + 36 * row_rank<W>(L, a, K) + foff[ti];
+                        } else if (a == -1) boffs[u][ti] = -2;
+                    }
+                }
+            }
+            double f[KU][2][4];
+#pragma unroll
+            for (int u = 0; u < KU; ++u)
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    const int k = 4 * sl + lk;
+#pragma unroll
+                    for (int ti = 0; ti < 4; ++ti) {
+                        f[u][sl][ti] = 0.0;
+                        if (k < 6) {
+                            if (boffs[u][ti] >= 0) f[u][sl][ti] = L.Ls[boffs[u][ti] + 6 * k];
+                            else if (boffs[u][ti] == -2) f[u][sl][ti] = L.yrow[6 * (K0 + u) + k];
+                        }
+                    }
+                }
+#pragma unroll
+            for (int u = 0; u < KU; ++u)
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    int t = 0;
+#pragma unroll
+                    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+                        for (int tj = 0; tj <= ti; ++tj) { acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[u][sl][ti], f[u][sl][tj], acc[t], 0, 0, 0); ++t; }
+                }
+        }
+        __syncthreads();   // (S is assembled)
+        for (int turn = 0; turn < NW; ++turn) {
+            if (wv == turn) {
+                int t = 0;
+#pragma unroll
+                for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj <= ti; ++tj) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const int R = 16 * ti + lk + 4 * v, C = 16 * tj + li;
+                            if (C <= R && R <= n && C < n) S[R * n + C] -= acc[t][v];
+                        }
+                        ++t;
+                    }
+            }
+            __syncthreads();
+        }
+    }
+    LOCAMD_TOC4(0);
     bool ok = true;
     // blocked right-looking Cholesky, 6 columns per step, two barriers per step: every thread factors the step's diagonal
     // block itself (registers), the rows below it (and the right-hand side, row n) are solved one per thread, the trailing
