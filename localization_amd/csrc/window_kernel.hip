@@ -13,20 +13,25 @@
 //             then optimizer.chi2()                                                 [localization.cpp:197]
 // (g2o semantics: SURVEY.md Appendix A.)
 //
-// MI355X mapping: ONE WAVE PER INSTANCE.
+// MI355X mapping: one wave per instance up to 64 poses, eight waves (one CU) per instance of 65 .. 512 poses.
 //   * edge evaluation: lane e evaluates edge e (error, Jacobian blocks, robust weight) into a record; range Jacobians are
 //     analytic, or g2o's central differences (delta = 1e-9, what the reference inherits) when WindowArgs::jacobian says so;
 //   * normal equations: a gather over per-pose incidence lists (fixed order => bit-reproducible, no atomics);
-//   * windows of up to 64 poses (SPARSE path): the wave first orders the poses by multiple-minimum-degree on 64-bit
-//     adjacency masks (lane = pose; what CHOLMOD's AMD ordering does for the reference, localization.h:82-84), derives the
-//     exact block structure of the Cholesky factor and its elimination-tree levels, and then factors LEVEL BY LEVEL: all
-//     block columns of a level are independent, their rows are spread over the 64 lanes (6x6 blocks, the right-hand side
-//     rides along as one more row), two barriers per level.  BASELINE config 5's key-frame tree is 6 levels instead of
-//     64 sequential block columns and has no fill; a chain is eaten from both ends;
-//   * larger windows (SKYLINE path): H and its factor in envelope form in the caller's pose order, one block column
-//     after the other;
+//   * windows of up to 512 poses (SPARSE path): the poses are first ordered by multiple-minimum-degree / nested dissection
+//     on adjacency bit masks (lane = pose; what CHOLMOD's AMD ordering does for the reference, localization.h:82-84), the
+//     exact block structure of the Cholesky factor and its elimination-tree levels are derived, and the factorisation
+//     runs LEVEL BY LEVEL: all block columns of a level are independent (6x6 blocks, the right-hand side rides along as
+//     one more row).  BASELINE config 5's key-frame tree is 6 levels instead of 64 sequential block columns and has no
+//     fill; a 500-pose chain is 10 levels; BASELINE config 4's arrowhead is 8 levels + a dense root supernode.
+//       - <= 64 poses, arrays in LDS: factor_and_solve_small (one lane per entry / per row, pre-decoded schedule);
+//       - <= 64 poses, arrays in the HBM workspace: factor_and_solve_sparse, one-word masks (column / row modes, pushed updates);
+//       - 65 .. 512 poses: eight-word masks in LDS, eight waves, dense blocks summed cooperatively, the trailing clique
+//         as one dense system in LDS whose sums run on the f64 matrix cores (root_factor_and_solve);
+//   * larger windows (SKYLINE path, 513 .. 1024 poses): H and its factor in envelope form in the caller's pose order, one
+//     block column after the other;
 //   * small windows keep everything in LDS, larger ones in a per-instance slice of an HBM workspace (index tables in LDS);
-//   * all LM control flow is wave-uniform (sums are DPP reductions: every lane holds the same bits).
+//   * all LM control flow is uniform over the instance's threads (sums are DPP reductions, combined across the waves in wave
+//     order: every thread holds the same bits).
 #include "window_kernel.h"
 #include "device_math.h"
 #include "numeric_jacobian.h"
