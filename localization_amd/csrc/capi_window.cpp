@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include <new>
@@ -31,6 +32,9 @@ struct loc_window {
     double *d_poses = nullptr, *d_rval = nullptr, *d_pval = nullptr, *d_sval = nullptr, *d_result = nullptr;
     double* d_workspace = nullptr;  // HBM copy of the (H, L) matrices when they do not fit LDS
     double* d_poses_in = nullptr;   // resident mode: the uploaded initial estimates (every resident solve starts from them)
+    double* d_chain_ws = nullptr;   // chain windows (one lane per window, window_kernel.hip: chain_lm_kernel): its workspace
+    bool resident_chain = false;    // the uploaded batch qualifies for it
+    long long chain_min = -1;       // smallest batch that takes it (-1: the default / LOCAMD_CHAIN_MIN_BATCH)
     long long n_resident = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -63,7 +67,8 @@ size_t loc_window_lds_bytes(const loc_window_caps* caps) {
 int loc_window_destroy(loc_window* w) {
     if (!w) return LOC_OK;
     (void)hipSetDevice(w->device);
-    void* ptrs[] = {w->d_anchors, w->d_counts, w->d_ridx, w->d_pidx, w->d_sidx, w->d_poses, w->d_rval, w->d_pval, w->d_sval, w->d_result, w->d_workspace, w->d_poses_in};
+    void* ptrs[] = {w->d_anchors, w->d_counts, w->d_ridx, w->d_pidx, w->d_sidx, w->d_poses, w->d_rval, w->d_pval, w->d_sval, w->d_result, w->d_workspace, w->d_poses_in,
+                    w->d_chain_ws};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : w->ev) (void)hipEventDestroy(e);
     if (w->h_stage) (void)hipHostFree(w->h_stage);
@@ -169,6 +174,53 @@ static int validate_instances(const loc_window* w, int64_t n, const int32_t* cou
     return LOC_OK;
 }
 
+// Large batches of CHAIN windows (every moving-moving edge joins consecutive poses, no SE3 edges; ranges ordered by their
+// later pose and priors by pose — the order Localization::addRangeEdge / addImuEdge create them in) run one lane per window
+// (chain_lm_kernel).  Below the threshold a wave per window is faster (the lane-per-window kernel takes about as long for 1 000
+// windows as for 65 536); LOCAMD_CHAIN_MIN_BATCH in the environment moves it (0 = never).
+static long long chain_min_batch() {
+    static const long long v = [] { const char* e = getenv("LOCAMD_CHAIN_MIN_BATCH"); return e ? atoll(e) : 24576LL; }();
+    return v;
+}
+static bool chain_eligible(const loc_window* w, int64_t n, const int32_t* counts, const int32_t* r_idx, const int32_t* p_idx) {
+    const long long mn = w->chain_min >= 0 ? w->chain_min : chain_min_batch();
+    if (mn <= 0 || n < mn || w->natural_order) return false;
+    const locamd::WindowCaps& c = w->caps;
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t* cn = counts + i * 4;
+        if (cn[3] != 0) return false;
+        int last = 0;
+        for (int e = 0; e < cn[1]; ++e) {
+            const int32_t* ix = r_idx + ((size_t)i * c.nr_max + e) * 2;
+            const int key = ix[1] > ix[0] ? ix[1] : ix[0];
+            if (key < last) return false;
+            last = key;
+            if (ix[1] >= 0 && ix[0] - ix[1] != 1 && ix[1] - ix[0] != 1) return false;
+        }
+        last = 0;
+        for (int e = 0; e < cn[2]; ++e) {
+            const int32_t v = p_idx[(size_t)i * c.np_max + e];
+            if (v < last) return false;
+            last = v;
+        }
+    }
+    return true;
+}
+static hipError_t launch_any(loc_window* w, const locamd::WindowArgs& a, hipStream_t st, bool chain) {
+    if (!chain) return locamd::launch_window(a, st);
+    if (!w->d_chain_ws) {
+        hipError_t e = hipMalloc((void**)&w->d_chain_ws, locamd::window_chain_workspace_doubles(w->caps, w->B) * sizeof(double));
+        if (e != hipSuccess) return e;
+    }
+    return locamd::launch_window_chain(a, w->d_chain_ws, st);
+}
+
+int loc_window_set_chain_threshold(loc_window* w, int64_t min_batch) {
+    if (!w) return locamd_fail(LOC_ERR_INVALID, "null");
+    w->chain_min = min_batch;
+    return LOC_OK;
+}
+
 int loc_window_set_jacobian(loc_window* w, int32_t jacobian) {
     if (!w || (jacobian != LOC_JAC_ANALYTIC && jacobian != LOC_JAC_NUMERIC_G2O)) return locamd_fail(LOC_ERR_INVALID, "jacobian mode");
     w->jacobian = jacobian;
@@ -219,7 +271,7 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
             a.anchors = w->d_anchors; a.workspace = w->d_workspace;
             a.n_anchors = w->n_anchors; a.B = (int)n; a.iterations = w->iterations; a.caps = c;
             LOC_HIP(hipEventRecord(w->ev0, st));
-            hipError_t e = locamd::launch_window(a, st);
+            hipError_t e = launch_any(w, a, st, chain_eligible(w, n, counts, r_idx, p_idx));
             if (e != hipSuccess) return locamd_fail_hip(e, "launch_window");
             LOC_HIP(hipEventRecord(w->ev1, st));
             LOC_HIP(hipMemcpyAsync(h, d, off[2], hipMemcpyDeviceToHost, st));  // [poses | result]
@@ -251,8 +303,9 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
     a.p_val = w->d_pval; a.s_idx = w->d_sidx; a.s_val = w->d_sval; a.anchors = w->d_anchors; a.result = w->d_result;
     a.workspace = w->d_workspace;
     a.n_anchors = w->n_anchors; a.B = (int)n; a.iterations = w->iterations; a.caps = c;
+    const bool chain = chain_eligible(w, n, counts, r_idx, p_idx);
     LOC_HIP(hipEventRecord(w->ev0, st));
-    hipError_t e = locamd::launch_window(a, st);
+    hipError_t e = launch_any(w, a, st, chain);
     if (e != hipSuccess) return locamd_fail_hip(e, "launch_window");
     LOC_HIP(hipEventRecord(w->ev1, st));
     LOC_HIP(hipMemcpyAsync(poses, w->d_poses, N * c.nv_max * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -291,6 +344,7 @@ int loc_window_upload(loc_window* w, int64_t n, const int32_t* counts, const dou
         LOC_HIP(hipMemcpy(w->d_sval, s_val, N * c.ns_max * 48 * sizeof(double), hipMemcpyHostToDevice));
     }
     w->n_resident = n;
+    w->resident_chain = chain_eligible(w, n, counts, r_idx, p_idx);
     return LOC_OK;
 }
 
@@ -306,7 +360,7 @@ int loc_window_solve_resident(loc_window* w, void* hip_stream) {
     a.natural_order = w->natural_order; a.caps = w->caps;
     const bool timed = w->timing && (size_t)(w->ev_used + 2) <= w->ev.size();
     if (timed) LOC_HIP(hipEventRecord(w->ev[w->ev_used], st));
-    hipError_t e = locamd::launch_window(a, st);
+    hipError_t e = launch_any(w, a, st, w->resident_chain && !w->natural_order);
     if (e != hipSuccess) return locamd_fail_hip(e, "launch_window");
     if (timed) { LOC_HIP(hipEventRecord(w->ev[w->ev_used + 1], st)); w->ev_used += 2; }
     return LOC_OK;

@@ -47,5 +47,8 @@ struct WindowArgs {
 size_t window_lds_bytes(const WindowCaps& c, bool global_a);
 size_t window_workspace_doubles(const WindowCaps& c);
 hipError_t launch_window(const WindowArgs& a, hipStream_t stream);
+// chain windows, one lane per window (window_kernel.hip: chain_lm_kernel): workspace size in doubles, launch
+size_t window_chain_workspace_doubles(const WindowCaps& c, long long B);
+hipError_t launch_window_chain(const WindowArgs& a, double* chain_ws, hipStream_t stream);
 
 }  // namespace locamd

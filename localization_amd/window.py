@@ -71,7 +71,7 @@ class WindowBatch:
 
 class WindowSolver:
     def __init__(self, anchors, batch, nv_max, nr_max, np_max=0, ns_max=0, maximum_iteration=10, device=0, bw_max=-1,
-                 jacobian="analytic", natural_order=False):
+                 jacobian="analytic", natural_order=False, chain_threshold=None):
         L = lib()
         if L.loc_device_count() <= 0:
             raise _lib.LocalizationAmdError(_lib.LOC_ERR_NO_DEVICE, "no HIP device visible: localization_amd has no CPU fallback")
@@ -85,6 +85,8 @@ class WindowSolver:
         self.lds_bytes = L.loc_window_lds_bytes(C.byref(caps))
         check(L.loc_window_set_jacobian(h, _lib.JAC_NUMERIC_G2O if jacobian in ("numeric", _lib.JAC_NUMERIC_G2O) else _lib.JAC_ANALYTIC))
         check(L.loc_window_set_ordering(h, int(bool(natural_order))))
+        if chain_threshold is not None:   # smallest batch that takes the one-lane-per-window kernel for chain windows
+            check(L.loc_window_set_chain_threshold(h, int(chain_threshold)))
 
     def close(self):
         if getattr(self, "h", None):

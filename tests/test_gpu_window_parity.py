@@ -436,3 +436,74 @@ def test_wide_windows_ragged_batch(gpu, jac):
         # (numeric vs numeric: the central differences amplify the last bits of the summation order, as in the other numeric tests)
         assert d < (1e-7 if jac == "analytic" else 1e-5), (i, d)
         assert abs(res[i, 0] - chi) <= (1e-6 if jac == "analytic" else 1e-4) * max(1.0, abs(chi)), (i, res[i, 0], chi)
+
+
+@pytest.mark.parametrize("T,with_imu,lever,jac", [
+    (10, False, False, "analytic"),   # cfg/uwb_only.yaml's window
+    (12, True, True, "analytic"),     # cfg/uwb_imu.yaml's window: IMU priors, lever arm
+    (10, False, False, "numeric"),    # the reference's Jacobian mode
+    (1, True, True, "analytic"),      # a lone pose
+    (16, True, True, "numeric"),
+])
+def test_chain_kernel_matches_oracle(gpu, T, with_imu, lever, jac):
+    """Large batches of chain windows run one lane per window (chain_lm_kernel: block-tridiagonal Cholesky in pose order,
+    the state in an [entry][lane] HBM workspace).  Forced here for a small batch through loc_window_set_chain_threshold:
+    against the oracle, against the wave-per-window kernel on the same batch, and through the resident API."""
+    import localization_amd as la
+    from oracle import oracle as O
+    from _oracle_window import oracle_solve_instance
+    B = 70   # (one full wave of windows + a partial one)
+    rng = np.random.default_rng(100 * T + len(jac))
+    nr_max, np_max = max(2 * T, 4), (T if with_imu else 0)
+    wb = la.WindowBatch(B, T, nr_max, np_max, 0)
+    for i in range(B):
+        Ti = T if i % 7 else max(T // 2, 1)   # ragged lengths inside the wave
+        est_t, est_R, off, ranges, smooth, priors, _ = _random_window(rng, Ti, with_imu, False, lever)
+        for k in range(Ti):
+            wb.add_pose(i, est_t[k], est_R[k])
+        # (the reference's creation order: a pose's anchor range, then its smoothness edge to the previous pose)
+        for k in range(Ti):
+            for (kk, a, d, info) in ranges:
+                if kk == k: wb.add_range(i, k, a, d, info, off, anchor=True)
+            for (k0, k1, d, info) in smooth:
+                if k1 == k: wb.add_range(i, k0, k1, d, info)
+        for (k, t, R, dg) in priors: wb.add_prior(i, k, t, R, dg)
+    wb.counts[3, 1:] = 0   # an instance whose poses have no edge at all: comes back untouched
+    before = wb.poses.copy()
+    mode = O.JAC_ANALYTIC if jac == "analytic" else O.JAC_NUMERIC_G2O
+    want = [oracle_solve_instance(wb, i, ANCH, jac_mode=mode) for i in range(B)]
+    ref = la.WindowBatch(B, T, nr_max, np_max, 0)
+    for name in ("counts", "poses", "r_idx", "r_val", "p_idx", "p_val"):
+        getattr(ref, name)[:] = getattr(wb, name)
+    general = la.WindowSolver(ANCH, B, T, nr_max, np_max, 0, jacobian=jac, chain_threshold=0)
+    res_general = general.solve(ref).copy()
+    general.close()
+    chain = la.WindowSolver(ANCH, B, T, nr_max, np_max, 0, jacobian=jac, chain_threshold=1)
+    res = chain.solve(wb).copy()
+    assert (res[res[:, 3] > 0, 7] % 65536 == 2 * (res[res[:, 3] > 0, 7] // 65536) - 1).all()   # (the chain kernel's signature: n levels, 2 n - 1 blocks)
+    tol = 1e-7 if jac == "analytic" else 1e-5
+    for i in range(B):
+        nv = int(wb.counts[i, 0])
+        if nv == 0 or wb.counts[i, 1] + wb.counts[i, 2] == 0:
+            assert np.array_equal(wb.poses[i], before[i]) and res[i, 4] == 0
+            continue
+        poses, chi, st = want[i]
+        d = np.abs(wb.poses[i, :nv] - poses).max()
+        assert d < tol, (i, d)
+        assert abs(res[i, 0] - chi) <= (1e-6 if jac == "analytic" else 1e-4) * max(1.0, abs(chi)), (i, res[i, 0], chi)
+    assert np.abs(wb.poses - ref.poses).max() < tol
+    if T > 1:   # (a lone well-observed pose converges early: the remaining decisions are taken on rounding-level chi differences)
+        assert (res[:, 4] != res_general[:, 4]).mean() < 0.05   # LM trial counts
+    # resident API: the same answer again
+    wb2 = la.WindowBatch(B, T, nr_max, np_max, 0)
+    for name in ("counts", "r_idx", "r_val", "p_idx", "p_val"):
+        getattr(wb2, name)[:] = getattr(wb, name)
+    wb2.poses[:] = before
+    chain.upload(wb2)
+    chain.solve_resident()
+    chain.download(wb2)
+    chain.close()
+    for i in range(B):   # (pose slots beyond an instance's nv are not written by the resident path)
+        nv = int(wb.counts[i, 0])
+        assert np.array_equal(wb2.poses[i, :nv], wb.poses[i, :nv]), i
+    assert np.array_equal(wb2.result, res)
