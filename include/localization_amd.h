@@ -187,7 +187,7 @@ int loc_window_set_ordering(loc_window* w, int32_t natural);
  * Robot::new_vertex, robot.cpp:75-110), no SE3 edges, range edges listed in the order of their later pose and priors in pose
  * order (the order addRangeEdge / addImuEdge create them in: cfg/uwb_only.yaml, cfg/uwb_imu.yaml) — are solved one GPU lane per
  * window by a block-tridiagonal kernel (same LM, elimination in pose order).  min_batch: the smallest batch that takes that
- * path (default 24 576, or LOCAMD_CHAIN_MIN_BATCH from the environment; 0: never; < 0: back to the default). */
+ * path (default 12 288, or LOCAMD_CHAIN_MIN_BATCH from the environment; 0: never; < 0: back to the default). */
 int loc_window_set_chain_threshold(loc_window* w, int64_t min_batch);
 /* Device-resident operation: upload n instances once (same host layouts as loc_window_solve_host), then run
  * loc_window_solve_resident any number of times — each launch starts from the uploaded estimates, is asynchronous on

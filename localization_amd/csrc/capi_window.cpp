@@ -179,7 +179,7 @@ static int validate_instances(const loc_window* w, int64_t n, const int32_t* cou
 // (chain_lm_kernel).  Below the threshold a wave per window is faster (the lane-per-window kernel takes about as long for 1 000
 // windows as for 65 536); LOCAMD_CHAIN_MIN_BATCH in the environment moves it (0 = never).
 static long long chain_min_batch() {
-    static const long long v = [] { const char* e = getenv("LOCAMD_CHAIN_MIN_BATCH"); return e ? atoll(e) : 24576LL; }();
+    static const long long v = [] { const char* e = getenv("LOCAMD_CHAIN_MIN_BATCH"); return e ? atoll(e) : 12288LL; }();
     return v;
 }
 static bool chain_eligible(const loc_window* w, int64_t n, const int32_t* counts, const int32_t* r_idx, const int32_t* p_idx) {

@@ -3049,7 +3049,7 @@ namespace {
 
 // one sweep over the window's edges in pose order: chi sums always; FULL: H and b as well (returns the largest diagonal entry)
 template <bool FULL, int JAC>
-__device__ __forceinline__ void chain_sweep(const WindowArgs& a, double* slab, long long inst, int nv, int nr, int np,
+__device__ __forceinline__ void chain_sweep(const WindowArgs& a, double* slab, long long inst, int nv, int nr, int np, int buf,
                                             double& robust_chi, double& plain_chi, double& max_diag) {
     using namespace chainw;
 #define CH(p, f, k) slab[((size_t)(p) * N + (f) + (k)) * 64]
@@ -3067,7 +3067,7 @@ __device__ __forceinline__ void chain_sweep(const WindowArgs& a, double* slab, l
     int e = 0, q = 0;
     for (int p = 0; p < nv; ++p) {
 #pragma unroll
-        for (int k = 0; k < 12; ++k) Xc[k] = CH(p, P, k);
+        for (int k = 0; k < 12; ++k) Xc[k] = CH(p, P + 12 * buf, k);
         if (FULL) {
 #pragma unroll
             for (int k = 0; k < 27; ++k) Dc[k] = 0.0;
@@ -3238,10 +3238,35 @@ __device__ __forceinline__ void chain_sweep(const WindowArgs& a, double* slab, l
     robust_chi = rsum; plain_chi = csum; max_diag = md;
 }
 
-// (H + lambda I) x = b for a block-tridiagonal H: forward sweep (Cholesky + forward substitution), then the back-substitution;
-// x is only written when every pivot was positive and finite (g2o leaves its x alone when the factorisation fails)
-__device__ __forceinline__ bool chain_factor_solve(double* slab, int nv, double lambda) {
+// pose p of the trial state: X (+) dx, read from pose buffer `buf`, written to the other one (accepting a step flips the
+// window's buffer, rejecting it costs nothing); returns the pose's share of g2o's computeScale sum
+__device__ __forceinline__ double chain_apply_step(double* slab, int p, int buf, const double* dx, double lambda) {
     using namespace chainw;
+    double Xo[12], sc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) Xo[k] = CH(p, P + 12 * buf, k);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) sc += dx[k] * (lambda * dx[k] + CH(p, HB, k));
+    double Rd[9];
+    const double ww = 1.0 - (dx[3] * dx[3] + dx[4] * dx[4] + dx[5] * dx[5]);
+    if (ww < 0) { Rd[0] = 1; Rd[1] = 0; Rd[2] = 0; Rd[3] = 0; Rd[4] = 1; Rd[5] = 0; Rd[6] = 0; Rd[7] = 0; Rd[8] = 1; }
+    else { const double qd[4] = {sqrt(ww), dx[3], dx[4], dx[5]}; quat_to_mat(qd, Rd); }
+    double Rn[9], tn[3];
+    mat_mul(Xo, Rd, Rn);
+    mat_vec(Xo, dx, tn);
+    const int ob = P + 12 * (1 - buf);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) CH(p, ob, k) = Rn[k];
+    CH(p, ob, 9) = Xo[9] + tn[0]; CH(p, ob, 10) = Xo[10] + tn[1]; CH(p, ob, 11) = Xo[11] + tn[2];
+    return sc;
+}
+
+// (H + lambda I) x = b for a block-tridiagonal H: forward sweep (Cholesky + forward substitution), then the back-substitution
+// with the step applied pose by pose as its x comes out.  x is only written when every pivot was positive and finite (g2o
+// leaves its x alone when the factorisation fails, and LM applies that stale x all the same).
+__device__ __forceinline__ bool chain_factor_solve(double* slab, int nv, double lambda, int buf, double& scale_sum) {
+    using namespace chainw;
+    scale_sum = 0.0;
     bool ok = true;
     double Gp[6][6], igp[6], yp[6];   // the previous pose's factor (strict lower), inverse pivots, y
 #pragma unroll
@@ -3341,7 +3366,15 @@ __device__ __forceinline__ bool chain_factor_solve(double* slab, int nv, double 
 #pragma unroll
             for (int cc = 0; cc < 6; ++cc) Gp[r][cc] = cc < r ? A[r][cc] : 0.0;
     }
-    if (!ok) return false;
+    if (!ok) {
+        for (int p = 0; p < nv; ++p) {
+            double dx[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) dx[k] = CH(p, X, k);
+            scale_sum += chain_apply_step(slab, p, buf, dx, lambda);
+        }
+        return false;
+    }
     double xn[6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) xn[r] = 0.0;
@@ -3389,6 +3422,7 @@ __device__ __forceinline__ bool chain_factor_solve(double* slab, int nv, double 
         }
 #pragma unroll
         for (int r = 0; r < 6; ++r) CH(p, X, r) = xn[r];
+        scale_sum += chain_apply_step(slab, p, buf, xn, lambda);
     }
     return true;
 }
@@ -3414,42 +3448,25 @@ __global__ void __launch_bounds__(64, 1) chain_lm_kernel(const WindowArgs a, dou
     constexpr double tau = 1e-5, good_lo = 1.0 / 3.0, good_hi = 2.0 / 3.0;
     constexpr int max_trials = 10;
     double lambda = 0.0, ni = 2.0, cur_chi = 0.0, last_plain = 0.0;
-    int it = 0, q = 0, trials = 0, terminated = 0;
+    int it = 0, q = 0, trials = 0, terminated = 0, buf = 0;
     bool need_lin = true;
     bool done = !live || nv <= 0 || nr + np <= 0 || a.iterations <= 0;
     while (__ballot(!done)) {
         if (!done) {
             if (need_lin) {
                 double plain, md;
-                chain_sweep<true, JAC>(a, slab, inst, nv, nr, np, cur_chi, plain, md);
+                chain_sweep<true, JAC>(a, slab, inst, nv, nr, np, buf, cur_chi, plain, md);
                 last_plain = plain;
                 if (it == 0) { lambda = tau * md; ni = 2.0; }
                 q = 0;
                 need_lin = false;
             }
-            // push, solve, update
-            const bool ok2 = chain_factor_solve(slab, nv, lambda);
-            double sc = 0.0;
-            for (int p = 0; p < nv; ++p) {
-                double Xo[12], dx[6];
-#pragma unroll
-                for (int k = 0; k < 12; ++k) { Xo[k] = CH(p, P, k); CH(p, PB, k) = Xo[k]; }
-#pragma unroll
-                for (int k = 0; k < 6; ++k) { dx[k] = CH(p, X, k); sc += dx[k] * (lambda * dx[k] + CH(p, HB, k)); }
-                double Rd[9];
-                const double ww = 1.0 - (dx[3] * dx[3] + dx[4] * dx[4] + dx[5] * dx[5]);
-                if (ww < 0) { Rd[0] = 1; Rd[1] = 0; Rd[2] = 0; Rd[3] = 0; Rd[4] = 1; Rd[5] = 0; Rd[6] = 0; Rd[7] = 0; Rd[8] = 1; }
-                else { const double qd[4] = {sqrt(ww), dx[3], dx[4], dx[5]}; quat_to_mat(qd, Rd); }
-                double Rn[9], tn[3];
-                mat_mul(Xo, Rd, Rn);
-                mat_vec(Xo, dx, tn);
-#pragma unroll
-                for (int k = 0; k < 9; ++k) CH(p, P, k) = Rn[k];
-                CH(p, P, 9) = Xo[9] + tn[0]; CH(p, P, 10) = Xo[10] + tn[1]; CH(p, P, 11) = Xo[11] + tn[2];
-            }
+            // solve and apply the step (the trial state goes to the other pose buffer)
+            double sc;
+            const bool ok2 = chain_factor_solve(slab, nv, lambda, buf, sc);
             ++trials;
             double temp_chi, plain2, md2;
-            chain_sweep<false, JAC>(a, slab, inst, nv, nr, np, temp_chi, plain2, md2);
+            chain_sweep<false, JAC>(a, slab, inst, nv, nr, np, 1 - buf, temp_chi, plain2, md2);
             last_plain = plain2;
             if (!ok2) temp_chi = DBL_MAX;
             const double scale = sc + 1e-3;
@@ -3462,15 +3479,12 @@ __global__ void __launch_bounds__(64, 1) chain_lm_kernel(const WindowArgs a, dou
                 lambda *= fmax(good_lo, alpha);
                 ni = 2.0;
                 cur_chi = temp_chi;
+                buf = 1 - buf;   // the trial state is the state
                 ++q;
                 iteration_over = true;
             } else {
                 lambda *= ni;
-                ni *= 2.0;
-                for (int p = 0; p < nv; ++p) {
-#pragma unroll
-                    for (int k = 0; k < 12; ++k) CH(p, P, k) = CH(p, PB, k);   // pop
-                }
+                ni *= 2.0;      // (pop: the state was never overwritten)
                 ++q;
                 iteration_over = !(rho < 0.0 && q < max_trials);
             }
@@ -3485,7 +3499,7 @@ __global__ void __launch_bounds__(64, 1) chain_lm_kernel(const WindowArgs a, dou
     if (live) {
         for (int p = 0; p < nv; ++p) {
 #pragma unroll
-            for (int k = 0; k < 12; ++k) gout[p * 12 + k] = CH(p, P, k);
+            for (int k = 0; k < 12; ++k) gout[p * 12 + k] = CH(p, P + 12 * buf, k);
         }
         double* res = a.result + (size_t)inst * 8;
         res[0] = last_plain; res[1] = cur_chi; res[2] = lambda; res[3] = (double)it; res[4] = (double)trials;
