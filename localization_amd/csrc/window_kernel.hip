@@ -3041,8 +3041,13 @@ namespace chainw {
 constexpr int HD = 0, HO = 21, HB = 57, G = 63, W = 84, Y = 120, X = 126, P = 132, PB = 144, N = 156;
 }
 
+// per window: nv_max poses x N doubles, then the edges as [entry][lane] too (range: v0, v1, measurement, information, lever
+// arm = 7 doubles; prior: v + 18 values = 19)
+__host__ __device__ inline size_t chain_window_doubles(const WindowCaps& c) {
+    return (size_t)c.nv_max * chainw::N + (size_t)c.nr_max * 7 + (size_t)c.np_max * 19;
+}
 size_t window_chain_workspace_doubles(const WindowCaps& c, long long B) {
-    return (size_t)((B + 63) / 64) * 64 * (size_t)c.nv_max * chainw::N;
+    return (size_t)((B + 63) / 64) * 64 * chain_window_doubles(c);
 }
 
 namespace {
@@ -3054,10 +3059,11 @@ __device__ __forceinline__ void chain_sweep(const WindowArgs& a, double* slab, l
     using namespace chainw;
 #define CH(p, f, k) slab[((size_t)(p) * N + (f) + (k)) * 64]
     const WindowCaps& c = a.caps;
-    const int32_t* ridx = a.r_idx + (size_t)inst * c.nr_max * 2;
-    const double* rval = a.r_val + (size_t)inst * c.nr_max * 5;
-    const int32_t* pidx = a.p_idx + (size_t)inst * c.np_max;
-    const double* pval = a.p_val + (size_t)inst * c.np_max * 18;
+    (void)inst;
+    // the window's edges, copied into the workspace once per launch ([entry][lane]: one line per load of the wave)
+    const size_t eoff = (size_t)c.nv_max * N, poff = eoff + (size_t)c.nr_max * 7;
+#define CE(e, k) slab[(eoff + (size_t)(e) * 7 + (k)) * 64]
+#define CP(e, k) slab[(poff + (size_t)(e) * 19 + (k)) * 64]
     double rsum = 0.0, csum = 0.0, md = 0.0;
     double Dp[27], Dc[27], O[36], Xp[12], Xc[12];
 #pragma unroll
@@ -3065,9 +3071,20 @@ __device__ __forceinline__ void chain_sweep(const WindowArgs& a, double* slab, l
 #pragma unroll
     for (int k = 0; k < 12; ++k) { Xp[k] = 0.0; Xc[k] = 0.0; }
     int e = 0, q = 0;
+    // (the next edge and the next pose are requested one step ahead: nothing else hides a memory round trip here)
+    double ne[7], nX[12], npv = 0.0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) ne[k] = nr > 0 ? CE(0, k) : 0.0;
+    if (np > 0) npv = CP(0, 0);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) nX[k] = nv > 0 ? CH(0, P + 12 * buf, k) : 0.0;
     for (int p = 0; p < nv; ++p) {
 #pragma unroll
-        for (int k = 0; k < 12; ++k) Xc[k] = CH(p, P + 12 * buf, k);
+        for (int k = 0; k < 12; ++k) Xc[k] = nX[k];
+        if (p + 1 < nv) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) nX[k] = CH(p + 1, P + 12 * buf, k);
+        }
         if (FULL) {
 #pragma unroll
             for (int k = 0; k < 27; ++k) Dc[k] = 0.0;
@@ -3076,10 +3093,14 @@ __device__ __forceinline__ void chain_sweep(const WindowArgs& a, double* slab, l
         }
         // range edges whose later pose is p
         while (e < nr) {
-            const int v0 = ridx[2 * e], v1 = ridx[2 * e + 1];
+            const int v0 = (int)ne[0], v1 = (int)ne[1];
             if ((v1 > v0 ? v1 : v0) != p) break;
-            const double meas = rval[5 * e], info = rval[5 * e + 1];
-            const double off[3] = {rval[5 * e + 2], rval[5 * e + 3], rval[5 * e + 4]};
+            const double meas = ne[2], info = ne[3];
+            const double off[3] = {ne[4], ne[5], ne[6]};
+            if (e + 1 < nr) {
+#pragma unroll
+                for (int k = 0; k < 7; ++k) ne[k] = CE(e + 1, k);
+            }
             const bool first_is_cur = v0 == p;   // endpoint 0 (the lever arm) is pose p (else p - 1)
             double X0[12], X1[12];
 #pragma unroll
@@ -3163,13 +3184,12 @@ __device__ __forceinline__ void chain_sweep(const WindowArgs& a, double* slab, l
             ++e;
         }
         // unary priors on pose p
-        while (q < np && pidx[q] == p) {
-            const double* val = pval + 18 * q;
+        while (q < np && (int)npv == p) {
             double Zi[12], Wd[6];
 #pragma unroll
-            for (int k = 0; k < 12; ++k) Zi[k] = val[k];
+            for (int k = 0; k < 12; ++k) Zi[k] = CP(q, 1 + k);
 #pragma unroll
-            for (int k = 0; k < 6; ++k) Wd[k] = val[12 + k];
+            for (int k = 0; k < 6; ++k) Wd[k] = CP(q, 13 + k);
             double RE[9], tE[3], qq[4];
             mat_mul(Zi, Xc, RE);
             mat_vec(Zi, Xc + 9, tE);
@@ -3209,6 +3229,7 @@ __device__ __forceinline__ void chain_sweep(const WindowArgs& a, double* slab, l
                 }
             }
             ++q;
+            if (q < np) npv = CP(q, 0);
         }
         if (FULL) {
             if (p > 0) {
@@ -3236,6 +3257,8 @@ __device__ __forceinline__ void chain_sweep(const WindowArgs& a, double* slab, l
         for (int r = 0; r < 6; ++r) md = fmax(md, fabs(Dp[r * (r + 1) / 2 + r]));
     }
     robust_chi = rsum; plain_chi = csum; max_diag = md;
+#undef CE
+#undef CP
 }
 
 // pose p of the trial state: X (+) dx, read from pose buffer `buf`, written to the other one (accepting a step flips the
@@ -3434,7 +3457,7 @@ __global__ void __launch_bounds__(64, 1) chain_lm_kernel(const WindowArgs a, dou
     const long long inst = (long long)blockIdx.x * 64 + lane;
     const bool live = inst < a.B;
     const WindowCaps& c = a.caps;
-    double* slab = ws + (size_t)blockIdx.x * 64 * (size_t)c.nv_max * N + lane;
+    double* slab = ws + (size_t)blockIdx.x * 64 * chain_window_doubles(c) + lane;
     int nv = 0, nr = 0, np = 0;
     if (live) { nv = a.counts[inst * 4 + 0]; nr = a.counts[inst * 4 + 1]; np = a.counts[inst * 4 + 2]; }
     const double* gin = a.poses_in + (size_t)(live ? inst : 0) * c.nv_max * 12;
@@ -3444,6 +3467,24 @@ __global__ void __launch_bounds__(64, 1) chain_lm_kernel(const WindowArgs a, dou
         for (int k = 0; k < 12; ++k) CH(p, P, k) = gin[p * 12 + k];
 #pragma unroll
         for (int k = 0; k < 6; ++k) CH(p, X, k) = 0.0;   // the solver's x of a fresh optimize() call
+    }
+    {
+        const size_t eoff = (size_t)c.nv_max * N, poff = eoff + (size_t)c.nr_max * 7;
+        const int32_t* ridx = a.r_idx + (size_t)(live ? inst : 0) * c.nr_max * 2;
+        const double* rval = a.r_val + (size_t)(live ? inst : 0) * c.nr_max * 5;
+        for (int e = 0; e < nr; ++e) {
+            slab[(eoff + (size_t)e * 7 + 0) * 64] = (double)ridx[2 * e];
+            slab[(eoff + (size_t)e * 7 + 1) * 64] = (double)ridx[2 * e + 1];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) slab[(eoff + (size_t)e * 7 + 2 + k) * 64] = rval[5 * e + k];
+        }
+        const int32_t* pidx = a.p_idx + (size_t)(live ? inst : 0) * c.np_max;
+        const double* pval = a.p_val + (size_t)(live ? inst : 0) * c.np_max * 18;
+        for (int e = 0; e < np; ++e) {
+            slab[(poff + (size_t)e * 19) * 64] = (double)pidx[e];
+#pragma unroll
+            for (int k = 0; k < 18; ++k) slab[(poff + (size_t)e * 19 + 1 + k) * 64] = pval[18 * e + k];
+        }
     }
     constexpr double tau = 1e-5, good_lo = 1.0 / 3.0, good_hi = 2.0 / 3.0;
     constexpr int max_trials = 10;
