@@ -287,6 +287,10 @@ def _window_leg(D, args, wb, anchors, bw_max, name, workload, metric, unit, algo
            "elimination_levels": float(wb.result[0, 7] // 65536), "factor_blocks": float(int(wb.result[0, 7]) % 65536),
            "root_supernode_poses": float(round((wb.result[0, 7] % 1.0) * 16)),
            "roofline": hbm_roofline("window_lm_kernel", algo_bytes_per_instance * B, kern_ms, n_launch, name)}
+    nv0 = int(wb.counts[0, 0])
+    if nv0 > 1 and int(wb.result[0, 7]) == nv0 * 65536 + 2 * nv0 - 1 and not res["root_supernode_poses"]:
+        # (the signature of the one-lane-per-window kernel that large batches of chain windows take: pose order, n levels)
+        res["roofline"]["kernel"] = "chain_lm_kernel"
     if flops_per_instance:
         tf = flops_per_instance * B / (kern_ms * 1e-3) / 1e12
         res["valu_f64"] = {"achieved_tflops": tf, "peak_tflops": F64_VECTOR_PEAK_TFLOPS, "frac": tf / F64_VECTOR_PEAK_TFLOPS,

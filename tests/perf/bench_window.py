@@ -231,7 +231,7 @@ def main():
     algo_bytes = 2.0 * T * 56 + 240
     ach = algo_bytes * a.batch / (k_ms * 1e-3) / 1e9
     roof = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
-            "algorithmic_bytes_per_window": algo_bytes, "kernel": "window_lm_kernel", "kernel_ms_avg": k_ms}
+            "algorithmic_bytes_per_window": algo_bytes, "kernel": "window_lm_kernel", "kernel_ms_avg": k_ms}   # ("kernel" is corrected below for chain batches)
     if a.pmc_json and os.path.exists(a.pmc_json):
         pj = json.load(open(a.pmc_json))
         lane_flop = 64.0 * (pj.get("SQ_INSTS_VALU_ADD_F64", 0) + pj.get("SQ_INSTS_VALU_MUL_F64", 0) + 2 * pj.get("SQ_INSTS_VALU_FMA_F64", 0)
@@ -242,6 +242,10 @@ def main():
         if pj.get("FETCH_SIZE") is not None and pj.get("WRITE_SIZE") is not None:
             roof["traffic"] = (2.0 * pj["FETCH_SIZE"] + pj["WRITE_SIZE"]) * 1024.0   # KB -> B, FETCH_SIZE x2 (gfx950, MI355X_MICROARCH.md)
             roof["traffic_note"] = "HBM-side bytes per launch from PMC (FETCH_SIZE x 2 + WRITE_SIZE); uncalibrated for this access pattern"
+    if T > 1 and a.shape in ("uwb_only", "uwb_imu") and int(wb.result[0, 7]) == T * 65536 + 2 * T - 1:
+        # (the signature of the one-lane-per-window kernel that large batches of chain windows take: pose order, T levels)
+        roof["kernel"] = "chain_lm_kernel"
+        roof["note"] = "bound by its [entry][lane] workspace traffic (~0.5 MB per window), not by the algorithmic bytes"
     print(json.dumps({
         "roofline": roof,
         "shape": a.shape, "poses_per_window": T, "unknowns": 6 * T, "batch": a.batch, "bw_max": bw, "lds_bytes_per_instance": solver.lds_bytes,

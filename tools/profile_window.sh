@@ -1,5 +1,6 @@
 #!/bin/bash
 # rocprofv3 evidence for window_lm_kernel on the GPU box:  tools/profile_window.sh SHAPE BATCH OUTDIR [extra bench args]
+# (KERNEL=chain_lm_kernel in the environment for batches that take the one-lane-per-window kernel)
 #   1. plain run (JSON line)  2. --kernel-trace --stats  3. four --pmc passes (SQ twice, FETCH_SIZE, WRITE_SIZE: separate
 #   passes, never combined with a trace domain).  The batch is generated once and cached in /tmp between the passes.
 # Summaries land in OUTDIR (under gpurun_out/); copy what should be judged into profiles/.
@@ -26,7 +27,7 @@ for P in "$P1" "$P2" "$P3" "$P4" "$P5"; do
   rocprofv3 --pmc $P --output-format csv -d "$OUT/pmc${i}_${SHAPE}" -o p -- $BENCH > /dev/null || echo "[profile_window] pmc pass $i failed"
   echo "[profile_window] pmc pass $i done"
 done
-python3 tests/perf/pmc_summary.py window_lm_kernel "$OUT"/pmc*_${SHAPE} > "$OUT/pmc_${SHAPE}_${BATCH}.json"
+python3 tests/perf/pmc_summary.py ${KERNEL:-window_lm_kernel} "$OUT"/pmc*_${SHAPE} > "$OUT/pmc_${SHAPE}_${BATCH}.json"
 cat "$OUT/pmc_${SHAPE}_${BATCH}.json"
 # the same run once more with the counters folded into its roofline record
 $BENCH --cpu-n 0 --pmc-json "$OUT/pmc_${SHAPE}_${BATCH}.json" > "$OUT/bench_roofline_${SHAPE}_${BATCH}.json"
