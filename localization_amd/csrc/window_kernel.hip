@@ -3031,14 +3031,14 @@ hipError_t launch_window(const WindowArgs& a, hipStream_t stream) {
 // would run — and the wave's instruction stream is shared by 64 windows: ~12 k instructions per LM trial per 64 windows.
 // No cross-lane traffic, no LDS, no barriers.  The state of a window lives in an HBM workspace laid out [entry][lane]
 // (every load / store of the wave is one 512-byte line), per pose: H_pp (21), H_p,p-1 (36), b_p (6), G_p (15 + 6 inverse
-// pivots), W_p = L_p,p-1 (36), y_p, x_p, the pose and its backup: 156 doubles.  The LM loops are flattened into one loop of
+// pivots), y_p, x_p and two pose buffers: 120 doubles (W_p = L_p,p-1 is never stored: the back-substitution re-forms W^T x).  The LM loops are flattened into one loop of
 // passes (a pass = one trial; a lane that starts an iteration linearises first), lanes leave when their window is done.
 // The kernel is bound by that workspace traffic (~16 KB per window per trial), not by instruction issue.
 // Conditions (checked on the host, capi_window.cpp: chain_eligible): no SE3 edges; every moving-moving range edge joins
 // poses p - 1 and p; range edges sorted by their later pose, priors sorted by pose (the order the reference adds them in).
 // Elimination order = pose order (no fill), so the rounding differs from the general kernel's in the last bits.
 namespace chainw {
-constexpr int HD = 0, HO = 21, HB = 57, G = 63, W = 84, Y = 120, X = 126, P = 132, PB = 144, N = 156;
+constexpr int HD = 0, HO = 21, HB = 57, G = 63, Y = 84, X = 90, P = 96, PB = 108, N = 120;
 }
 
 // per window: nv_max poses x N doubles, then the edges as [entry][lane] too (range: v0, v1, measurement, information, lever
@@ -3339,7 +3339,7 @@ __device__ __forceinline__ bool chain_factor_solve(double* slab, int nv, double 
                     for (int c2 = cc + 1; c2 < 6; ++c2) w[c2] = __builtin_fma(-w[cc], Gp[c2][cc], w[c2]);
                 }
 #pragma unroll
-                for (int cc = 0; cc < 6; ++cc) { CH(p, W, 6 * cc + r) = w[cc]; Wm[6 * cc + r] = w[cc]; }
+                for (int cc = 0; cc < 6; ++cc) Wm[6 * cc + r] = w[cc];   // (not stored: the back-substitution re-forms W^T x from H_p,p-1 and G)
                 double acc = rhs[r];
 #pragma unroll
                 for (int cc = 0; cc < 6; ++cc) acc = __builtin_fma(-w[cc], yp[cc], acc);
@@ -3401,7 +3401,9 @@ __device__ __forceinline__ bool chain_factor_solve(double* slab, int nv, double 
     double xn[6];
 #pragma unroll
     for (int r = 0; r < 6; ++r) xn[r] = 0.0;
-    double nG[21], nY[6], nW[36];   // (requested one pose ahead, as in the forward sweep)
+    // x_p = G_p^-T (y_p - W_{p+1}^T x_{p+1}) with W_{p+1}^T x = G_p^-1 (H_{p+1,p}^T x): W itself is never stored (it was a fifth of the
+    // bytes a trial moved)
+    double nG[21], nY[6], nW[36];   // (requested one pose ahead, as in the forward sweep; nW: H_{p+1,p})
 #pragma unroll
     for (int k = 0; k < 21; ++k) nG[k] = CH(nv - 1, G, k);
 #pragma unroll
@@ -3429,13 +3431,25 @@ __device__ __forceinline__ bool chain_factor_solve(double* slab, int nv, double 
         }
         if (p > 0) {
 #pragma unroll
-            for (int k = 0; k < 36; ++k) nW[k] = CH(p, W, k);   // (pose p's W is what pose p - 1 needs next)
+            for (int k = 0; k < 36; ++k) nW[k] = CH(p, HO, k);   // (pose p's coupling block is what pose p - 1 needs next)
         }
         if (p < nv - 1) {
+            double v[6];
 #pragma unroll
-            for (int cc = 0; cc < 6; ++cc)
+            for (int cc = 0; cc < 6; ++cc) {
+                double acc = 0.0;
 #pragma unroll
-                for (int r = 0; r < 6; ++r) t[cc] = __builtin_fma(-Wn[6 * cc + r], xn[r], t[cc]);
+                for (int r = 0; r < 6; ++r) acc = __builtin_fma(Wn[6 * cc + r], xn[r], acc);
+                v[cc] = acc;
+            }
+            // z = G_p^-1 v (forward substitution), t -= z
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc) {
+                v[cc] *= ig[cc];
+#pragma unroll
+                for (int c2 = cc + 1; c2 < 6; ++c2) v[c2] = __builtin_fma(-v[cc], Gl[c2][cc], v[c2]);
+                t[cc] -= v[cc];
+            }
         }
 #pragma unroll
         for (int rr = 5; rr >= 0; --rr) {
