@@ -3055,7 +3055,7 @@ namespace {
 // one sweep over the window's edges in pose order: chi sums always; FULL: H and b as well (returns the largest diagonal entry)
 template <bool FULL, int JAC>
 __device__ __forceinline__ void chain_sweep(const WindowArgs& a, double* slab, long long inst, int nv, int nr, int np, int buf,
-                                            double& robust_chi, double& plain_chi, double& max_diag) {
+                                            double& robust_chi, double& plain_chi, double& max_diag, unsigned long long& ho_kind) {
     using namespace chainw;
 #define CH(p, f, k) slab[((size_t)(p) * N + (f) + (k)) * 64]
     const WindowCaps& c = a.caps;
@@ -3070,6 +3070,15 @@ __device__ __forceinline__ void chain_sweep(const WindowArgs& a, double* slab, l
     for (int k = 0; k < 27; ++k) { Dp[k] = 0.0; Dc[k] = 0.0; }
 #pragma unroll
     for (int k = 0; k < 12; ++k) { Xp[k] = 0.0; Xc[k] = 0.0; }
+    // The coupling block H_p,p-1 of a pair of poses joined by ONE range edge (the reference's smoothness edge) is the rank-1
+    // matrix (w J_p) J_{p-1}^T: it is stored as those two vectors (12 doubles instead of 36 — the block is read twice per LM
+    // trial, a quarter of all the bytes a trial moved).  ho_kind: two bits per pose (0 no coupling, 1 rank-1, 2 full block;
+    // poses from 32 on always store the full block).
+    unsigned long long kinds = 0;
+    int nbin = 0;
+    double fu[6], fv[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { fu[k] = 0.0; fv[k] = 0.0; }
     int e = 0, q = 0;
     // (the next edge and the next pose are requested one step ahead: nothing else hides a memory round trip here)
     double ne[7], nX[12], npv = 0.0;
@@ -3090,6 +3099,7 @@ __device__ __forceinline__ void chain_sweep(const WindowArgs& a, double* slab, l
             for (int k = 0; k < 27; ++k) Dc[k] = 0.0;
 #pragma unroll
             for (int k = 0; k < 36; ++k) O[k] = 0.0;
+            nbin = 0;
         }
         // range edges whose later pose is p
         while (e < nr) {
@@ -3170,15 +3180,29 @@ __device__ __forceinline__ void chain_sweep(const WindowArgs& a, double* slab, l
                         Dc[21 + r] += first_is_cur ? 0.0 : bb;
                         Dp[21 + r] += first_is_cur ? bb : 0.0;
                     }
+                    // J of pose p (rows) x J of pose p - 1 (columns); J1 has three entries
+                    double jr[6], jc[6];
 #pragma unroll
-                    for (int r = 0; r < 6; ++r)
+                    for (int r = 0; r < 6; ++r) {
+                        jr[r] = first_is_cur ? J0[r] : (r < 3 ? J1[r] : 0.0);
+                        jc[r] = first_is_cur ? (r < 3 ? J1[r] : 0.0) : J0[r];
+                    }
+                    if (nbin == 0 && p < 32) {
 #pragma unroll
-                        for (int cc = 0; cc < 6; ++cc) {
-                            // J of pose p (rows) x J of pose p - 1 (columns); J1 has three entries
-                            const double jr = first_is_cur ? J0[r] : (r < 3 ? J1[r] : 0.0);
-                            const double jc = first_is_cur ? (cc < 3 ? J1[cc] : 0.0) : J0[cc];
-                            O[6 * cc + r] += wr * jr * jc;
+                        for (int r = 0; r < 6; ++r) { fu[r] = wr * jr[r]; fv[r] = jc[r]; }
+                    } else {
+                        if (nbin == 1 && p < 32) {   // a second edge on the pair: expand the first
+#pragma unroll
+                            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                                for (int cc = 0; cc < 6; ++cc) O[6 * cc + r] = fu[r] * fv[cc];
                         }
+#pragma unroll
+                        for (int r = 0; r < 6; ++r)
+#pragma unroll
+                            for (int cc = 0; cc < 6; ++cc) O[6 * cc + r] += wr * jr[r] * jc[cc];
+                    }
+                    ++nbin;
                 }
             }
             ++e;
@@ -3239,8 +3263,15 @@ __device__ __forceinline__ void chain_sweep(const WindowArgs& a, double* slab, l
                 for (int k = 0; k < 6; ++k) CH(p - 1, HB, k) = Dp[21 + k];
 #pragma unroll
                 for (int r = 0; r < 6; ++r) md = fmax(md, fabs(Dp[r * (r + 1) / 2 + r]));
+                if (nbin == 1 && p < 32) {
 #pragma unroll
-                for (int k = 0; k < 36; ++k) CH(p, HO, k) = O[k];
+                    for (int k = 0; k < 6; ++k) { CH(p, HO, k) = fu[k]; CH(p, HO, 6 + k) = fv[k]; }
+                    kinds |= 1ull << (2 * p);
+                } else if (nbin >= 1 || p >= 32) {   // (poses from 32 on are always read as full blocks: zeros when uncoupled)
+#pragma unroll
+                    for (int k = 0; k < 36; ++k) CH(p, HO, k) = O[k];
+                    if (p < 32) kinds |= 2ull << (2 * p);
+                }
             }
 #pragma unroll
             for (int k = 0; k < 27; ++k) Dp[k] = Dc[k];
@@ -3257,6 +3288,7 @@ __device__ __forceinline__ void chain_sweep(const WindowArgs& a, double* slab, l
         for (int r = 0; r < 6; ++r) md = fmax(md, fabs(Dp[r * (r + 1) / 2 + r]));
     }
     robust_chi = rsum; plain_chi = csum; max_diag = md;
+    if (FULL) ho_kind = kinds;
 #undef CE
 #undef CP
 }
@@ -3287,9 +3319,11 @@ __device__ __forceinline__ double chain_apply_step(double* slab, int p, int buf,
 // (H + lambda I) x = b for a block-tridiagonal H: forward sweep (Cholesky + forward substitution), then the back-substitution
 // with the step applied pose by pose as its x comes out.  x is only written when every pivot was positive and finite (g2o
 // leaves its x alone when the factorisation fails, and LM applies that stale x all the same).
-__device__ __forceinline__ bool chain_factor_solve(double* slab, int nv, double lambda, int buf, double& scale_sum) {
+__device__ __forceinline__ bool chain_factor_solve(double* slab, int nv, double lambda, int buf, unsigned long long ho_kind, double& scale_sum) {
     using namespace chainw;
     scale_sum = 0.0;
+    // kind of pose p's coupling block (chain_sweep): 0 none, 1 rank-1 (12 doubles), 2 full (36)
+    auto kind_of = [&](int p) { return p < 32 ? (int)((ho_kind >> (2 * p)) & 3ull) : (p > 0 ? 2 : 0); };
     bool ok = true;
     double Gp[6][6], igp[6], yp[6];   // the previous pose's factor (strict lower), inverse pivots, y
 #pragma unroll
@@ -3316,15 +3350,28 @@ __device__ __forceinline__ bool chain_factor_solve(double* slab, int nv, double 
         }
 #pragma unroll
         for (int k = 0; k < 36; ++k) Ho[k] = nHo[k];
+        const int kd = kind_of(p);
+        if (kd == 1) {   // rank-1: u v^T
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 6; ++cc) Ho[6 * cc + r] = nHo[r] * nHo[6 + cc];
+        }
         if (p + 1 < nv) {
 #pragma unroll
             for (int k = 0; k < 21; ++k) nHd[k] = CH(p + 1, HD, k);
 #pragma unroll
             for (int k = 0; k < 6; ++k) nHb[k] = CH(p + 1, HB, k);
+            const int kn = kind_of(p + 1);
+            if (kn == 1) {
 #pragma unroll
-            for (int k = 0; k < 36; ++k) nHo[k] = CH(p + 1, HO, k);
+                for (int k = 0; k < 12; ++k) nHo[k] = CH(p + 1, HO, k);
+            } else if (kn == 2) {
+#pragma unroll
+                for (int k = 0; k < 36; ++k) nHo[k] = CH(p + 1, HO, k);
+            }
         }
-        if (p > 0) {
+        if (kd != 0) {
             // row by row: w = row r of W = H_p,p-1 G_{p-1}^-T; S -= w w^T; rhs_r -= w . y_{p-1}
             double Wm[36];   // W, entry (r, c) at 6 c + r
 #pragma unroll
@@ -3429,18 +3476,33 @@ __device__ __forceinline__ bool chain_factor_solve(double* slab, int nv, double 
 #pragma unroll
             for (int k = 0; k < 6; ++k) nY[k] = CH(p - 1, Y, k);
         }
-        if (p > 0) {
+        const int kup = p < nv - 1 ? kind_of(p + 1) : 0;   // kind of the block that couples pose p + 1 to this one (held in Wn)
+        {
+            const int kme = kind_of(p);   // (pose p's coupling block is what pose p - 1 needs next)
+            if (kme == 1) {
 #pragma unroll
-            for (int k = 0; k < 36; ++k) nW[k] = CH(p, HO, k);   // (pose p's coupling block is what pose p - 1 needs next)
+                for (int k = 0; k < 12; ++k) nW[k] = CH(p, HO, k);
+            } else if (kme == 2) {
+#pragma unroll
+                for (int k = 0; k < 36; ++k) nW[k] = CH(p, HO, k);
+            }
         }
-        if (p < nv - 1) {
+        if (kup != 0) {
             double v[6];
+            if (kup == 1) {   // (u v^T)^T x = v (u . x)
+                double sx = 0.0;
 #pragma unroll
-            for (int cc = 0; cc < 6; ++cc) {
-                double acc = 0.0;
+                for (int r = 0; r < 6; ++r) sx = __builtin_fma(Wn[r], xn[r], sx);
 #pragma unroll
-                for (int r = 0; r < 6; ++r) acc = __builtin_fma(Wn[6 * cc + r], xn[r], acc);
-                v[cc] = acc;
+                for (int cc = 0; cc < 6; ++cc) v[cc] = Wn[6 + cc] * sx;
+            } else {
+#pragma unroll
+                for (int cc = 0; cc < 6; ++cc) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) acc = __builtin_fma(Wn[6 * cc + r], xn[r], acc);
+                    v[cc] = acc;
+                }
             }
             // z = G_p^-1 v (forward substitution), t -= z
 #pragma unroll
@@ -3504,13 +3566,14 @@ __global__ void __launch_bounds__(64, 1) chain_lm_kernel(const WindowArgs a, dou
     constexpr int max_trials = 10;
     double lambda = 0.0, ni = 2.0, cur_chi = 0.0, last_plain = 0.0;
     int it = 0, q = 0, trials = 0, terminated = 0, buf = 0;
+    unsigned long long ho_kind = 0;
     bool need_lin = true;
     bool done = !live || nv <= 0 || nr + np <= 0 || a.iterations <= 0;
     while (__ballot(!done)) {
         if (!done) {
             if (need_lin) {
                 double plain, md;
-                chain_sweep<true, JAC>(a, slab, inst, nv, nr, np, buf, cur_chi, plain, md);
+                chain_sweep<true, JAC>(a, slab, inst, nv, nr, np, buf, cur_chi, plain, md, ho_kind);
                 last_plain = plain;
                 if (it == 0) { lambda = tau * md; ni = 2.0; }
                 q = 0;
@@ -3518,10 +3581,11 @@ __global__ void __launch_bounds__(64, 1) chain_lm_kernel(const WindowArgs a, dou
             }
             // solve and apply the step (the trial state goes to the other pose buffer)
             double sc;
-            const bool ok2 = chain_factor_solve(slab, nv, lambda, buf, sc);
+            const bool ok2 = chain_factor_solve(slab, nv, lambda, buf, ho_kind, sc);
             ++trials;
             double temp_chi, plain2, md2;
-            chain_sweep<false, JAC>(a, slab, inst, nv, nr, np, 1 - buf, temp_chi, plain2, md2);
+            unsigned long long unused_kind;
+            chain_sweep<false, JAC>(a, slab, inst, nv, nr, np, 1 - buf, temp_chi, plain2, md2, unused_kind);
             last_plain = plain2;
             if (!ok2) temp_chi = DBL_MAX;
             const double scale = sc + 1e-3;

@@ -444,6 +444,7 @@ def test_wide_windows_ragged_batch(gpu, jac):
     (10, False, False, "numeric"),    # the reference's Jacobian mode
     (1, True, True, "analytic"),      # a lone pose
     (16, True, True, "numeric"),
+    (40, False, True, "analytic"),    # beyond 32 poses the coupling blocks are always stored in full
 ])
 def test_chain_kernel_matches_oracle(gpu, T, with_imu, lever, jac):
     """Large batches of chain windows run one lane per window (chain_lm_kernel: block-tridiagonal Cholesky in pose order,
@@ -454,7 +455,7 @@ def test_chain_kernel_matches_oracle(gpu, T, with_imu, lever, jac):
     from _oracle_window import oracle_solve_instance
     B = 70   # (one full wave of windows + a partial one)
     rng = np.random.default_rng(100 * T + len(jac))
-    nr_max, np_max = max(2 * T, 4), (T if with_imu else 0)
+    nr_max, np_max = max(2 * T + 2, 4), (T if with_imu else 0)
     wb = la.WindowBatch(B, T, nr_max, np_max, 0)
     for i in range(B):
         Ti = T if i % 7 else max(T // 2, 1)   # ragged lengths inside the wave
@@ -466,7 +467,9 @@ def test_chain_kernel_matches_oracle(gpu, T, with_imu, lever, jac):
             for (kk, a, d, info) in ranges:
                 if kk == k: wb.add_range(i, k, a, d, info, off, anchor=True)
             for (k0, k1, d, info) in smooth:
-                if k1 == k: wb.add_range(i, k0, k1, d, info)
+                if k1 == k and not (i % 5 == 2 and k == 3):   # (some windows miss a link: two independent chains)
+                    wb.add_range(i, k0, k1, d, info)
+                    if i % 5 == 1 and k == 2: wb.add_range(i, k1, k0, 0.02, 0.5 * info, off)   # (and some have two edges on one pair, the second the other way round with a lever arm)
         for (k, t, R, dg) in priors: wb.add_prior(i, k, t, R, dg)
     wb.counts[3, 1:] = 0   # an instance whose poses have no edge at all: comes back untouched
     before = wb.poses.copy()
@@ -481,7 +484,9 @@ def test_chain_kernel_matches_oracle(gpu, T, with_imu, lever, jac):
     chain = la.WindowSolver(ANCH, B, T, nr_max, np_max, 0, jacobian=jac, chain_threshold=1)
     res = chain.solve(wb).copy()
     assert (res[res[:, 3] > 0, 7] % 65536 == 2 * (res[res[:, 3] > 0, 7] // 65536) - 1).all()   # (the chain kernel's signature: n levels, 2 n - 1 blocks)
-    tol = 1e-7 if jac == "analytic" else 1e-5
+    # (numeric vs numeric: the central differences of the near-zero ranges between consecutive poses — some of them doubled here —
+    #  amplify the last bits of a different summation order; the analytic mode holds 1e-7)
+    tol = 1e-7 if jac == "analytic" else 3e-5
     for i in range(B):
         nv = int(wb.counts[i, 0])
         if nv == 0 or wb.counts[i, 1] + wb.counts[i, 2] == 0:
