@@ -148,7 +148,11 @@ int loc_snapshot_timing_end(loc_snapshot* s, int32_t* n_launches, double* total_
  *   s_idx  int32 [B][ns_max][4]   vi, vj, robust (0/1), 0
  *   s_val  double[B][ns_max][48]  INVERSE measurement Z^-1 as R(9), t(3); information 6x6 row-major
  *   result double[B][8]           chi2() over all edges at the last evaluated state, robust chi2 of the accepted
- *                                 state, final lambda, outer iterations run, LM trials, terminated flag, 0, 0
+ *                                 state, final lambda, outer iterations run, LM trials, terminated flag, [6] number of
+ *                                 pose-to-pose edges that share their pair of poses with another edge, [7] diagnostics of
+ *                                 the factorisation (windows of <= 512 poses): elimination levels * 65536 + blocks of the
+ *                                 factor + (poses in the dense root supernode) / 16; the one-lane-per-window kernel
+ *                                 reports nv * 65536 + 2 nv - 1
  * The normal equations are kept as sparse 6x6 blocks (storage sized from the envelope bound nv_max * bw_max: per pose,
  * columns from its leftmost neighbour to itself), so storage and work scale with nv_max * bw_max^2, not nv_max^3:
  * cfg/uwb_pose.yaml's 500-pose chain is 3000 rows of ~12 entries.

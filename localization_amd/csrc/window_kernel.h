@@ -25,7 +25,7 @@ struct WindowCaps {
 //   s_val   double[B][ns_max][48]   Z^-1 as R(9), t(3); information 6x6 row-major (36)
 //   result  double[B][8]            chi2 (all edges, last evaluated), robust chi2, lambda, outer iterations,
 //                                   LM trials, terminated, number of binary edges that share their pair of poses with another edge,
-//                                   (nv_max <= 64) elimination-tree levels * 65536 + blocks of the factor
+//                                   (nv_max <= 512) elimination-tree levels * 65536 + blocks of the factor + root-supernode poses / 16
 struct WindowArgs {
     const int32_t* counts;
     const double* poses_in;  // initial estimates (may alias `poses`: every instance reads its poses before it writes them)
