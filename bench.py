@@ -256,7 +256,7 @@ def leg_cfg3(D, args):
 
 
 def _window_leg(D, args, wb, anchors, bw_max, name, workload, metric, unit, algo_bytes_per_instance, total_instances, oracle_fn, n_cpu,
-                flops_per_instance=None):
+                flops_per_instance=None, parity_fn=None, n_parity=0):
     """Resident window solves: upload once, `steps` launches from the same initial estimates, HIP-event kernel times."""
     import numpy as np
     import localization_amd as la
@@ -306,6 +306,10 @@ def _window_leg(D, args, wb, anchors, bw_max, name, workload, metric, unit, algo
                                "diff_note": "GPU leg: analytic range Jacobians; oracle: g2o's central differences (the reference's configuration). "
                                             "The two modes take different LM accept/reject decisions on a few instances (tests/test_gpu_node_parity.py "
                                             "holds numeric vs numeric and analytic vs analytic to 1e-5 / 1e-7 m)"}
+        if parity_fn is not None and n_parity > 0:   # the same Jacobian mode on both sides
+            same = parity_fn(n_parity)
+            res["cpu_baseline"]["max_abs_diff_vs_gpu_same_jacobian_mode_m"] = float(np.abs(wb.poses[:n_parity, :, 9:] - same).max())
+            res["cpu_baseline"]["same_mode_sample"] = f"first {n_parity} instances, oracle with analytic Jacobians like the GPU leg"
     wb.poses[:] = poses0
     return res
 
@@ -344,7 +348,8 @@ def leg_cfg1_windows(D, args):
     return _window_leg(D, args, wb, anchors, 1, "1360 B/window; the kernel is bound by instruction issue and LDS capacity (8 windows per CU), not bytes",
                        "cfg/uwb_only.yaml's sliding window as a batch: 10 poses, 19 range edges (10 to anchors, 9 smoothness), Cauchy, 10 LM iterations",
                        "window solves/sec", "windows/s", 1360.0, total,
-                       lambda n: bw.oracle_time(graphs, anchors, T, n)[1], 2048)
+                       lambda n: bw.oracle_time(graphs, anchors, T, n)[1], 2048,
+                       parity_fn=lambda n: bw.oracle_time(graphs, anchors, T, n, analytic=True)[1], n_parity=512)
 
 
 def leg_cfg4(D, args):

@@ -142,7 +142,7 @@ def oracle_selfcal(g, T, A, iters=10):
     return np.array([G.estimate(100 + k)[1] for k in range(T + A)])
 
 
-def oracle_time(graphs, anchors, T, n, iters=10):
+def oracle_time(graphs, anchors, T, n, iters=10, analytic=False):
     from oracle import oracle as O
     t0 = time.perf_counter()
     out = []
@@ -159,7 +159,7 @@ def oracle_time(graphs, anchors, T, n, iters=10):
         for (k0, k1) in g["smooth"]: G.add_range_edge(100 + k0, 100 + k1, 0.0, 1 / (5.0 / 32 / 3) ** 2)
         for (k, t, R, dg) in g["priors"]: G.add_prior_edge(100 + k, t, R, np.diag(dg))
         for (ki, kj, t, R) in g.get("se3", []): G.add_se3_edge(100 + ki, 100 + kj, t, R, np.eye(6) * 1e4, True)
-        G.optimize(iters, O.JAC_NUMERIC_G2O)
+        G.optimize(iters, O.JAC_ANALYTIC if analytic else O.JAC_NUMERIC_G2O)
         out.append(np.array([G.estimate(100 + k)[1] for k in range(T)]))
     return time.perf_counter() - t0, np.array(out)
 
