@@ -47,6 +47,19 @@ def kernel_source_hash(names):
 
 
 SNAPSHOT_KERNEL_SOURCES = ("snapshot_kernel.hip", "snapshot_kernel.h", "device_math.h")
+WINDOW_KERNEL_SOURCES = ("window_kernel.hip", "window_kernel.h", "device_math.h", "numeric_jacobian.h")
+
+
+def window_traffic(leg, world):
+    """PMC-measured HBM-side bytes per launch of a window leg's single-GPU batch (profiles/window_traffic.json,
+    tools/make_window_traffic.py), or None when the kernel sources have changed since or the batch is sharded differently."""
+    path = os.path.join(ROOT, "profiles", "window_traffic.json")
+    if world != 1 or not os.path.exists(path):
+        return None
+    pj = json.load(open(path))
+    if pj.get("kernel_source_sha256") != kernel_source_hash(WINDOW_KERNEL_SOURCES):
+        return {"stale": "profiles/window_traffic.json was measured on different kernel sources (hash mismatch): traffic withheld"}
+    return pj.get("legs", {}).get(leg)
 
 
 def cpu_baseline(anchors, dist_tiles, err_tiles, init, n_tags, n_epochs, gpu_pos, M):
@@ -256,7 +269,7 @@ def leg_cfg3(D, args):
 
 
 def _window_leg(D, args, wb, anchors, bw_max, name, workload, metric, unit, algo_bytes_per_instance, total_instances, oracle_fn, n_cpu,
-                flops_per_instance=None, parity_fn=None, n_parity=0):
+                flops_per_instance=None, parity_fn=None, n_parity=0, leg=None):
     """Resident window solves: upload once, `steps` launches from the same initial estimates, HIP-event kernel times."""
     import numpy as np
     import localization_amd as la
@@ -291,6 +304,17 @@ def _window_leg(D, args, wb, anchors, bw_max, name, workload, metric, unit, algo
     if nv0 > 1 and int(wb.result[0, 7]) == nv0 * 65536 + 2 * nv0 - 1 and not res["root_supernode_poses"]:
         # (the signature of the one-lane-per-window kernel that large batches of chain windows take: pose order, n levels)
         res["roofline"]["kernel"] = "chain_lm_kernel"
+    tr = window_traffic(leg, D.world) if leg else None
+    if tr and "stale" in tr:
+        res["roofline"]["stale"] = tr["stale"]
+    elif tr:
+        res["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+        res["roofline"]["traffic_unit"] = "bytes per launch"
+        res["roofline"]["traffic_source"] = tr["source"]
+        res["roofline"]["traffic_rate"] = {"achieved": tr["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": tr["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                           "note": "PMC-measured HBM-side bytes of the same launch shape / live kernel time: what the memory system "
+                                                   "actually moved (workspace traffic), against the 8 TB/s peak"}
     if flops_per_instance:
         tf = flops_per_instance * B / (kern_ms * 1e-3) / 1e12
         res["valu_f64"] = {"achieved_tflops": tf, "peak_tflops": F64_VECTOR_PEAK_TFLOPS, "frac": tf / F64_VECTOR_PEAK_TFLOPS,
@@ -326,7 +350,7 @@ def leg_cfg5(D, args):
     return _window_leg(D, args, wb, anchors, 8, "7408 B/window (SURVEY §8(d)); the kernel is bound by latency and VALU issue, not bytes",
                        "BASELINE cfg5: 64-pose windows (cfg/uwb_pose.yaml topology), one range + one key-frame EdgeSE3 per pose, Cauchy, 10 LM iterations",
                        "window solves/sec", "windows/s", ALGO_BYTES_CFG5, total,
-                       lambda n: bw.oracle_time(graphs, anchors, T, n)[1], 256)
+                       lambda n: bw.oracle_time(graphs, anchors, T, n)[1], 256, leg="cfg5")
 
 
 def leg_cfg1_windows(D, args):
@@ -349,7 +373,7 @@ def leg_cfg1_windows(D, args):
                        "cfg/uwb_only.yaml's sliding window as a batch: 10 poses, 19 range edges (10 to anchors, 9 smoothness), Cauchy, 10 LM iterations",
                        "window solves/sec", "windows/s", 1360.0, total,
                        lambda n: bw.oracle_time(graphs, anchors, T, n)[1], 2048,
-                       parity_fn=lambda n: bw.oracle_time(graphs, anchors, T, n, analytic=True)[1], n_parity=512)
+                       parity_fn=lambda n: bw.oracle_time(graphs, anchors, T, n, analytic=True)[1], n_parity=512, leg="cfg1_windows")
 
 
 def leg_cfg4(D, args):
@@ -364,7 +388,7 @@ def leg_cfg4(D, args):
     res = _window_leg(D, args, wb, anchors, nv - 1, "33 248 B per hypothesis per LM iteration x 10 iterations (SURVEY §8(d))",
                       "BASELINE cfg4: anchor self-calibration, 256 tag poses + 10 unknown anchors per hypothesis (1596 unknowns, 2815 range edges), 10 LM iterations",
                       "hypothesis solves/sec", "solves/s", ALGO_BYTES_CFG4_PER_IT * 10, total,
-                      lambda n: np.array([bw.oracle_selfcal(g, 256, 10) for g in graphs[:n]]), 8)
+                      lambda n: np.array([bw.oracle_selfcal(g, 256, 10) for g in graphs[:n]]), 8, leg="cfg4")
     res["lm_iterations_per_s"] = res["value"] * 10
     return res
 
