@@ -2837,13 +2837,23 @@ __global__ void __launch_bounds__(64 * NW, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 
     }
     sync_<SOLO>();
     if (SMALL) plan = make_small_plan(L, lane, nv, plan.level);
-    if (!SOLO) compute_incidence<SP, SOLO>(L, lane, nv, nr, np, ns);
+    if (!SOLO) {
+        const int nnz = L.boff[nv];
+        for (int i = lane; i < nnz; i += 64) L.Hs[i] = 0.0;   // (once per launch: see the LM loop)
+        __syncthreads();
+        compute_incidence<SP, SOLO>(L, lane, nv, nr, np, ns);
+    }
     }
     if (SOLO) {   // the other waves join: the structure is in LDS / the workspace, the level count in wave 0's registers
         if (lane == 0) { s_meta[0] = L.nlev; s_meta[1] = L.dense_ok; s_meta[2] = L.root_level; }
         __syncthreads();
         L.nlev = s_meta[0]; L.dense_ok = s_meta[1]; L.root_level = s_meta[2];
         L.colmode = 0; L.pushmask = 0;
+        {
+            const int nnz = L.boff[nv];
+            for (int i = lane; i < nnz; i += NT) L.Hs[i] = 0.0;   // (once per launch: see the LM loop)
+            __syncthreads();
+        }
         compute_incidence_wide<SP, NW>(L, lane, nv, nr, np, ns);
     }
 
@@ -2862,13 +2872,10 @@ __global__ void __launch_bounds__(64 * NW, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 
     bool ok = !empty;
     for (it = 0; it < a.iterations && ok; ++it) {
         double plain;
-        {
-            LOCAMD_TIC();
-            const int nnz = L.boff[nv];
-            for (int i = lane; i < nnz; i += NT) L.Hs[i] = 0.0;
-            __syncthreads();
-            LOCAMD_TOC(2);
-        }
+        // (H is zeroed ONCE per launch, below the structure set-up: every iteration writes all 36 entries of every block that has
+        //  an edge and the lower triangle of every diagonal block — the only entries of those blocks that are ever read — and the
+        //  fill blocks of the factor's structure are never written: they stay zero.  Zeroing it per iteration was 8 % of the bytes
+        //  BASELINE config 5 moved.)
         {
             LOCAMD_TIC();
             evaluate_edges<true, JAC, SP, NW>(a, L, inst, lane, nr, np, ns, cur_chi, plain);  // computeActiveErrors + linearize
