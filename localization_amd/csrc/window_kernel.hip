@@ -2897,7 +2897,7 @@ __global__ void __launch_bounds__(64 * NW, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 
         double rho = 0.0;
         int q = 0;
         do {
-            for (int i = lane; i < nv * 12; i += NT) L.bak[i] = L.pose[i];  // push
+            // (push / pop without copies: the trial state is written to the other pose buffer and the two pointers swap)
 #ifdef LOCAMD_WINDOW_TIMING
             const long long locamd_tf = clock64();
 #endif
@@ -2915,7 +2915,8 @@ __global__ void __launch_bounds__(64 * NW, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 
             // update: X <- X * fromVectorMQT(dx), one pose per lane
             for (int v = lane; v < nv; v += NT) {
                 const double* dx = L.x + v * 6;
-                double* X = L.pose + v * 12;
+                const double* X = L.pose + v * 12;
+                double* Xn = L.bak + v * 12;
                 double Rd[9];
                 const double ww = 1.0 - (dx[3] * dx[3] + dx[4] * dx[4] + dx[5] * dx[5]);
                 if (ww < 0) { Rd[0] = 1; Rd[1] = 0; Rd[2] = 0; Rd[3] = 0; Rd[4] = 1; Rd[5] = 0; Rd[6] = 0; Rd[7] = 0; Rd[8] = 1; }
@@ -2923,10 +2924,11 @@ __global__ void __launch_bounds__(64 * NW, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 
                 double Rn[9], tn[3];
                 mat_mul(X, Rd, Rn);
                 mat_vec(X, dx, tn);
-                X[9] += tn[0]; X[10] += tn[1]; X[11] += tn[2];
+                Xn[9] = X[9] + tn[0]; Xn[10] = X[10] + tn[1]; Xn[11] = X[11] + tn[2];
 #pragma unroll
-                for (int i = 0; i < 9; ++i) X[i] = Rn[i];
+                for (int i = 0; i < 9; ++i) Xn[i] = Rn[i];
             }
+            { double* t = L.pose; L.pose = L.bak; L.bak = t; }   // L.pose: the trial state; L.bak: the state it came from
             __syncthreads();
             ++trials;
             double temp_chi, plain2;
@@ -2948,8 +2950,7 @@ __global__ void __launch_bounds__(64 * NW, (GLOBAL_A && SP) ? LOCAMD_WS_WAVES : 
             } else {
                 lambda *= ni;
                 ni *= 2.0;
-                __syncthreads();
-                for (int i = lane; i < nv * 12; i += NT) L.pose[i] = L.bak[i];  // pop
+                { double* t = L.pose; L.pose = L.bak; L.bak = t; }   // pop
             }
             __syncthreads();
             ++q;
