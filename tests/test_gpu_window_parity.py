@@ -512,3 +512,40 @@ def test_chain_kernel_matches_oracle(gpu, T, with_imu, lever, jac):
         nv = int(wb.counts[i, 0])
         assert np.array_equal(wb2.poses[i, :nv], wb.poses[i, :nv]), i
     assert np.array_equal(wb2.result, res)
+
+
+def test_skyline_window_matches_chain_kernel_600_poses(gpu):
+    """Windows of 513 .. 1024 poses take the envelope (skyline) factorisation in the caller's order; the oracle's dense solve of
+    3600 unknowns is out of reach for a unit test, so the check is against the other independent implementation of the same
+    problem: the one-lane-per-window block-tridiagonal kernel (forced by the threshold), whose own parity with the oracle is
+    held by test_chain_kernel_matches_oracle.  Same LM trajectory, same poses."""
+    import localization_amd as la
+    T, B = 600, 2
+    rng = np.random.default_rng(600)
+    nr_max = 2 * T
+    wbs = []
+    for rep in range(2):
+        wb = la.WindowBatch(B, T, nr_max, 0, 0)
+        wbs.append(wb)
+    for i in range(B):
+        est_t, est_R, off, ranges, smooth, priors, _ = _random_window(rng, T, False, False, True)
+        for wb in wbs:
+            for k in range(T):
+                wb.add_pose(i, est_t[k], est_R[k])
+            for k in range(T):
+                for (kk, a, d, info) in ranges:
+                    if kk == k: wb.add_range(i, k, a, d, info, off, anchor=True)
+                for (k0, k1, d, info) in smooth:
+                    if k1 == k: wb.add_range(i, k0, k1, d, info)
+    sky = la.WindowSolver(ANCH, B, T, nr_max, 0, 0, bw_max=1, chain_threshold=0)
+    res_sky = sky.solve(wbs[0]).copy()
+    sky.close()
+    chain = la.WindowSolver(ANCH, B, T, nr_max, 0, 0, bw_max=1, chain_threshold=1)
+    res_chain = chain.solve(wbs[1]).copy()
+    chain.close()
+    assert (res_chain[:, 7] == T * 65536 + 2 * T - 1).all() and (res_sky[:, 7] == 0).all()   # (which kernel ran)
+    assert np.isfinite(wbs[0].poses).all()
+    assert np.abs(wbs[0].poses - wbs[1].poses).max() < 1e-7
+    assert np.array_equal(res_sky[:, 3:6], res_chain[:, 3:6])                                # iterations, trials, terminated
+    assert np.abs(res_sky[:, 0] - res_chain[:, 0]).max() <= 1e-6 * np.abs(res_sky[:, 0]).max()
+    assert (res_sky[:, 1] < 0.5 * 1e9).all() and (res_sky[:, 4] >= 10).all()
