@@ -187,10 +187,11 @@ int loc_window_set_jacobian(loc_window* w, int32_t jacobian);
  * whose fill under that order would not fit the storage bw_max sized.  Larger windows (513 ... 1024 poses) always use the
  * caller's order (loc_node_* packs them leaf-first). */
 int loc_window_set_ordering(loc_window* w, int32_t natural);
-/* Large batches of CHAIN windows — every pose-to-pose edge is a range edge between consecutive poses (the smoothness edge of
- * Robot::new_vertex, robot.cpp:75-110), no SE3 edges, range edges listed in the order of their later pose and priors in pose
- * order (the order addRangeEdge / addImuEdge create them in: cfg/uwb_only.yaml, cfg/uwb_imu.yaml) — are solved one GPU lane per
- * window by a block-tridiagonal kernel (same LM, elimination in pose order).  min_batch: the smallest batch that takes that
+/* Large batches of CHAIN windows — every pose-to-pose edge (range or SE3) joins consecutive poses (the smoothness edge of
+ * Robot::new_vertex, robot.cpp:75-110; addTwistEdge's EdgeSE3, localization.cpp:438-459), edges listed in the order of their later
+ * pose and priors in pose order (the order addRangeEdge / addImuEdge / addTwistEdge create them in: cfg/uwb_only.yaml,
+ * cfg/uwb_imu.yaml, cfg/uwb_imu_lidar.yaml, cfg/uwb_twist.yaml) — are solved one GPU lane per window by a block-tridiagonal
+ * kernel (same LM, elimination in pose order).  min_batch: the smallest batch that takes that
  * path (default 12 288, or LOCAMD_CHAIN_MIN_BATCH from the environment; 0: never; < 0: back to the default). */
 int loc_window_set_chain_threshold(loc_window* w, int64_t min_batch);
 /* Device-resident operation: upload n instances once (same host layouts as loc_window_solve_host), then run

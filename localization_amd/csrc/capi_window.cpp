@@ -174,7 +174,7 @@ static int validate_instances(const loc_window* w, int64_t n, const int32_t* cou
     return LOC_OK;
 }
 
-// Large batches of CHAIN windows (every moving-moving edge joins consecutive poses, no SE3 edges; ranges ordered by their
+// Large batches of CHAIN windows (every pose-to-pose edge — range or SE3 — joins consecutive poses; edges ordered by their
 // later pose and priors by pose — the order Localization::addRangeEdge / addImuEdge create them in) run one lane per window
 // (chain_lm_kernel).  Below the threshold a wave per window is faster (the lane-per-window kernel takes about as long for 1 000
 // windows as for 65 536); LOCAMD_CHAIN_MIN_BATCH in the environment moves it (0 = never).
@@ -182,14 +182,20 @@ static long long chain_min_batch() {
     static const long long v = [] { const char* e = getenv("LOCAMD_CHAIN_MIN_BATCH"); return e ? atoll(e) : 12288LL; }();
     return v;
 }
-static bool chain_eligible(const loc_window* w, int64_t n, const int32_t* counts, const int32_t* r_idx, const int32_t* p_idx) {
+static bool chain_eligible(const loc_window* w, int64_t n, const int32_t* counts, const int32_t* r_idx, const int32_t* p_idx, const int32_t* s_idx) {
     const long long mn = w->chain_min >= 0 ? w->chain_min : chain_min_batch();
     if (mn <= 0 || n < mn || w->natural_order) return false;
     const locamd::WindowCaps& c = w->caps;
     for (int64_t i = 0; i < n; ++i) {
         const int32_t* cn = counts + i * 4;
-        if (cn[3] != 0) return false;
         int last = 0;
+        for (int e = 0; e < cn[3]; ++e) {   // EdgeSE3 factors: between consecutive poses, ordered by their later pose (addTwistEdge)
+            const int32_t* ix = s_idx + ((size_t)i * c.ns_max + e) * 4;
+            const int key = ix[1] > ix[0] ? ix[1] : ix[0];
+            if (key < last || (ix[0] - ix[1] != 1 && ix[1] - ix[0] != 1)) return false;
+            last = key;
+        }
+        last = 0;
         for (int e = 0; e < cn[1]; ++e) {
             const int32_t* ix = r_idx + ((size_t)i * c.nr_max + e) * 2;
             const int key = ix[1] > ix[0] ? ix[1] : ix[0];
@@ -271,7 +277,7 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
             a.anchors = w->d_anchors; a.workspace = w->d_workspace;
             a.n_anchors = w->n_anchors; a.B = (int)n; a.iterations = w->iterations; a.caps = c;
             LOC_HIP(hipEventRecord(w->ev0, st));
-            hipError_t e = launch_any(w, a, st, chain_eligible(w, n, counts, r_idx, p_idx));
+            hipError_t e = launch_any(w, a, st, chain_eligible(w, n, counts, r_idx, p_idx, s_idx));
             if (e != hipSuccess) return locamd_fail_hip(e, "launch_window");
             LOC_HIP(hipEventRecord(w->ev1, st));
             LOC_HIP(hipMemcpyAsync(h, d, off[2], hipMemcpyDeviceToHost, st));  // [poses | result]
@@ -303,7 +309,7 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
     a.p_val = w->d_pval; a.s_idx = w->d_sidx; a.s_val = w->d_sval; a.anchors = w->d_anchors; a.result = w->d_result;
     a.workspace = w->d_workspace;
     a.n_anchors = w->n_anchors; a.B = (int)n; a.iterations = w->iterations; a.caps = c;
-    const bool chain = chain_eligible(w, n, counts, r_idx, p_idx);
+    const bool chain = chain_eligible(w, n, counts, r_idx, p_idx, s_idx);
     LOC_HIP(hipEventRecord(w->ev0, st));
     hipError_t e = launch_any(w, a, st, chain);
     if (e != hipSuccess) return locamd_fail_hip(e, "launch_window");
@@ -344,7 +350,7 @@ int loc_window_upload(loc_window* w, int64_t n, const int32_t* counts, const dou
         LOC_HIP(hipMemcpy(w->d_sval, s_val, N * c.ns_max * 48 * sizeof(double), hipMemcpyHostToDevice));
     }
     w->n_resident = n;
-    w->resident_chain = chain_eligible(w, n, counts, r_idx, p_idx);
+    w->resident_chain = chain_eligible(w, n, counts, r_idx, p_idx, s_idx);
     return LOC_OK;
 }
 

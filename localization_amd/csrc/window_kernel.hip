@@ -3050,9 +3050,9 @@ constexpr int HD = 0, HO = 21, HB = 57, G = 63, Y = 84, X = 90, P = 96, PB = 108
 }
 
 // per window: nv_max poses x N doubles, then the edges as [entry][lane] too (range: v0, v1, measurement, information, lever
-// arm = 7 doubles; prior: v + 18 values = 19)
+// arm = 7 doubles; prior: v + 18 values = 19; SE3: vi, vj, robust + 48 values = 51)
 __host__ __device__ inline size_t chain_window_doubles(const WindowCaps& c) {
-    return (size_t)c.nv_max * chainw::N + (size_t)c.nr_max * 7 + (size_t)c.np_max * 19;
+    return (size_t)c.nv_max * chainw::N + (size_t)c.nr_max * 7 + (size_t)c.np_max * 19 + (size_t)c.ns_max * 51;
 }
 size_t window_chain_workspace_doubles(const WindowCaps& c, long long B) {
     return (size_t)((B + 63) / 64) * 64 * chain_window_doubles(c);
@@ -3060,18 +3060,162 @@ size_t window_chain_workspace_doubles(const WindowCaps& c, long long B) {
 
 namespace {
 
+// One EdgeSE3 between the consecutive poses i and j of a chain window: the math of evaluate_edges' SE3 branch, with the record in
+// registers.  Returns chi; rterm = the edge's robust cost; FULL: H_ii, H_jj (lower triangles, 21), the off-diagonal block with the
+// rows of the LATER pose (36, column-major), b_i, b_j.
+template <bool FULL>
+__device__ __forceinline__ double chain_se3_terms(const double* Xi, const double* Xj, const double* val, bool robust, bool j_is_later,
+                                                  double* Hii, double* Hjj, double* Hoff, double* bi_, double* bj_, double& rterm) {
+    double RB[9], tB[3], dt[3] = {Xj[9] - Xi[9], Xj[10] - Xi[10], Xj[11] - Xi[11]};
+    mat_tmul(Xi, Xj, RB);
+    mat_tvec(Xi, dt, tB);
+    double RE[9], tE[3];
+    mat_mul(val, RB, RE);
+    mat_vec(val, tB, tE);
+    tE[0] += val[9]; tE[1] += val[10]; tE[2] += val[11];
+    double qE[4];
+    mat_to_quat(RE, qE);
+    quat_normalize_sign(qE);
+    const double err[6] = {tE[0], tE[1], tE[2], qE[1], qE[2], qE[3]};
+    const double* Om = val + 12;
+    double Oe[6];
+    double chi = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double r = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) r += Om[i * 6 + j] * err[j];
+        Oe[i] = r;
+        chi += err[i] * r;
+    }
+    const double aux = 1.0 + chi;
+    rterm = robust ? fast_log_ge1(aux) : chi;
+    if (FULL) {
+        const double w = robust ? 1.0 / aux : 1.0;
+        double J0[36], J1[36];
+#pragma unroll
+        for (int i = 0; i < 36; ++i) { J0[i] = 0.0; J1[i] = 0.0; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) J1[i * 6 + j] = RE[i * 3 + j];
+        quat_right_jac(qE, 1.0, J1, 6);
+        const double S[9] = {0, -tB[2], tB[1], tB[2], 0, -tB[0], -tB[1], tB[0], 0};
+        double RAS[9];
+        mat_mul(val, S, RAS);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { J0[i * 6 + j] = -val[i * 3 + j]; J0[i * 6 + 3 + j] = 2.0 * RAS[i * 3 + j]; }
+        double qA[4], qB[4], qAB[4];
+        mat_to_quat(val, qA);
+        mat_to_quat(RB, qB);
+        quat_mul(qA, qB, qAB);
+        const double sg = qAB[0] < 0 ? -1.0 : 1.0;
+        const double nrm = 1.0 / sqrt(qAB[0] * qAB[0] + qAB[1] * qAB[1] + qAB[2] * qAB[2] + qAB[3] * qAB[3]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            double ek[4] = {0, 0, 0, 0}, r1[4], r2[4];
+            ek[1 + k] = 1.0;
+            quat_mul(qA, ek, r1);
+            quat_mul(r1, qB, r2);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) J0[(3 + i) * 6 + 3 + k] = -sg * nrm * r2[1 + i];
+        }
+#define LOCAMD_J1_LO(c) ((c) < 3 ? 0 : 3)
+#define LOCAMD_J1_HI(c) ((c) < 3 ? 3 : 6)
+#define LOCAMD_J0_HI(c) ((c) < 3 ? 3 : 6)
+        double WJ[36];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc) {
+                double s0 = 0.0;
+#pragma unroll
+                for (int j = 0; j < LOCAMD_J0_HI(cc); ++j) s0 += Om[i * 6 + j] * J0[j * 6 + cc];
+                WJ[i * 6 + cc] = w * s0;
+            }
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int cc = 0; cc <= r; ++cc) {
+                double h = 0.0;
+#pragma unroll
+                for (int i = 0; i < LOCAMD_J0_HI(r); ++i) h += J0[i * 6 + r] * WJ[i * 6 + cc];
+                Hii[r * (r + 1) / 2 + cc] = h;
+            }
+        if (j_is_later) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 6; ++cc) {
+                    double h = 0.0;
+#pragma unroll
+                    for (int i = LOCAMD_J1_LO(r); i < LOCAMD_J1_HI(r); ++i) h += J1[i * 6 + r] * WJ[i * 6 + cc];
+                    Hoff[6 * cc + r] = h;
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc) {
+                double s1 = 0.0;
+#pragma unroll
+                for (int j = LOCAMD_J1_LO(cc); j < LOCAMD_J1_HI(cc); ++j) s1 += Om[i * 6 + j] * J1[j * 6 + cc];
+                WJ[i * 6 + cc] = w * s1;
+            }
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int cc = 0; cc <= r; ++cc) {
+                double h = 0.0;
+#pragma unroll
+                for (int i = LOCAMD_J1_LO(r); i < LOCAMD_J1_HI(r); ++i) h += J1[i * 6 + r] * WJ[i * 6 + cc];
+                Hjj[r * (r + 1) / 2 + cc] = h;
+            }
+        if (!j_is_later) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 6; ++cc) {
+                    double h = 0.0;
+#pragma unroll
+                    for (int i = 0; i < LOCAMD_J0_HI(r); ++i) h += J0[i * 6 + r] * WJ[i * 6 + cc];
+                    Hoff[6 * cc + r] = h;
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            double bi = 0.0, bj = 0.0;
+#pragma unroll
+            for (int i = 0; i < LOCAMD_J0_HI(r); ++i) bi += J0[i * 6 + r] * (-w * Oe[i]);
+#pragma unroll
+            for (int i = LOCAMD_J1_LO(r); i < LOCAMD_J1_HI(r); ++i) bj += J1[i * 6 + r] * (-w * Oe[i]);
+            bi_[r] = bi;
+            bj_[r] = bj;
+        }
+#undef LOCAMD_J1_LO
+#undef LOCAMD_J1_HI
+#undef LOCAMD_J0_HI
+    }
+    return chi;
+}
+
 // one sweep over the window's edges in pose order: chi sums always; FULL: H and b as well (returns the largest diagonal entry)
-template <bool FULL, int JAC>
-__device__ __forceinline__ void chain_sweep(const WindowArgs& a, double* slab, long long inst, int nv, int nr, int np, int buf,
+template <bool FULL, int JAC, bool SE3>
+__device__ __forceinline__ void chain_sweep(const WindowArgs& a, double* slab, long long inst, int nv, int nr, int np, int ns, int buf,
                                             double& robust_chi, double& plain_chi, double& max_diag, unsigned long long& ho_kind) {
     using namespace chainw;
 #define CH(p, f, k) slab[((size_t)(p) * N + (f) + (k)) * 64]
     const WindowCaps& c = a.caps;
     (void)inst;
     // the window's edges, copied into the workspace once per launch ([entry][lane]: one line per load of the wave)
-    const size_t eoff = (size_t)c.nv_max * N, poff = eoff + (size_t)c.nr_max * 7;
+    const size_t eoff = (size_t)c.nv_max * N, poff = eoff + (size_t)c.nr_max * 7, soff = poff + (size_t)c.np_max * 19;
 #define CE(e, k) slab[(eoff + (size_t)(e) * 7 + (k)) * 64]
 #define CP(e, k) slab[(poff + (size_t)(e) * 19 + (k)) * 64]
+#define CS(e, k) slab[(soff + (size_t)(e) * 51 + (k)) * 64]
+    (void)soff; (void)ns;
+    int es = 0;   // (SE3 edges between consecutive poses — the reference's addTwistEdge —, sorted by their later pose like the ranges)
     double rsum = 0.0, csum = 0.0, md = 0.0;
     double Dp[27], Dc[27], O[36], Xp[12], Xc[12];
 #pragma unroll
@@ -3215,6 +3359,44 @@ __device__ __forceinline__ void chain_sweep(const WindowArgs& a, double* slab, l
             }
             ++e;
         }
+        if (SE3) {
+            while (es < ns) {
+                const int vi = (int)CS(es, 0), vj = (int)CS(es, 1);
+                if ((vj > vi ? vj : vi) != p) break;
+                const bool robust = CS(es, 2) != 0.0, i_is_cur = vi == p;
+                double val[48], Xi[12], Xj[12];
+#pragma unroll
+                for (int k = 0; k < 48; ++k) val[k] = CS(es, 3 + k);
+#pragma unroll
+                for (int k = 0; k < 12; ++k) { Xi[k] = i_is_cur ? Xc[k] : Xp[k]; Xj[k] = i_is_cur ? Xp[k] : Xc[k]; }
+                double Hii[21], Hjj[21], Hoff[36], bi[6], bj[6], rterm;
+                const double chi = chain_se3_terms<FULL>(Xi, Xj, val, robust, !i_is_cur, Hii, Hjj, Hoff, bi, bj, rterm);
+                rsum += rterm;
+                csum += chi;
+                if (FULL) {
+#pragma unroll
+                    for (int k = 0; k < 21; ++k) {
+                        Dc[k] += i_is_cur ? Hii[k] : Hjj[k];
+                        Dp[k] += i_is_cur ? Hjj[k] : Hii[k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        Dc[21 + k] += i_is_cur ? bi[k] : bj[k];
+                        Dp[21 + k] += i_is_cur ? bj[k] : bi[k];
+                    }
+                    if (nbin == 1 && p < 32) {   // a range edge on the pair is waiting as two vectors: expand it
+#pragma unroll
+                        for (int r = 0; r < 6; ++r)
+#pragma unroll
+                            for (int cc = 0; cc < 6; ++cc) O[6 * cc + r] = fu[r] * fv[cc];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 36; ++k) O[k] += Hoff[k];
+                    nbin += 2;   // (an SE3 coupling is never rank-1: the block is stored in full)
+                }
+                ++es;
+            }
+        }
         // unary priors on pose p
         while (q < np && (int)npv == p) {
             double Zi[12], Wd[6];
@@ -3299,6 +3481,7 @@ __device__ __forceinline__ void chain_sweep(const WindowArgs& a, double* slab, l
     if (FULL) ho_kind = kinds;
 #undef CE
 #undef CP
+#undef CS
 }
 
 // pose p of the trial state: X (+) dx, read from pose buffer `buf`, written to the other one (accepting a step flips the
@@ -3534,7 +3717,7 @@ __device__ __forceinline__ bool chain_factor_solve(double* slab, int nv, double 
     return true;
 }
 
-template <int JAC>
+template <int JAC, bool SE3>
 __global__ void __launch_bounds__(64, 1) chain_lm_kernel(const WindowArgs a, double* ws) {
     using namespace chainw;
     const int lane = threadIdx.x;
@@ -3542,8 +3725,8 @@ __global__ void __launch_bounds__(64, 1) chain_lm_kernel(const WindowArgs a, dou
     const bool live = inst < a.B;
     const WindowCaps& c = a.caps;
     double* slab = ws + (size_t)blockIdx.x * 64 * chain_window_doubles(c) + lane;
-    int nv = 0, nr = 0, np = 0;
-    if (live) { nv = a.counts[inst * 4 + 0]; nr = a.counts[inst * 4 + 1]; np = a.counts[inst * 4 + 2]; }
+    int nv = 0, nr = 0, np = 0, ns = 0;
+    if (live) { nv = a.counts[inst * 4 + 0]; nr = a.counts[inst * 4 + 1]; np = a.counts[inst * 4 + 2]; ns = SE3 ? a.counts[inst * 4 + 3] : 0; }
     const double* gin = a.poses_in + (size_t)(live ? inst : 0) * c.nv_max * 12;
     double* gout = a.poses + (size_t)(live ? inst : 0) * c.nv_max * 12;
     for (int p = 0; p < nv; ++p) {
@@ -3569,6 +3752,16 @@ __global__ void __launch_bounds__(64, 1) chain_lm_kernel(const WindowArgs a, dou
 #pragma unroll
             for (int k = 0; k < 18; ++k) slab[(poff + (size_t)e * 19 + 1 + k) * 64] = pval[18 * e + k];
         }
+        if (SE3) {
+            const size_t soff = poff + (size_t)c.np_max * 19;
+            const int32_t* sidx = a.s_idx + (size_t)(live ? inst : 0) * c.ns_max * 4;
+            const double* sval = a.s_val + (size_t)(live ? inst : 0) * c.ns_max * 48;
+            for (int e = 0; e < ns; ++e) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) slab[(soff + (size_t)e * 51 + k) * 64] = (double)sidx[4 * e + k];
+                for (int k = 0; k < 48; ++k) slab[(soff + (size_t)e * 51 + 3 + k) * 64] = sval[48 * e + k];
+            }
+        }
     }
     constexpr double tau = 1e-5, good_lo = 1.0 / 3.0, good_hi = 2.0 / 3.0;
     constexpr int max_trials = 10;
@@ -3576,12 +3769,12 @@ __global__ void __launch_bounds__(64, 1) chain_lm_kernel(const WindowArgs a, dou
     int it = 0, q = 0, trials = 0, terminated = 0, buf = 0;
     unsigned long long ho_kind = 0;
     bool need_lin = true;
-    bool done = !live || nv <= 0 || nr + np <= 0 || a.iterations <= 0;
+    bool done = !live || nv <= 0 || nr + np + ns <= 0 || a.iterations <= 0;
     while (__ballot(!done)) {
         if (!done) {
             if (need_lin) {
                 double plain, md;
-                chain_sweep<true, JAC>(a, slab, inst, nv, nr, np, buf, cur_chi, plain, md, ho_kind);
+                chain_sweep<true, JAC, SE3>(a, slab, inst, nv, nr, np, ns, buf, cur_chi, plain, md, ho_kind);
                 last_plain = plain;
                 if (it == 0) { lambda = tau * md; ni = 2.0; }
                 q = 0;
@@ -3593,7 +3786,7 @@ __global__ void __launch_bounds__(64, 1) chain_lm_kernel(const WindowArgs a, dou
             ++trials;
             double temp_chi, plain2, md2;
             unsigned long long unused_kind;
-            chain_sweep<false, JAC>(a, slab, inst, nv, nr, np, 1 - buf, temp_chi, plain2, md2, unused_kind);
+            chain_sweep<false, JAC, SE3>(a, slab, inst, nv, nr, np, ns, 1 - buf, temp_chi, plain2, md2, unused_kind);
             last_plain = plain2;
             if (!ok2) temp_chi = DBL_MAX;
             const double scale = sc + 1e-3;
@@ -3640,8 +3833,15 @@ __global__ void __launch_bounds__(64, 1) chain_lm_kernel(const WindowArgs a, dou
 hipError_t launch_window_chain(const WindowArgs& a, double* chain_ws, hipStream_t stream) {
     if (a.B <= 0 || !chain_ws) return hipErrorInvalidValue;
     const unsigned blocks = (unsigned)((a.B + 63) / 64);
-    if (a.jacobian) hipLaunchKernelGGL((chain_lm_kernel<1>), dim3(blocks), dim3(64), 0, stream, a, chain_ws);
-    else hipLaunchKernelGGL((chain_lm_kernel<0>), dim3(blocks), dim3(64), 0, stream, a, chain_ws);
+    // (the variant with EdgeSE3 factors between consecutive poses is a separate instantiation: the range-only windows keep their
+    //  register budget)
+    if (a.caps.ns_max > 0) {
+        if (a.jacobian) hipLaunchKernelGGL((chain_lm_kernel<1, true>), dim3(blocks), dim3(64), 0, stream, a, chain_ws);
+        else hipLaunchKernelGGL((chain_lm_kernel<0, true>), dim3(blocks), dim3(64), 0, stream, a, chain_ws);
+    } else {
+        if (a.jacobian) hipLaunchKernelGGL((chain_lm_kernel<1, false>), dim3(blocks), dim3(64), 0, stream, a, chain_ws);
+        else hipLaunchKernelGGL((chain_lm_kernel<0, false>), dim3(blocks), dim3(64), 0, stream, a, chain_ws);
+    }
     return hipGetLastError();
 }
 

@@ -438,15 +438,17 @@ def test_wide_windows_ragged_batch(gpu, jac):
         assert abs(res[i, 0] - chi) <= (1e-6 if jac == "analytic" else 1e-4) * max(1.0, abs(chi)), (i, res[i, 0], chi)
 
 
-@pytest.mark.parametrize("T,with_imu,lever,jac", [
-    (10, False, False, "analytic"),   # cfg/uwb_only.yaml's window
-    (12, True, True, "analytic"),     # cfg/uwb_imu.yaml's window: IMU priors, lever arm
-    (10, False, False, "numeric"),    # the reference's Jacobian mode
-    (1, True, True, "analytic"),      # a lone pose
-    (16, True, True, "numeric"),
-    (40, False, True, "analytic"),    # beyond 32 poses the coupling blocks are always stored in full
+@pytest.mark.parametrize("T,with_imu,lever,jac,twist", [
+    (10, False, False, "analytic", False),   # cfg/uwb_only.yaml's window
+    (12, True, True, "analytic", False),     # cfg/uwb_imu.yaml's window: IMU priors, lever arm
+    (10, False, False, "numeric", False),    # the reference's Jacobian mode
+    (1, True, True, "analytic", False),      # a lone pose
+    (16, True, True, "numeric", False),
+    (40, False, True, "analytic", False),    # beyond 32 poses the coupling blocks are always stored in full
+    (10, False, True, "analytic", True),     # cfg/uwb_twist.yaml's window: an EdgeSE3 between consecutive poses (addTwistEdge)
+    (12, True, True, "numeric", True),
 ])
-def test_chain_kernel_matches_oracle(gpu, T, with_imu, lever, jac):
+def test_chain_kernel_matches_oracle(gpu, T, with_imu, lever, jac, twist):
     """Large batches of chain windows run one lane per window (chain_lm_kernel: block-tridiagonal Cholesky in pose order,
     the state in an [entry][lane] HBM workspace).  Forced here for a small batch through loc_window_set_chain_threshold:
     against the oracle, against the wave-per-window kernel on the same batch, and through the resident API."""
@@ -455,11 +457,19 @@ def test_chain_kernel_matches_oracle(gpu, T, with_imu, lever, jac):
     from _oracle_window import oracle_solve_instance
     B = 70   # (one full wave of windows + a partial one)
     rng = np.random.default_rng(100 * T + len(jac))
-    nr_max, np_max = max(2 * T + 2, 4), (T if with_imu else 0)
-    wb = la.WindowBatch(B, T, nr_max, np_max, 0)
+    nr_max, np_max, ns_max = max(2 * T + 2, 4), (T if with_imu else 0), (T if twist else 0)
+    wb = la.WindowBatch(B, T, nr_max, np_max, ns_max)
     for i in range(B):
         Ti = T if i % 7 else max(T // 2, 1)   # ragged lengths inside the wave
         est_t, est_R, off, ranges, smooth, priors, _ = _random_window(rng, Ti, with_imu, False, lever)
+        if twist:   # odometry-like relative poses between consecutive poses, every other one stored the other way round
+            for k in range(1, Ti):
+                a, b = (k - 1, k) if k % 2 else (k, k - 1)
+                Ra, Rb = Rotation.from_matrix(est_R[a]), Rotation.from_matrix(est_R[b])
+                Zt = Ra.inv().apply(est_t[b] - est_t[a]) + rng.normal(0, 0.01, 3)
+                ZR = (Ra.inv() * Rb * Rotation.from_rotvec(rng.normal(0, 0.01, 3))).as_matrix()
+                A = rng.normal(size=(6, 6)); info = A @ A.T + 6 * np.eye(6); info *= 1e3 / np.trace(info)
+                wb.add_se3(i, a, b, Zt, ZR, info, bool(k % 3))
         for k in range(Ti):
             wb.add_pose(i, est_t[k], est_R[k])
         # (the reference's creation order: a pose's anchor range, then its smoothness edge to the previous pose)
@@ -475,13 +485,13 @@ def test_chain_kernel_matches_oracle(gpu, T, with_imu, lever, jac):
     before = wb.poses.copy()
     mode = O.JAC_ANALYTIC if jac == "analytic" else O.JAC_NUMERIC_G2O
     want = [oracle_solve_instance(wb, i, ANCH, jac_mode=mode) for i in range(B)]
-    ref = la.WindowBatch(B, T, nr_max, np_max, 0)
-    for name in ("counts", "poses", "r_idx", "r_val", "p_idx", "p_val"):
+    ref = la.WindowBatch(B, T, nr_max, np_max, ns_max)
+    for name in ("counts", "poses", "r_idx", "r_val", "p_idx", "p_val", "s_idx", "s_val"):
         getattr(ref, name)[:] = getattr(wb, name)
-    general = la.WindowSolver(ANCH, B, T, nr_max, np_max, 0, jacobian=jac, chain_threshold=0)
+    general = la.WindowSolver(ANCH, B, T, nr_max, np_max, ns_max, jacobian=jac, chain_threshold=0)
     res_general = general.solve(ref).copy()
     general.close()
-    chain = la.WindowSolver(ANCH, B, T, nr_max, np_max, 0, jacobian=jac, chain_threshold=1)
+    chain = la.WindowSolver(ANCH, B, T, nr_max, np_max, ns_max, jacobian=jac, chain_threshold=1)
     res = chain.solve(wb).copy()
     assert (res[res[:, 3] > 0, 7] % 65536 == 2 * (res[res[:, 3] > 0, 7] // 65536) - 1).all()   # (the chain kernel's signature: n levels, 2 n - 1 blocks)
     # (numeric vs numeric: the central differences of the near-zero ranges between consecutive poses — some of them doubled here —
@@ -489,7 +499,7 @@ def test_chain_kernel_matches_oracle(gpu, T, with_imu, lever, jac):
     tol = 1e-7 if jac == "analytic" else 3e-5
     for i in range(B):
         nv = int(wb.counts[i, 0])
-        if nv == 0 or wb.counts[i, 1] + wb.counts[i, 2] == 0:
+        if nv == 0 or wb.counts[i, 1] + wb.counts[i, 2] + wb.counts[i, 3] == 0:
             assert np.array_equal(wb.poses[i], before[i]) and res[i, 4] == 0
             continue
         poses, chi, st = want[i]
@@ -500,8 +510,8 @@ def test_chain_kernel_matches_oracle(gpu, T, with_imu, lever, jac):
     if T > 1:   # (a lone well-observed pose converges early: the remaining decisions are taken on rounding-level chi differences)
         assert (res[:, 4] != res_general[:, 4]).mean() < 0.05   # LM trial counts
     # resident API: the same answer again
-    wb2 = la.WindowBatch(B, T, nr_max, np_max, 0)
-    for name in ("counts", "r_idx", "r_val", "p_idx", "p_val"):
+    wb2 = la.WindowBatch(B, T, nr_max, np_max, ns_max)
+    for name in ("counts", "r_idx", "r_val", "p_idx", "p_val", "s_idx", "s_val"):
         getattr(wb2, name)[:] = getattr(wb, name)
     wb2.poses[:] = before
     chain.upload(wb2)
