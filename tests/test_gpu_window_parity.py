@@ -559,3 +559,33 @@ def test_skyline_window_matches_chain_kernel_600_poses(gpu):
     assert np.array_equal(res_sky[:, 3:6], res_chain[:, 3:6])                                # iterations, trials, terminated
     assert np.abs(res_sky[:, 0] - res_chain[:, 0]).max() <= 1e-6 * np.abs(res_sky[:, 0]).max()
     assert (res_sky[:, 1] < 0.5 * 1e9).all() and (res_sky[:, 4] >= 10).all()
+
+
+def test_chain_kernel_failed_cholesky_like_g2o(gpu):
+    """The lane-per-window kernel on a window whose every range has zero information (H = 0, lambda_0 = 0: the factorisation fails
+    in every trial): 10 trials, 1 outer iteration, terminated, poses untouched — next to healthy windows in the same wave."""
+    import localization_amd as la
+    from _oracle_window import oracle_solve_instance
+    T, B = 6, 5
+    rng = np.random.default_rng(66)
+    wb = la.WindowBatch(B, T, 2 * T, 0, 0)
+    for i in range(B):
+        est_t, est_R, off, ranges, smooth, _, _ = _random_window(rng, T, False, False, False)
+        for k in range(T):
+            wb.add_pose(i, est_t[k], est_R[k])
+        for k in range(T):
+            for (kk, a, d, info) in ranges:
+                if kk == k: wb.add_range(i, k, a, d, 0.0 if i == 2 else info, off, anchor=True)
+            if i != 2:
+                for (k0, k1, d, info) in smooth:
+                    if k1 == k: wb.add_range(i, k0, k1, d, info)
+    before = wb.poses.copy()
+    want = [oracle_solve_instance(wb, i, ANCH) for i in range(B)]
+    s = la.WindowSolver(ANCH, B, T, 2 * T, 0, 0, chain_threshold=1)
+    res = s.solve(wb).copy()
+    s.close()
+    assert (res[[0, 1, 3, 4], 7] == T * 65536 + 2 * T - 1).all()
+    assert res[2, 5] == 1 and res[2, 4] == 10 and res[2, 3] == 1 and np.array_equal(wb.poses[2], before[2])
+    assert want[2][2].terminated == 1 and want[2][2].lm_trials == 10
+    for i in (0, 1, 3, 4):
+        assert np.abs(wb.poses[i] - want[i][0]).max() < 1e-7
