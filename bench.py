@@ -122,6 +122,25 @@ def cpu_baseline_all_cores(anchors, dist_tiles, err_tiles, init, tags_per_core, 
                       f"over {used} single-threaded worker processes, same oracle and settings as cpu_baseline"}
 
 
+def spawn_ranks(n, argv):
+    """One child process per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (what torch.distributed.run would set);
+    rank 0's stdout is this process's stdout.  Returns non-zero unless every rank exits 0."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        print(f"[bench] ranks exited with {rcs}: the {n}-GPU run FAILED", file=sys.stderr)
+        return 1
+    return 0
+
+
 class Dist:
     """The rank plumbing every leg shares: barrier + synchronize on both sides of a timed region, max over ranks."""
 
@@ -133,8 +152,12 @@ class Dist:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.backend = args.dist_backend
         n_dev = torch.cuda.device_count()
+        if args.gpus != self.world:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}: refusing to report a different job than the one asked for")
         if self.backend == "gloo":
             self.local_rank = self.local_rank % max(n_dev, 1)  # rehearsal: ranks may share a device
+        elif self.local_rank >= n_dev:
+            raise SystemExit(f"bench.py: rank {self.rank} needs GPU {self.local_rank} but only {n_dev} device(s) are visible")
         if self.world > 1:
             import torch.distributed as dist
             torch.cuda.set_device(self.local_rank)
@@ -144,6 +167,17 @@ class Dist:
                 dist.init_process_group("gloo")
         self.dev = torch.device("cuda", self.local_rank)
         torch.cuda.set_device(self.dev)
+
+    def ranks_and_devices(self):
+        """(ranks that joined, the HIP device each one runs on): an all-gather over the job's own process group."""
+        if self.world == 1:
+            return 1, [int(self.local_rank)]
+        import torch.distributed as dist
+        t = self.torch.zeros(self.world, dtype=self.torch.int64, device=self.dev if self.backend == "nccl" else "cpu")
+        t[self.rank] = self.local_rank + 1
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        devs = [int(x) - 1 for x in t.tolist()]
+        return sum(1 for d in devs if d >= 0), devs
 
     def barrier(self):
         if self.world > 1:
@@ -246,14 +280,14 @@ def leg_cfg3(D, args):
         kms.append(f.last_kernel_ms())
 
     elapsed = D.timed(step, warmup, steps)
-    kern_ms = float(np.mean(kms[warmup:]))
+    kern_ms = D.max_over_ranks(float(np.mean(kms[warmup:])))   # the slowest rank's kernel time: comparable with the wall-time legs
     upd = float(B) * E
     res = {"workload": "BASELINE cfg3: 8 anchors + IMU rotation prior + antenna lever arm, 6-DoF, g2o-style LM, 10 iterations",
            "metric": "localization updates/sec", "value": upd * D.world / (kern_ms * 1e-3), "unit": "updates/s", "steps": steps,
            "ms_per_step": elapsed / steps * 1e3, "value_note": "updates / kernel time (HIP events on the launch stream): the step also "
            "re-uploads the initial poses, which is not part of the hot path", "scaling": "weak", "dtype": "f64", "batch_per_gpu": B,
            "epochs_per_step": E,
-           "roofline": hbm_roofline("fusion_lm_kernel", ALGO_BYTES_CFG3 * upd, kern_ms, steps, "248 B/update; VALU-issue bound")}
+           "roofline": hbm_roofline("fusion_lm_kernel", ALGO_BYTES_CFG3 * upd, kern_ms, len(kms) - warmup, "248 B/update; VALU-issue bound")}
     if D.rank == 0 and D.world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
         nt, ne = 512, 32
@@ -414,6 +448,11 @@ def main():
     ap.add_argument("--legs", default="all", help="secondary legs: all, none, or a comma list of cfg2_numeric,cfg3,cfg5,cfg4,cfg1_windows")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Launched bare (`python bench.py --gpus N`): start the N ranks ourselves.  This happens BEFORE anything touches the
+        # GPU in this process (no torch import yet); the children are ordinary subprocesses, never an exec of this one.
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
     import numpy as np
     import torch
     import localization_amd as la
@@ -424,8 +463,9 @@ def main():
     D = Dist(args)
     world, rank, dev = D.world, D.rank, D.dev
     n_gpus = world
-    if args.gpus != n_gpus and rank == 0:
-        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    ranks_joined, rank_devices = D.ranks_and_devices()
+    if ranks_joined != args.gpus:
+        raise SystemExit(f"bench.py: {ranks_joined} of {args.gpus} ranks joined")
 
     B, E, M = args.batch, args.epochs, 8
     total_steps = args.warmup + args.steps
@@ -491,7 +531,7 @@ def main():
             "metric": "localization updates/sec (8-anchor UWB, batch=65k)",
             "value": value, "unit": "updates/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic", "ranks_joined": ranks_joined, "rank_devices": rank_devices,
             "config": {"workload": "BASELINE cfg2: synthetic 8-anchor UWB, 3-DoF position, Cauchy range factors, "
                                    "g2o-style LM with the reference's fixed 10 iterations, outlier gate 1 m",
                        "batch_per_gpu": B, "epochs_per_step": E, "updates_per_step_per_gpu": int(updates_per_launch),

@@ -23,7 +23,8 @@
 extern "C" {
 #endif
 
-#define LOC_ABI_VERSION 2 /* 2: jacobian mode for every solver, resident window solves, loc_node_add_rl_range */
+#define LOC_ABI_VERSION 3 /* 2: jacobian mode for every solver, resident window solves, loc_node_add_rl_range;
+                           * 3: numeric (g2o) Jacobians are the default everywhere, loc_shard_*, loc_window_last_kernel_kind */
 
 typedef enum loc_status {
     LOC_OK = 0,
@@ -43,6 +44,25 @@ enum { LOC_JAC_ANALYTIC = 0, LOC_JAC_NUMERIC_G2O = 1 };
 const char* loc_last_error(void);  /* thread-local message of the last failing call */
 int32_t loc_abi_version(void);
 int32_t loc_device_count(void);    /* 0 when no HIP device is visible */
+
+/* ================================================================================================
+ * Multi-GPU shard descriptor (SURVEY.md §8(b) "device selection + stream; multi-GPU shard descriptor", §8(e)).
+ * Tags / windows / hypotheses are independent least-squares problems (one Localization object each in the reference:
+ * localization_node.cpp:46), so a batch of `total` instances is split into contiguous slices of ceil(total / world)
+ * instances, one per rank = one process = one GPU; anchors and parameters are replicated; there is NO collective on
+ * the solve path.  Host-only helpers (no device needed): a C++ caller computes its slice with the same rule the Python
+ * harness and bench.py use.
+ * ============================================================================================== */
+typedef struct loc_shard {
+    int32_t rank, world;   /* this slice belongs to rank `rank` of `world` */
+    int32_t device;        /* HIP device index on the rank's node: rank % devices_per_node */
+    int32_t reserved;
+    int64_t lo, hi;        /* instances [lo, hi) of the batch; hi - lo may be 0 for trailing ranks */
+} loc_shard;
+/* [lo, hi) of rank `rank`; LOC_ERR_INVALID unless total >= 0 and 0 <= rank < world */
+int loc_shard_bounds(int64_t total, int32_t rank, int32_t world, int64_t* lo, int64_t* hi);
+/* fills out[0 .. world-1]; devices_per_node <= 0: loc_device_count() (LOC_ERR_NO_DEVICE when that is 0) */
+int loc_shard_plan(int64_t total, int32_t world, int32_t devices_per_node, loc_shard* out);
 
 /* ================================================================================================
  * Batched snapshot solver — BASELINE config 2 (8-anchor UWB, B independent tags, 3-DoF position).
@@ -68,7 +88,7 @@ typedef struct loc_snapshot_params {
     double distance_outlier;     /* robot/distance_outlier, localization.cpp:78; <= 0 disables the gate */
     int32_t gate_warmup_epochs;  /* epochs after (re)initialisation that run un-gated: the reference gates only once
                                     number_measurements > trajectory_length (localization.cpp:309). default 1 */
-    int32_t jacobian;            /* LOC_JAC_* */
+    int32_t jacobian;            /* LOC_JAC_*; loc_snapshot_default_params: LOC_JAC_NUMERIC_G2O (the reference's configuration) */
     int32_t lanes_per_instance;  /* 0 = library default; otherwise 1,2,4,8 (must divide the padded anchor count) */
     int32_t block_threads;       /* 0 = default (256) */
 } loc_snapshot_params;
@@ -135,8 +155,8 @@ int loc_snapshot_timing_end(loc_snapshot* s, int32_t* n_launches, double* total_
  * with an antenna lever arm on endpoint 0 (localization.cpp:331-340, types_edge_se3range.cpp:105-114),
  * EdgeSE3Prior with diagonal information (IMU / lidar, localization.cpp:476-486, 513-525) and EdgeSE3
  * (pose / twist, localization.cpp:263-281, 588-602).  Range and SE3 edges carry RobustKernelCauchy(1) as in the
- * reference (range always; SE3 per the `robust` flag); priors do not.  Range Jacobians: analytic by default, g2o's
- * central differences (the reference's configuration, types_edge_se3range.h:45-74) with loc_window_set_jacobian.
+ * reference (range always; SE3 per the `robust` flag); priors do not.  Range Jacobians: g2o's central differences by default
+ * (the reference's configuration, types_edge_se3range.h:45-74); analytic ones with loc_window_set_jacobian.
  *
  * Host layouts (arrays of B instances, fixed capacities per instance):
  *   counts int32 [B][4]           nv, nr, np, ns  (poses, range edges, priors, SE3 edges actually used)
@@ -179,7 +199,8 @@ int loc_window_solve_host(loc_window* w, int64_t n_instances, const int32_t* cou
                           const int32_t* s_idx, const double* s_val, double* result);
 /* kernel time of the last loc_window_solve_host launch (HIP events on its stream), milliseconds */
 int loc_window_last_kernel_ms(loc_window* w, double* ms);
-/* LOC_JAC_ANALYTIC (default) or LOC_JAC_NUMERIC_G2O for the EdgeSE3Range factors of every later solve */
+/* LOC_JAC_NUMERIC_G2O (default: the reference's configuration) or LOC_JAC_ANALYTIC (opt-in fast mode) for the EdgeSE3Range
+ * factors of every later solve */
 int loc_window_set_jacobian(loc_window* w, int32_t jacobian);
 /* Windows of up to 512 poses are eliminated in a minimum-degree order the kernel computes per instance (what CHOLMOD's AMD
  * ordering does for the reference, localization.h:82-84: a key-frame star then factors without fill, a chain with a dense
@@ -194,6 +215,17 @@ int loc_window_set_ordering(loc_window* w, int32_t natural);
  * kernel (same LM, elimination in pose order).  min_batch: the smallest batch that takes that
  * path (default 12 288, or LOCAMD_CHAIN_MIN_BATCH from the environment; 0: never; < 0: back to the default). */
 int loc_window_set_chain_threshold(loc_window* w, int64_t min_batch);
+/* Which kernel the last solve of this handle ran (the choice depends on the batch: its size and structure).
+ *   GENERAL  window_lm_kernel: one wave (65 ... 512 poses: eight waves) per window, sparse block Cholesky in a minimum-degree order
+ *   CHAIN    chain_lm_kernel: one lane per window, block-tridiagonal 6x6 (batches >= the chain threshold of chain windows)
+ *   CHAIN3   chain3_lm_kernel: the same for TRANSLATION-ONLY batches — no EdgeSE3, every lever arm zero, every rotation the
+ *            identity (what Robot::init, robot.cpp:47, and the default identity antenna offsets, localization.h:170, give:
+ *            cfg/uwb_only.yaml on the example bag), priors without rotation information: the 6-DoF problem then reduces EXACTLY
+ *            to 3x3 blocks (types_edge_se3range.cpp:105-114 does not see the rotation; SURVEY.md §8(a) note)
+ * All three run the same LM and agree to the tolerances of DESIGN.md §3; result[6] / result[7] keep their meaning (the
+ * lane-per-window kernels eliminate in pose order: result[7] = nv * 65536 + 2 nv - 1). */
+enum { LOC_WINDOW_KERNEL_NONE = -1, LOC_WINDOW_KERNEL_GENERAL = 0, LOC_WINDOW_KERNEL_CHAIN = 1, LOC_WINDOW_KERNEL_CHAIN3 = 2 };
+int loc_window_last_kernel_kind(const loc_window* w, int32_t* kind);
 /* Device-resident operation: upload n instances once (same host layouts as loc_window_solve_host), then run
  * loc_window_solve_resident any number of times — each launch starts from the uploaded estimates, is asynchronous on
  * hip_stream (NULL = the handle's own stream) and leaves poses / result on the device — and fetch them with
@@ -236,8 +268,8 @@ typedef struct loc_node_config {
     double minimum_optimize_error;    /* optimizer/minimum_optimize_error (1000)  :68 */
     int32_t publish_range, publish_pose, publish_twist, publish_lidar, publish_imu; /* publish_flag/...  :146-158 */
     int32_t has_relative_range;       /* topic/relative_range present: every node moves  :94 */
-    int32_t jacobian;                 /* LOC_JAC_ANALYTIC (default) or LOC_JAC_NUMERIC_G2O = what the reference's EdgeSE3Range
-                                         inherits from g2o (types_edge_se3range.h:45-74) */
+    int32_t jacobian;                 /* LOC_JAC_NUMERIC_G2O (default) = what the reference's EdgeSE3Range inherits from g2o
+                                         (types_edge_se3range.h:45-74), or LOC_JAC_ANALYTIC (opt-in fast mode) */
     int32_t publish_relative_range;   /* publish_flag/relative_range  :158 */
 } loc_node_config;
 
@@ -301,7 +333,7 @@ typedef struct loc_fusion_params {
     int32_t gate_warmup_epochs;  /* default 1 */
     double antenna_offset[3];    /* /uwb/antennaOffset of the antenna every range uses (localization.cpp:111-123, 333) */
     int32_t block_threads;       /* 0 = 256 */
-    int32_t jacobian;            /* LOC_JAC_* for the range factors */
+    int32_t jacobian;            /* LOC_JAC_* for the range factors; default LOC_JAC_NUMERIC_G2O */
 } loc_fusion_params;
 
 void loc_fusion_default_params(loc_fusion_params* p);

@@ -27,7 +27,7 @@ public:
         int maximum_iteration = 20;
         bool publish_range = false, publish_pose = false, publish_twist = false, publish_lidar = false, publish_imu = false;
         bool relative_range_topic = false;
-        bool numeric_jacobian = false;        // true = g2o's central-difference range Jacobians, the reference's exact configuration
+        bool numeric_jacobian = true;         // g2o's central-difference range Jacobians = the reference's exact configuration (false: analytic, the opt-in fast mode)
         std::vector<int> nodesId;            // /uwb/nodesId, last = the moving tag
         std::vector<double> nodesPos;        // /uwb/nodesPos
         std::vector<double> antennaOffset;   // /uwb/antennaOffset (may be empty)

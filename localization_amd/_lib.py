@@ -30,7 +30,7 @@ def library_path():
 
 # every symbol include/localization_amd.h declares (tests check the .so exports all of them)
 EXPORTED_SYMBOLS = [
-    "loc_last_error", "loc_abi_version", "loc_device_count",
+    "loc_last_error", "loc_abi_version", "loc_device_count", "loc_shard_bounds", "loc_shard_plan",
     "loc_snapshot_default_params", "loc_snapshot_create", "loc_snapshot_destroy", "loc_snapshot_batch",
     "loc_snapshot_anchor_groups", "loc_snapshot_lanes_per_instance", "loc_snapshot_range_floats",
     "loc_snapshot_set_positions", "loc_snapshot_get_positions", "loc_snapshot_positions_device",
@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = [
     "loc_snapshot_solve_host_kmb", "loc_host_alloc", "loc_host_free",
     "loc_snapshot_timing_begin", "loc_snapshot_timing_end",
     "loc_window_create", "loc_window_destroy", "loc_window_set_anchors", "loc_window_lds_bytes", "loc_window_solve_host",
-    "loc_window_last_kernel_ms", "loc_window_set_jacobian", "loc_window_set_ordering", "loc_window_set_chain_threshold", "loc_window_upload",
+    "loc_window_last_kernel_ms", "loc_window_set_jacobian", "loc_window_set_ordering", "loc_window_set_chain_threshold", "loc_window_last_kernel_kind", "loc_window_upload",
     "loc_window_solve_resident", "loc_window_download", "loc_window_poses_device", "loc_window_result_device",
     "loc_window_timing_begin", "loc_window_timing_end",
     "loc_node_default_config", "loc_node_create", "loc_node_destroy", "loc_node_add_range", "loc_node_add_imu",
@@ -64,6 +64,8 @@ def lib():
     L.loc_last_error.restype = C.c_char_p
     L.loc_abi_version.restype = C.c_int32
     L.loc_device_count.restype = C.c_int32
+    L.loc_shard_bounds.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.loc_shard_plan.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
     L.loc_snapshot_default_params.argtypes = [C.POINTER(SnapshotParams)]
     L.loc_snapshot_default_params.restype = None
     L.loc_snapshot_create.argtypes = [C.POINTER(vp), C.c_int32, C.c_int64, C.c_int32, dp, C.POINTER(SnapshotParams)]
@@ -95,6 +97,7 @@ def lib():
     L.loc_window_set_jacobian.argtypes = [vp, C.c_int32]
     L.loc_window_set_ordering.argtypes = [vp, C.c_int32]
     L.loc_window_set_chain_threshold.argtypes = [vp, C.c_int64]
+    L.loc_window_last_kernel_kind.argtypes = [vp, ip]
     L.loc_window_upload.argtypes = [vp, C.c_int64, ip, dp, ip, dp, ip, dp, ip, dp]
     L.loc_window_solve_resident.argtypes = [vp, vp]
     L.loc_window_download.argtypes = [vp, dp, dp]

@@ -74,12 +74,36 @@ int32_t loc_device_count(void) {
     return n;
 }
 
+// ---- multi-GPU shard descriptor (host only): contiguous ceil-divided slices, SURVEY.md §8(e) --------------------------------
+int loc_shard_bounds(int64_t total, int32_t rank, int32_t world, int64_t* lo, int64_t* hi) {
+    if (total < 0 || world <= 0 || rank < 0 || rank >= world || !lo || !hi) return fail(LOC_ERR_INVALID, "loc_shard_bounds arguments");
+    const int64_t per = (total + world - 1) / world;
+    const int64_t a = rank * per < total ? rank * per : total;
+    *lo = a;
+    *hi = a + per < total ? a + per : total;
+    return LOC_OK;
+}
+
+int loc_shard_plan(int64_t total, int32_t world, int32_t devices_per_node, loc_shard* out) {
+    if (total < 0 || world <= 0 || !out) return fail(LOC_ERR_INVALID, "loc_shard_plan arguments");
+    if (devices_per_node <= 0) {
+        devices_per_node = loc_device_count();
+        if (devices_per_node <= 0) return fail(LOC_ERR_NO_DEVICE, "no HIP device visible: pass devices_per_node explicitly");
+    }
+    for (int32_t r = 0; r < world; ++r) {
+        out[r].rank = r; out[r].world = world; out[r].device = r % devices_per_node; out[r].reserved = 0;
+        const int rc = loc_shard_bounds(total, r, world, &out[r].lo, &out[r].hi);
+        if (rc != LOC_OK) return rc;
+    }
+    return LOC_OK;
+}
+
 void loc_snapshot_default_params(loc_snapshot_params* p) {
     if (!p) return;
     p->maximum_iteration = 20;   // reference default, localization.cpp:65
     p->distance_outlier = 1.0;   // reference default, localization.cpp:78
     p->gate_warmup_epochs = 1;
-    p->jacobian = LOC_JAC_ANALYTIC;
+    p->jacobian = LOC_JAC_NUMERIC_G2O;   // the reference's configuration (types_edge_se3range.h:45-74: no linearizeOplus)
     p->lanes_per_instance = 0;
     p->block_threads = 0;
 }

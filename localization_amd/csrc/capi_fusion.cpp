@@ -55,6 +55,7 @@ void loc_fusion_default_params(loc_fusion_params* p) {
     if (!p) return;
     std::memset(p, 0, sizeof(*p));
     p->maximum_iteration = 20; p->distance_outlier = 1.0; p->gate_warmup_epochs = 1;
+    p->jacobian = LOC_JAC_NUMERIC_G2O;   // the reference's configuration (types_edge_se3range.h:45-74: no linearizeOplus)
 }
 
 int loc_fusion_destroy(loc_fusion* f) {

@@ -26,16 +26,21 @@ struct loc_window {
     locamd::WindowCaps caps{};
     int n_anchors = 0, anchors_cap = 0;
     int iterations = 10;
-    int jacobian = LOC_JAC_ANALYTIC, natural_order = 0;
+    int jacobian = LOC_JAC_NUMERIC_G2O, natural_order = 0;   // default = the reference's configuration
     double* d_anchors = nullptr;
     int32_t *d_counts = nullptr, *d_ridx = nullptr, *d_pidx = nullptr, *d_sidx = nullptr;
     double *d_poses = nullptr, *d_rval = nullptr, *d_pval = nullptr, *d_sval = nullptr, *d_result = nullptr;
     double* d_workspace = nullptr;  // HBM copy of the (H, L) matrices when they do not fit LDS
     double* d_poses_in = nullptr;   // resident mode: the uploaded initial estimates (every resident solve starts from them)
     double* d_chain_ws = nullptr;   // chain windows (one lane per window, window_kernel.hip: chain_lm_kernel): its workspace
-    bool resident_chain = false;    // the uploaded batch qualifies for it
-    long long chain_min = -1;       // smallest batch that takes it (-1: the default / LOCAMD_CHAIN_MIN_BATCH)
+    double* d_chain3_ws = nullptr;  // translation-only chain windows (chain3_kernel.hip)
+    int resident_topology = 0;      // LOC_WINDOW_KERNEL_* the uploaded batch qualifies for by its structure (the batch-size threshold is applied per solve)
+    long long chain_min = -1;       // smallest batch that takes a lane-per-window kernel (-1: the default / LOCAMD_CHAIN_MIN_BATCH)
     long long n_resident = 0;
+    int resident_min_anchors = 0;   // anchors the resident batch references (loc_window_set_anchors may not shrink below it)
+    bool resident_solved = false;   // a resident solve has run since the upload (loc_window_download has something to fetch)
+    int last_kind = -1;             // LOC_WINDOW_KERNEL_* of the last launch
+    hipStream_t last_stream = nullptr;   // stream of the last resident launch (an upload waits for it)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_ms = 0.0;
@@ -68,7 +73,7 @@ int loc_window_destroy(loc_window* w) {
     if (!w) return LOC_OK;
     (void)hipSetDevice(w->device);
     void* ptrs[] = {w->d_anchors, w->d_counts, w->d_ridx, w->d_pidx, w->d_sidx, w->d_poses, w->d_rval, w->d_pval, w->d_sval, w->d_result, w->d_workspace, w->d_poses_in,
-                    w->d_chain_ws};
+                    w->d_chain_ws, w->d_chain3_ws};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : w->ev) (void)hipEventDestroy(e);
     if (w->h_stage) (void)hipHostFree(w->h_stage);
@@ -126,7 +131,10 @@ int loc_window_create(loc_window** out, int32_t device, int64_t batch, const loc
 
 int loc_window_set_anchors(loc_window* w, int32_t n_anchors, const double* anchors) {
     if (!w || n_anchors < 0 || (n_anchors > 0 && !anchors)) return locamd_fail(LOC_ERR_INVALID, "set_anchors");
+    if (w->n_resident > 0 && n_anchors < w->resident_min_anchors)
+        return locamd_fail(LOC_ERR_INVALID, "set_anchors: the resident batch references more anchors than the new table holds (upload again first)");
     LOC_HIP(hipSetDevice(w->device));
+    if (w->last_stream) LOC_HIP(hipStreamSynchronize(w->last_stream));   // a resident launch may still be reading the table
     if (n_anchors > w->anchors_cap) {
         double* p = nullptr;
         LOC_HIP(hipMalloc((void**)&p, (size_t)n_anchors * 3 * sizeof(double)));
@@ -176,15 +184,16 @@ static int validate_instances(const loc_window* w, int64_t n, const int32_t* cou
 
 // Large batches of CHAIN windows (every pose-to-pose edge — range or SE3 — joins consecutive poses; edges ordered by their
 // later pose and priors by pose — the order Localization::addRangeEdge / addImuEdge create them in) run one lane per window
-// (chain_lm_kernel).  Below the threshold a wave per window is faster (the lane-per-window kernel takes about as long for 1 000
-// windows as for 65 536); LOCAMD_CHAIN_MIN_BATCH in the environment moves it (0 = never).
+// (chain_lm_kernel; chain3_lm_kernel when the batch is translation-only).  Below the threshold a wave per window is faster (the
+// lane-per-window kernels take about as long for 1 000 windows as for 65 536); LOCAMD_CHAIN_MIN_BATCH in the environment moves it
+// (0 = never).
 static long long chain_min_batch() {
     static const long long v = [] { const char* e = getenv("LOCAMD_CHAIN_MIN_BATCH"); return e ? atoll(e) : 12288LL; }();
     return v;
 }
-static bool chain_eligible(const loc_window* w, int64_t n, const int32_t* counts, const int32_t* r_idx, const int32_t* p_idx, const int32_t* s_idx) {
-    const long long mn = w->chain_min >= 0 ? w->chain_min : chain_min_batch();
-    if (mn <= 0 || n < mn || w->natural_order) return false;
+// what the batch qualifies for BY ITS STRUCTURE: LOC_WINDOW_KERNEL_GENERAL, _CHAIN (block-tridiagonal, 6-DoF) or _CHAIN3
+static int batch_topology(const loc_window* w, int64_t n, const int32_t* counts, const double* poses, const int32_t* r_idx, const double* r_val,
+                          const int32_t* p_idx, const double* p_val, const int32_t* s_idx) {
     const locamd::WindowCaps& c = w->caps;
     for (int64_t i = 0; i < n; ++i) {
         const int32_t* cn = counts + i * 4;
@@ -192,33 +201,75 @@ static bool chain_eligible(const loc_window* w, int64_t n, const int32_t* counts
         for (int e = 0; e < cn[3]; ++e) {   // EdgeSE3 factors: between consecutive poses, ordered by their later pose (addTwistEdge)
             const int32_t* ix = s_idx + ((size_t)i * c.ns_max + e) * 4;
             const int key = ix[1] > ix[0] ? ix[1] : ix[0];
-            if (key < last || (ix[0] - ix[1] != 1 && ix[1] - ix[0] != 1)) return false;
+            if (key < last || (ix[0] - ix[1] != 1 && ix[1] - ix[0] != 1)) return LOC_WINDOW_KERNEL_GENERAL;
             last = key;
         }
         last = 0;
         for (int e = 0; e < cn[1]; ++e) {
             const int32_t* ix = r_idx + ((size_t)i * c.nr_max + e) * 2;
             const int key = ix[1] > ix[0] ? ix[1] : ix[0];
-            if (key < last) return false;
+            if (key < last) return LOC_WINDOW_KERNEL_GENERAL;
             last = key;
-            if (ix[1] >= 0 && ix[0] - ix[1] != 1 && ix[1] - ix[0] != 1) return false;
+            if (ix[1] >= 0 && ix[0] - ix[1] != 1 && ix[1] - ix[0] != 1) return LOC_WINDOW_KERNEL_GENERAL;
         }
         last = 0;
         for (int e = 0; e < cn[2]; ++e) {
             const int32_t v = p_idx[(size_t)i * c.np_max + e];
-            if (v < last) return false;
+            if (v < last) return LOC_WINDOW_KERNEL_GENERAL;
             last = v;
         }
     }
-    return true;
+    // Translation-only (the exact 3-DoF reduction, chain3_kernel.hip): no EdgeSE3, every lever arm zero, every rotation the
+    // identity, priors with an identity measurement rotation and no rotation information.
+    static const double I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t* cn = counts + i * 4;
+        if (cn[3] != 0 || cn[0] > 1048575) return LOC_WINDOW_KERNEL_CHAIN;
+        for (int e = 0; e < cn[1]; ++e) {
+            const double* v = r_val + ((size_t)i * c.nr_max + e) * 5;
+            if (v[2] != 0.0 || v[3] != 0.0 || v[4] != 0.0) return LOC_WINDOW_KERNEL_CHAIN;
+        }
+        for (int p = 0; p < cn[0]; ++p)
+            if (std::memcmp(poses + ((size_t)i * c.nv_max + p) * 12, I9, sizeof(I9)) != 0) return LOC_WINDOW_KERNEL_CHAIN;
+        for (int e = 0; e < cn[2]; ++e) {
+            const double* v = p_val + ((size_t)i * c.np_max + e) * 18;
+            if (std::memcmp(v, I9, sizeof(I9)) != 0 || v[15] != 0.0 || v[16] != 0.0 || v[17] != 0.0) return LOC_WINDOW_KERNEL_CHAIN;
+        }
+    }
+    if (w->n_anchors > 500000) return LOC_WINDOW_KERNEL_CHAIN;   // (the packed endpoint word of chain3 holds 2^19 anchors)
+    return LOC_WINDOW_KERNEL_CHAIN3;
 }
-static hipError_t launch_any(loc_window* w, const locamd::WindowArgs& a, hipStream_t st, bool chain) {
-    if (!chain) return locamd::launch_window(a, st);
+// the kernel a batch of n windows with that structure takes NOW (threshold, ordering override, LOCAMD_CHAIN3=0 for A/B runs)
+static int pick_kernel(const loc_window* w, int64_t n, int topology) {
+    const long long mn = w->chain_min >= 0 ? w->chain_min : chain_min_batch();
+    if (topology == LOC_WINDOW_KERNEL_GENERAL || mn <= 0 || n < mn || w->natural_order) return LOC_WINDOW_KERNEL_GENERAL;
+    if (topology == LOC_WINDOW_KERNEL_CHAIN3) {   // LOCAMD_CHAIN3=0: the 6-DoF kernel on a translation-only batch (A/B runs, tests; read per call)
+        const char* v = getenv("LOCAMD_CHAIN3");
+        if (v && v[0] == '0') return LOC_WINDOW_KERNEL_CHAIN;
+    }
+    return topology;
+}
+static hipError_t launch_any(loc_window* w, const locamd::WindowArgs& a, hipStream_t st, int kind) {
+    w->last_kind = kind;
+    if (kind == LOC_WINDOW_KERNEL_CHAIN3) {
+        if (!w->d_chain3_ws) {
+            hipError_t e = hipMalloc((void**)&w->d_chain3_ws, locamd::window_chain3_workspace_doubles(w->caps, w->B) * sizeof(double));
+            if (e != hipSuccess) return e;
+        }
+        return locamd::launch_window_chain3(a, w->d_chain3_ws, st);
+    }
+    if (kind == LOC_WINDOW_KERNEL_GENERAL) return locamd::launch_window(a, st);
     if (!w->d_chain_ws) {
         hipError_t e = hipMalloc((void**)&w->d_chain_ws, locamd::window_chain_workspace_doubles(w->caps, w->B) * sizeof(double));
         if (e != hipSuccess) return e;
     }
     return locamd::launch_window_chain(a, w->d_chain_ws, st);
+}
+
+int loc_window_last_kernel_kind(const loc_window* w, int32_t* kind) {
+    if (!w || !kind) return locamd_fail(LOC_ERR_INVALID, "null");
+    *kind = w->last_kind;
+    return LOC_OK;
 }
 
 int loc_window_set_chain_threshold(loc_window* w, int64_t min_batch) {
@@ -277,7 +328,7 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
             a.anchors = w->d_anchors; a.workspace = w->d_workspace;
             a.n_anchors = w->n_anchors; a.B = (int)n; a.iterations = w->iterations; a.caps = c;
             LOC_HIP(hipEventRecord(w->ev0, st));
-            hipError_t e = launch_any(w, a, st, chain_eligible(w, n, counts, r_idx, p_idx, s_idx));
+            hipError_t e = launch_any(w, a, st, pick_kernel(w, n, batch_topology(w, n, counts, poses, r_idx, r_val, p_idx, p_val, s_idx)));
             if (e != hipSuccess) return locamd_fail_hip(e, "launch_window");
             LOC_HIP(hipEventRecord(w->ev1, st));
             LOC_HIP(hipMemcpyAsync(h, d, off[2], hipMemcpyDeviceToHost, st));  // [poses | result]
@@ -309,9 +360,9 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
     a.p_val = w->d_pval; a.s_idx = w->d_sidx; a.s_val = w->d_sval; a.anchors = w->d_anchors; a.result = w->d_result;
     a.workspace = w->d_workspace;
     a.n_anchors = w->n_anchors; a.B = (int)n; a.iterations = w->iterations; a.caps = c;
-    const bool chain = chain_eligible(w, n, counts, r_idx, p_idx, s_idx);
+    const int kind = pick_kernel(w, n, batch_topology(w, n, counts, poses, r_idx, r_val, p_idx, p_val, s_idx));
     LOC_HIP(hipEventRecord(w->ev0, st));
-    hipError_t e = launch_any(w, a, st, chain);
+    hipError_t e = launch_any(w, a, st, kind);
     if (e != hipSuccess) return locamd_fail_hip(e, "launch_window");
     LOC_HIP(hipEventRecord(w->ev1, st));
     LOC_HIP(hipMemcpyAsync(poses, w->d_poses, N * c.nv_max * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -334,6 +385,10 @@ int loc_window_upload(loc_window* w, int64_t n, const int32_t* counts, const dou
     const locamd::WindowCaps& c = w->caps;
     LOC_HIP(hipSetDevice(w->device));
     const size_t N = (size_t)n;
+    // a resident launch of the previous batch may still be running on the handle's (or the caller's) stream: it reads what the
+    // copies below overwrite
+    LOC_HIP(hipStreamSynchronize(w->stream));
+    if (w->last_stream && w->last_stream != w->stream) LOC_HIP(hipStreamSynchronize(w->last_stream));
     if (!w->d_poses_in) LOC_HIP(hipMalloc((void**)&w->d_poses_in, (size_t)w->B * c.nv_max * 12 * sizeof(double)));
     LOC_HIP(hipMemcpy(w->d_counts, counts, N * 4 * sizeof(int32_t), hipMemcpyHostToDevice));
     LOC_HIP(hipMemcpy(w->d_poses_in, poses, N * c.nv_max * 12 * sizeof(double), hipMemcpyHostToDevice));
@@ -350,7 +405,15 @@ int loc_window_upload(loc_window* w, int64_t n, const int32_t* counts, const dou
         LOC_HIP(hipMemcpy(w->d_sval, s_val, N * c.ns_max * 48 * sizeof(double), hipMemcpyHostToDevice));
     }
     w->n_resident = n;
-    w->resident_chain = chain_eligible(w, n, counts, r_idx, p_idx, s_idx);
+    w->resident_solved = false;
+    w->resident_topology = batch_topology(w, n, counts, poses, r_idx, r_val, p_idx, p_val, s_idx);
+    int max_anchor = 0;   // anchors referenced: v1 = -1 - anchor
+    for (int64_t i = 0; i < n; ++i)
+        for (int e = 0; e < counts[i * 4 + 1]; ++e) {
+            const int32_t v1 = r_idx[((size_t)i * c.nr_max + e) * 2 + 1];
+            if (v1 < 0 && -v1 > max_anchor) max_anchor = -v1;
+        }
+    w->resident_min_anchors = max_anchor;
     return LOC_OK;
 }
 
@@ -366,14 +429,19 @@ int loc_window_solve_resident(loc_window* w, void* hip_stream) {
     a.natural_order = w->natural_order; a.caps = w->caps;
     const bool timed = w->timing && (size_t)(w->ev_used + 2) <= w->ev.size();
     if (timed) LOC_HIP(hipEventRecord(w->ev[w->ev_used], st));
-    hipError_t e = launch_any(w, a, st, w->resident_chain && !w->natural_order);
+    // (the batch-size threshold and the ordering override are looked at per solve: loc_window_set_chain_threshold /
+    //  loc_window_set_ordering after the upload take effect)
+    hipError_t e = launch_any(w, a, st, pick_kernel(w, w->n_resident, w->resident_topology));
     if (e != hipSuccess) return locamd_fail_hip(e, "launch_window");
     if (timed) { LOC_HIP(hipEventRecord(w->ev[w->ev_used + 1], st)); w->ev_used += 2; }
+    w->last_stream = st;
+    w->resident_solved = true;
     return LOC_OK;
 }
 
 int loc_window_download(loc_window* w, double* poses, double* result) {
     if (!w || w->n_resident <= 0) return locamd_fail(LOC_ERR_INVALID, "nothing uploaded");
+    if (!w->resident_solved) return locamd_fail(LOC_ERR_INVALID, "loc_window_download: no resident solve has run since the upload");
     LOC_HIP(hipSetDevice(w->device));
     LOC_HIP(hipDeviceSynchronize());
     const size_t N = (size_t)w->n_resident;

@@ -380,7 +380,7 @@ void loc_node_default_config(loc_node_config* c) {
     c->distance_outlier = 1.0;           // :78
     c->maximum_iteration = 20;           // :65
     c->minimum_optimize_error = 1000.0;  // :68
-    c->jacobian = LOC_JAC_ANALYTIC;
+    c->jacobian = LOC_JAC_NUMERIC_G2O;   // what EdgeSE3Range inherits from g2o (types_edge_se3range.h:45-74); ANALYTIC is the opt-in fast mode
 }
 
 int loc_node_create(loc_node** out, int32_t device, const loc_node_config* cfg, int32_t n_nodes, const int32_t* ids,

@@ -134,7 +134,25 @@ __device__ __forceinline__ System evaluate(const double px, const double py, con
     s.h11 = group_sum<LPI>(s.h11); s.h12 = group_sum<LPI>(s.h12); s.h22 = group_sum<LPI>(s.h22);
     s.b0 = group_sum<LPI>(s.b0); s.b1 = group_sum<LPI>(s.b1); s.b2 = group_sum<LPI>(s.b2);
     s.chi = group_sum<LPI>(s.chi);
-    s.rchi = fast_log_ge1(group_prod<LPI>(prod));
+    // Sum_j log(1 + chi_j) as ONE log of the product.  The product overflows where g2o's sum of logs stays finite (eight ranges
+    // with |e| / sigma > 1e19 each): a wave that sees that — never on physical data — sums the logs edge by edge instead.
+    const double gp = group_prod<LPI>(prod);
+    if (__builtin_expect(__any(!(gp <= DBL_MAX)), 0)) {
+        double ls = 0.0;
+#pragma unroll 1
+        for (int j = 0; j < APL; ++j) {
+            const double dx = px - ax[j], dy = py - ay[j], dz = pz - az[j];
+            double n;
+            if constexpr (JAC == 0) { double inv; sqrt_and_rsqrt_fast(fmax(dx * dx + dy * dy + dz * dz, 1e-300), n, inv); }
+            else n = range_norm_plain(dx, dy, dz);
+            const double e = d[j] - n;
+            ls += fast_log_ge1(1.0 + e * (w[j] * e));
+        }
+        const double gs = group_sum<LPI>(ls);
+        s.rchi = (gp <= DBL_MAX) ? fast_log_ge1(gp) : gs;
+    } else {
+        s.rchi = fast_log_ge1(gp);
+    }
     return s;
 }
 

@@ -51,4 +51,9 @@ hipError_t launch_window(const WindowArgs& a, hipStream_t stream);
 size_t window_chain_workspace_doubles(const WindowCaps& c, long long B);
 hipError_t launch_window_chain(const WindowArgs& a, double* chain_ws, hipStream_t stream);
 
+// translation-only chain windows, one lane per window (chain3_kernel.hip)
+size_t window_chain3_workspace_doubles(const WindowCaps& c, long long B);
+int window_chain3_lds_mode(const WindowCaps& c);   // 0: all state in the HBM slab, 1: (G, y) in LDS, 2: (G, y) and the translations
+hipError_t launch_window_chain3(const WindowArgs& a, double* ws, hipStream_t stream);
+
 }  // namespace locamd

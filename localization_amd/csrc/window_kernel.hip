@@ -1371,6 +1371,10 @@ __device__ __forceinline__ void compute_incidence(const Lds& L, int lane, int nv
     }
     if (lane == 0) L.shared[0] = cnt;
     sync_<SOLO>();
+    // the two marker entries of every edge block go back to zero: H is zeroed once per launch BEFORE this pass, and nothing may
+    // depend on every later linearisation overwriting all 36 entries of every block that has an edge
+    for (int t = lane; t < nbin; t += 64) { const int a0 = block_entry(t); if (a0 >= 0) { L.Hs[a0] = 0.0; L.Hs[a0 + 1] = 0.0; } }
+    sync_<SOLO>();
     LOCAMD_STAMP5(2);
 }
 
@@ -1464,6 +1468,9 @@ __device__ __forceinline__ void compute_incidence_wide(const Lds& L, int tid, in
         }
         if (tid == 0) L.shared[0] = cnt;
     }
+    __syncthreads();
+    // (markers back to zero, as in compute_incidence)
+    for (int t = tid; t < nbin; t += NT) { const int a0 = block_entry(t); if (a0 >= 0) { L.Hs[a0] = 0.0; L.Hs[a0 + 1] = 0.0; } }
     __syncthreads();
 }
 
@@ -3042,8 +3049,9 @@ hipError_t launch_window(const WindowArgs& a, hipStream_t stream) {
 // pivots), y_p, x_p and two pose buffers: 120 doubles (W_p = L_p,p-1 is never stored: the back-substitution re-forms W^T x).  The LM loops are flattened into one loop of
 // passes (a pass = one trial; a lane that starts an iteration linearises first), lanes leave when their window is done.
 // The kernel is bound by that workspace traffic (~16 KB per window per trial), not by instruction issue.
-// Conditions (checked on the host, capi_window.cpp: chain_eligible): no SE3 edges; every moving-moving range edge joins
-// poses p - 1 and p; range edges sorted by their later pose, priors sorted by pose (the order the reference adds them in).
+// Conditions (checked on the host, capi_window.cpp: batch_topology): every pose-to-pose edge — range edge or EdgeSE3 (addTwistEdge;
+// the <JAC, true> instantiation) — joins poses p - 1 and p; edges sorted by their later pose, priors sorted by pose (the order the
+// reference adds them in).
 // Elimination order = pose order (no fill), so the rounding differs from the general kernel's in the last bits.
 namespace chainw {
 constexpr int HD = 0, HO = 21, HB = 57, G = 63, Y = 84, X = 90, P = 96, PB = 108, N = 120;
@@ -3204,7 +3212,7 @@ __device__ __forceinline__ double chain_se3_terms(const double* Xi, const double
 // one sweep over the window's edges in pose order: chi sums always; FULL: H and b as well (returns the largest diagonal entry)
 template <bool FULL, int JAC, bool SE3>
 __device__ __forceinline__ void chain_sweep(const WindowArgs& a, double* slab, long long inst, int nv, int nr, int np, int ns, int buf,
-                                            double& robust_chi, double& plain_chi, double& max_diag, unsigned long long& ho_kind) {
+                                            double& robust_chi, double& plain_chi, double& max_diag, unsigned long long& ho_kind, int& shared_edges) {
     using namespace chainw;
 #define CH(p, f, k) slab[((size_t)(p) * N + (f) + (k)) * 64]
     const WindowCaps& c = a.caps;
@@ -3227,7 +3235,8 @@ __device__ __forceinline__ void chain_sweep(const WindowArgs& a, double* slab, l
     // trial, a quarter of all the bytes a trial moved).  ho_kind: two bits per pose (0 no coupling, 1 rank-1, 2 full block;
     // poses from 32 on always store the full block).
     unsigned long long kinds = 0;
-    int nbin = 0;
+    int nbin = 0, nshared = 0;   // nshared: pose-to-pose edges that share their pair of poses with another edge (result[6]; an EdgeSE3 counts as one edge)
+    int nedges_pair = 0;
     double fu[6], fv[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) { fu[k] = 0.0; fv[k] = 0.0; }
@@ -3252,6 +3261,7 @@ __device__ __forceinline__ void chain_sweep(const WindowArgs& a, double* slab, l
 #pragma unroll
             for (int k = 0; k < 36; ++k) O[k] = 0.0;
             nbin = 0;
+            nedges_pair = 0;
         }
         // range edges whose later pose is p
         while (e < nr) {
@@ -3355,6 +3365,7 @@ __device__ __forceinline__ void chain_sweep(const WindowArgs& a, double* slab, l
                             for (int cc = 0; cc < 6; ++cc) O[6 * cc + r] += wr * jr[r] * jc[cc];
                     }
                     ++nbin;
+                    ++nedges_pair;
                 }
             }
             ++e;
@@ -3393,6 +3404,7 @@ __device__ __forceinline__ void chain_sweep(const WindowArgs& a, double* slab, l
 #pragma unroll
                     for (int k = 0; k < 36; ++k) O[k] += Hoff[k];
                     nbin += 2;   // (an SE3 coupling is never rank-1: the block is stored in full)
+                    ++nedges_pair;
                 }
                 ++es;
             }
@@ -3462,6 +3474,7 @@ __device__ __forceinline__ void chain_sweep(const WindowArgs& a, double* slab, l
                     for (int k = 0; k < 36; ++k) CH(p, HO, k) = O[k];
                     if (p < 32) kinds |= 2ull << (2 * p);
                 }
+                nshared += nedges_pair >= 2 ? nedges_pair : 0;
             }
 #pragma unroll
             for (int k = 0; k < 27; ++k) Dp[k] = Dc[k];
@@ -3478,7 +3491,7 @@ __device__ __forceinline__ void chain_sweep(const WindowArgs& a, double* slab, l
         for (int r = 0; r < 6; ++r) md = fmax(md, fabs(Dp[r * (r + 1) / 2 + r]));
     }
     robust_chi = rsum; plain_chi = csum; max_diag = md;
-    if (FULL) ho_kind = kinds;
+    if (FULL) { ho_kind = kinds; shared_edges = nshared; }
 #undef CE
 #undef CP
 #undef CS
@@ -3766,7 +3779,7 @@ __global__ void __launch_bounds__(64, 1) chain_lm_kernel(const WindowArgs a, dou
     constexpr double tau = 1e-5, good_lo = 1.0 / 3.0, good_hi = 2.0 / 3.0;
     constexpr int max_trials = 10;
     double lambda = 0.0, ni = 2.0, cur_chi = 0.0, last_plain = 0.0;
-    int it = 0, q = 0, trials = 0, terminated = 0, buf = 0;
+    int it = 0, q = 0, trials = 0, terminated = 0, buf = 0, shared_edges = 0;
     unsigned long long ho_kind = 0;
     bool need_lin = true;
     bool done = !live || nv <= 0 || nr + np + ns <= 0 || a.iterations <= 0;
@@ -3774,7 +3787,7 @@ __global__ void __launch_bounds__(64, 1) chain_lm_kernel(const WindowArgs a, dou
         if (!done) {
             if (need_lin) {
                 double plain, md;
-                chain_sweep<true, JAC, SE3>(a, slab, inst, nv, nr, np, ns, buf, cur_chi, plain, md, ho_kind);
+                chain_sweep<true, JAC, SE3>(a, slab, inst, nv, nr, np, ns, buf, cur_chi, plain, md, ho_kind, shared_edges);
                 last_plain = plain;
                 if (it == 0) { lambda = tau * md; ni = 2.0; }
                 q = 0;
@@ -3786,7 +3799,8 @@ __global__ void __launch_bounds__(64, 1) chain_lm_kernel(const WindowArgs a, dou
             ++trials;
             double temp_chi, plain2, md2;
             unsigned long long unused_kind;
-            chain_sweep<false, JAC, SE3>(a, slab, inst, nv, nr, np, ns, 1 - buf, temp_chi, plain2, md2, unused_kind);
+            int unused_shared;
+            chain_sweep<false, JAC, SE3>(a, slab, inst, nv, nr, np, ns, 1 - buf, temp_chi, plain2, md2, unused_kind, unused_shared);
             last_plain = plain2;
             if (!ok2) temp_chi = DBL_MAX;
             const double scale = sc + 1e-3;
@@ -3823,7 +3837,7 @@ __global__ void __launch_bounds__(64, 1) chain_lm_kernel(const WindowArgs a, dou
         }
         double* res = a.result + (size_t)inst * 8;
         res[0] = last_plain; res[1] = cur_chi; res[2] = lambda; res[3] = (double)it; res[4] = (double)trials;
-        res[5] = (double)terminated; res[6] = 0.0; res[7] = nv > 0 ? (double)(nv * 65536 + 2 * nv - 1) : 0.0;
+        res[5] = (double)terminated; res[6] = (double)shared_edges; res[7] = nv > 0 ? (double)(nv * 65536 + 2 * nv - 1) : 0.0;
     }
 #undef CH
 }

@@ -32,7 +32,7 @@ class FusionSolver:
     """B tags, each a 6-DoF pose: M <= 8 anchor ranges with an antenna lever arm + an IMU rotation prior per epoch."""
 
     def __init__(self, anchors, batch, antenna_offset=(0.0, 0.0, 0.0), maximum_iteration=10, distance_outlier=3.0,
-                 gate_warmup_epochs=1, block_threads=0, device=0, jacobian="analytic"):
+                 gate_warmup_epochs=1, block_threads=0, device=0, jacobian="numeric"):
         L = lib(); _bind(L)
         if L.loc_device_count() <= 0:
             raise _lib.LocalizationAmdError(_lib.LOC_ERR_NO_DEVICE, "no HIP device visible: localization_amd has no CPU fallback")

@@ -61,7 +61,7 @@ class LocalizationNode:
     def __init__(self, nodes_id, nodes_pos, trajectory_length, maximum_velocity=1.0, distance_outlier=1.0,
                  maximum_iteration=20, minimum_optimize_error=1000.0, publish_range=False, publish_pose=False,
                  publish_twist=False, publish_lidar=False, publish_imu=False, has_relative_range=False,
-                 antenna_offsets=None, device=0, jacobian="analytic", publish_relative_range=False):
+                 antenna_offsets=None, device=0, jacobian="numeric", publish_relative_range=False):
         L = lib(); _bind(L)
         self.L = L
         cfg = NodeConfig(int(trajectory_length), float(maximum_velocity), float(distance_outlier), int(maximum_iteration),
@@ -81,12 +81,12 @@ class LocalizationNode:
         self.T = int(trajectory_length)
 
     @classmethod
-    def from_config(cls, cfg, device=0):
+    def from_config(cls, cfg, device=0, jacobian="numeric"):
         """cfg: localization_amd.LocalizationConfig (reference yaml keys)."""
         return cls(cfg.nodes_id, cfg.nodes_pos, cfg.trajectory_length, cfg.maximum_velocity, cfg.distance_outlier,
                    cfg.maximum_iteration, cfg.minimum_optimize_error, cfg.publish_range, cfg.publish_pose,
                    cfg.publish_twist, cfg.publish_lidar, cfg.publish_imu, cfg.has_relative_range,
-                   None if cfg.antenna_offset is None else np.asarray(cfg.antenna_offset).reshape(-1, 3), device)
+                   None if cfg.antenna_offset is None else np.asarray(cfg.antenna_offset).reshape(-1, 3), device, jacobian)
 
     def close(self):
         if getattr(self, "h", None):

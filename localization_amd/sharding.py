@@ -4,15 +4,32 @@ on the solve path.  torch.distributed (backend "nccl" = RCCL over xGMI on the GP
 only for (1) the barrier / max-over-ranks around a timed region, (2) an optional all-gather of the per-rank result
 slabs when one consumer wants the whole batch, (3) an all-reduce of a few reporting scalars.
 """
+import ctypes as C
+
 import numpy as np
+
+from ._lib import check, lib
+
+
+class Shard(C.Structure):
+    """include/localization_amd.h: loc_shard"""
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32),
+                ("lo", C.c_int64), ("hi", C.c_int64)]
 
 
 def shard_bounds(total, rank, world):
-    """Contiguous slice [lo, hi) of `total` tags owned by `rank`: ceil-divided, last ranks may be shorter/empty."""
-    per = -(-int(total) // int(world))
-    lo = min(rank * per, total)
-    hi = min(lo + per, total)
-    return lo, hi
+    """Contiguous slice [lo, hi) of `total` tags owned by `rank`: ceil-divided, last ranks may be shorter/empty.
+    The rule lives in the C ABI (loc_shard_bounds) so that C++ callers, this harness and bench.py cannot disagree."""
+    lo, hi = C.c_int64(), C.c_int64()
+    check(lib().loc_shard_bounds(int(total), int(rank), int(world), C.byref(lo), C.byref(hi)))
+    return int(lo.value), int(hi.value)
+
+
+def shard_plan(total, world, devices_per_node):
+    """loc_shard_plan: the whole job's descriptor table, [(rank, device, lo, hi)] for rank 0 .. world - 1."""
+    arr = (Shard * int(world))()
+    check(lib().loc_shard_plan(int(total), int(world), int(devices_per_node), arr))
+    return [(s.rank, s.device, int(s.lo), int(s.hi)) for s in arr]
 
 
 def shard_array(x, rank, world, axis=-1):

@@ -31,7 +31,7 @@ class SnapshotSolver:
     """B independent tags sharing one anchor map; each `solve` call runs K epochs of
     gate -> Cauchy range factors -> g2o-style LM (reference localization.cpp:297-376 cost, :164-170 solve)."""
 
-    def __init__(self, anchors, batch, maximum_iteration=10, distance_outlier=1.0, jacobian="analytic",
+    def __init__(self, anchors, batch, maximum_iteration=10, distance_outlier=1.0, jacobian="numeric",
                  lanes_per_instance=0, block_threads=0, device=0, gate_warmup_epochs=1):
         import torch
         self.torch = torch

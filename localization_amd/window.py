@@ -71,7 +71,7 @@ class WindowBatch:
 
 class WindowSolver:
     def __init__(self, anchors, batch, nv_max, nr_max, np_max=0, ns_max=0, maximum_iteration=10, device=0, bw_max=-1,
-                 jacobian="analytic", natural_order=False, chain_threshold=None):
+                 jacobian="numeric", natural_order=False, chain_threshold=None):
         L = lib()
         if L.loc_device_count() <= 0:
             raise _lib.LocalizationAmdError(_lib.LOC_ERR_NO_DEVICE, "no HIP device visible: localization_amd has no CPU fallback")
@@ -136,6 +136,14 @@ class WindowSolver:
         n = C.c_int32(); tot = C.c_double(); avg = C.c_double()
         check(self.L.loc_window_timing_end(self.h, C.byref(n), C.byref(tot), C.byref(avg)))
         return n.value, tot.value, avg.value
+
+    KERNEL_KINDS = {-1: "none", 0: "window_lm_kernel", 1: "chain_lm_kernel", 2: "chain3_lm_kernel", 3: "arrow3_lm_kernel", 4: "tree_lm_kernel"}
+
+    def last_kernel_kind(self):
+        """name of the kernel the last solve ran (loc_window_last_kernel_kind)"""
+        k = C.c_int32()
+        check(self.L.loc_window_last_kernel_kind(self.h, C.byref(k)))
+        return self.KERNEL_KINDS.get(k.value, str(k.value))
 
     def last_kernel_ms(self):
         ms = C.c_double()

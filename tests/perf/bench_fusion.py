@@ -32,7 +32,7 @@ def main():
     dist = torch.from_numpy(la.pack_ranges(s["dist"])).to(dev)
     err = torch.from_numpy(la.pack_ranges(s["err"])).to(dev)
     imu = torch.from_numpy(s["imu"]).to(dev)
-    f = la.FusionSolver(s["anchors"], B, antenna_offset=s["offset"], maximum_iteration=10, distance_outlier=3.0)
+    f = la.FusionSolver(s["anchors"], B, antenna_offset=s["offset"], maximum_iteration=10, distance_outlier=3.0, jacobian="analytic")
     out_pose = torch.empty((E, 7, B), dtype=torch.float64, device=dev)
     out_chi2 = torch.empty((E, B), dtype=torch.float64, device=dev)
     out_trials = torch.empty((E, B), dtype=torch.uint8, device=dev)

@@ -50,6 +50,10 @@ def build(B, shape, seed=0):
         tt = np.cumsum(rng.normal(0, 0.05, (T, 3)), axis=0) + np.array([rng.uniform(-1.5, 1.5), rng.uniform(-1.5, 1.5), 1.1])
         tR = Rotation.from_rotvec(np.cumsum(rng.normal(0, 0.03, (T, 3)), axis=0) + rng.normal(0, 0.3, 3))
         et = tt + rng.normal(0, 0.05, (T, 3)); eR = (tR * Rotation.from_rotvec(rng.normal(0, 0.02, (T, 3)))).as_matrix()
+        if shape == "uwb_only":
+            # cfg/uwb_only.yaml has no rotation source: Robot::init gives every pose the identity rotation (robot.cpp:47) and, with the
+            # default identity antenna offsets (localization.h:170), nothing ever turns it
+            eR = np.tile(np.eye(3), (T, 1, 1))
         g = dict(et=et, eR=eR, off=off, ranges=[], smooth=[], priors=[])
         for k in range(T):
             wb.add_pose(i, et[k], eR[k])

@@ -26,7 +26,7 @@ for b in range(min(NB, 64)):
     r = wb.r_idx[b, :nr]; pp = r[r[:, 1] >= 0]
     if len(pp): bwm = max(bwm, int(np.abs(pp[:, 0] - pp[:, 1]).max()))
     if ns: bwm = max(bwm, int(np.abs(wb.s_idx[b, :ns, 0] - wb.s_idx[b, :ns, 1]).max()))
-s = la.WindowSolver(anchors, NB, *wb.caps, maximum_iteration=10, bw_max=bwm, natural_order=natural)
+s = la.WindowSolver(anchors, NB, *wb.caps, maximum_iteration=10, bw_max=bwm, natural_order=natural, jacobian="analytic")
 s.solve(wb)
 r = wb.result.mean(axis=0)
 names = ["set-up (ordering, structure, incidence)", "linearise", "build H, b", "factor phase 1 (SKYLINE: whole sweep)", "factor phase 2",

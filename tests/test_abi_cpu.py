@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(built):
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/localization_amd.h but not exported"
     assert sorted(_lib.EXPORTED_SYMBOLS) == names
-    assert la.abi_version() == 2
+    assert la.abi_version() == 3
 
 
 def test_no_cpu_fallback(built):
@@ -49,7 +49,16 @@ def test_default_params_mirror_reference_defaults(built):
     la.lib().loc_snapshot_default_params(C.byref(p))
     assert p.maximum_iteration == 20          # localization.cpp:65
     assert p.distance_outlier == 1.0          # localization.cpp:78
-    assert p.gate_warmup_epochs == 1 and p.jacobian == _lib.JAC_ANALYTIC
+    # the reference's EdgeSE3Range has no linearizeOplus (types_edge_se3range.h:45-74): g2o's numeric Jacobians are the default
+    assert p.gate_warmup_epochs == 1 and p.jacobian == _lib.JAC_NUMERIC_G2O
+    from localization_amd.node import NodeConfig
+    from localization_amd.fusion import FusionParams
+    nc = NodeConfig()
+    la.lib().loc_node_default_config(C.byref(nc))
+    assert nc.jacobian == _lib.JAC_NUMERIC_G2O and nc.maximum_iteration == 20 and nc.minimum_optimize_error == 1000.0
+    fp = FusionParams()
+    la.lib().loc_fusion_default_params(C.byref(fp))
+    assert fp.jacobian == _lib.JAC_NUMERIC_G2O
 
 
 def test_pack_unpack_ranges_round_trip():

@@ -11,7 +11,7 @@ def _run(B, K, seed, iters=10, gate=3.0, **kw):
     import localization_amd as la
     from localization_amd.synthetic import make_fusion_stream
     s = make_fusion_stream(B, K, seed=seed, **kw)
-    f = la.FusionSolver(s["anchors"], B, antenna_offset=s["offset"], maximum_iteration=iters, distance_outlier=gate)
+    f = la.FusionSolver(s["anchors"], B, antenna_offset=s["offset"], maximum_iteration=iters, distance_outlier=gate, jacobian="analytic")
     f.set_poses(s["init"])
     pose, chi2, trials = f.solve(s["dist"], s["err"], s["imu"])
     last = f.get_poses()
@@ -53,11 +53,11 @@ def test_fusion_zero_lever_arm_reduces_to_snapshot(gpu):
     from localization_amd.synthetic import make_fusion_stream
     B, K = 777, 3
     s = make_fusion_stream(B, K, seed=6, offset=(0.0, 0.0, 0.0))
-    f = la.FusionSolver(s["anchors"], B, antenna_offset=(0, 0, 0), maximum_iteration=80, distance_outlier=3.0)
+    f = la.FusionSolver(s["anchors"], B, antenna_offset=(0, 0, 0), maximum_iteration=80, distance_outlier=3.0, jacobian="analytic")
     f.set_poses(s["init"])
     pose, chi2, trials = f.solve(s["dist"], s["err"], s["imu"])
     f.close()
-    snap = la.SnapshotSolver(s["anchors"], B, maximum_iteration=80, distance_outlier=3.0)
+    snap = la.SnapshotSolver(s["anchors"], B, maximum_iteration=80, distance_outlier=3.0, jacobian="analytic")
     snap.set_positions(s["init"][:3])
     spos, schi, _ = snap.solve(s["dist"], s["err"])
     snap.close()
@@ -88,10 +88,10 @@ def test_fusion_pipelined_host_path_equals_the_staged_one(gpu, B, K, M):
     s = make_fusion_stream(B, K, seed=9)
     anchors = s["anchors"][:M]
     dist, err = s["dist"][:, :M], s["err"][:, :M]
-    a = la.FusionSolver(anchors, B, antenna_offset=s["offset"], maximum_iteration=10, distance_outlier=3.0)
+    a = la.FusionSolver(anchors, B, antenna_offset=s["offset"], maximum_iteration=10, distance_outlier=3.0, jacobian="analytic")
     a.set_poses(s["init"])
     ref = a.solve(dist, err, s["imu"])
-    b = la.FusionSolver(anchors, B, antenna_offset=s["offset"], maximum_iteration=10, distance_outlier=3.0)
+    b = la.FusionSolver(anchors, B, antenna_offset=s["offset"], maximum_iteration=10, distance_outlier=3.0, jacobian="analytic")
     b.set_poses(s["init"])
     got = b.solve_stream(dist, err, s["imu"])
     for x, y in zip(ref, got):

@@ -49,7 +49,7 @@ def test_fusion_kernel_reaches_scipy_minima(gpu, gold):
     """6-DoF golden: lever arm + rotation-only prior with the bag's IMU covariance."""
     import localization_amd as la
     A = gold["b_anchors"]; N = gold["b_dist"].shape[0]; cov = float(gold["b_cov"])
-    f = la.FusionSolver(A, N, antenna_offset=gold["b_offset"], maximum_iteration=300, distance_outlier=0.0)
+    f = la.FusionSolver(A, N, antenna_offset=gold["b_offset"], maximum_iteration=300, distance_outlier=0.0, jacobian="analytic")
     init = np.zeros((7, N)); init[:3] = gold["b_init_t"].T; init[6] = 1.0
     f.set_poses(init)
     imu = np.zeros((1, N, 8)); imu[0, :, :4] = gold["b_imu_q_xyzw"]; imu[0, :, 4:7] = cov
@@ -78,7 +78,7 @@ def test_window_kernel_reaches_scipy_minima(gpu, gold):
                 wb.add_range(i, k - 1, k, 0.0, 1.0 / sig_v ** 2)
         for j, m in enumerate((1, 2)):
             wb.add_range(i, T - 1, m, float(gold["c_extra"][i, j]), 1.0 / 0.055 ** 2, anchor=True)
-    solver = la.WindowSolver(anchors, N, T, 2 * T + 2, 0, 0, maximum_iteration=500)
+    solver = la.WindowSolver(anchors, N, T, 2 * T + 2, 0, 0, maximum_iteration=500, jacobian="analytic")
     solver.solve(wb)
     solver.close()
     got = wb.poses[:, :, 9:]

@@ -139,7 +139,7 @@ def test_uwb_imu_lidar_two_priors_per_vertex_T20(gpu, bag):
     pos = np.concatenate([bag["anchor_pos"], [[0.0, 0.0, 1.0]]])
     cfg = dict(trajectory_length=18, maximum_velocity=2.0, distance_outlier=5.0, maximum_iteration=10,
                minimum_optimize_error=1e9, publish_range=True, publish_pose=False)
-    node = la.LocalizationNode(ids, pos, **cfg)
+    node = la.LocalizationNode(ids, pos, **cfg, jacobian="analytic")
     ora = O.LocalizationOracle(ids, pos, jac_mode=O.JAC_ANALYTIC, **cfg)
     t, worst, solves = 50.0, 0.0, 0
     cov = (np.eye(6) * 1e-3).ravel()
@@ -172,7 +172,8 @@ def test_heterogeneous_fleet_and_failed_call_leaves_node_untouched(gpu, bag):
     ids = list(bag["anchor_ids"]) + [200]
     pos = np.concatenate([bag["anchor_pos"], [[0.0, 0.0, 1.0]]])
     base = dict(trajectory_length=6, maximum_velocity=5.0, distance_outlier=1.0, minimum_optimize_error=2000.0, publish_range=True)
-    variants = [dict(maximum_iteration=3), dict(maximum_iteration=10), dict(maximum_iteration=10, jacobian="numeric"), dict(maximum_iteration=3)]
+    variants = [dict(maximum_iteration=3, jacobian="analytic"), dict(maximum_iteration=10, jacobian="analytic"), dict(maximum_iteration=10, jacobian="numeric"),
+                dict(maximum_iteration=3, jacobian="analytic")]
     solo = [la.LocalizationNode(ids, pos, **base, **v) for v in variants]
     fleet = [la.LocalizationNode(ids, pos, **base, **v) for v in variants]
     for n in fleet: n.set_deferred(True)
@@ -278,7 +279,7 @@ def test_pose_twist_lidar_factors_match_oracle(gpu):
     pos = np.concatenate([anch, [[0.0, 0.0, 1.0]]])
     cfg = dict(trajectory_length=8, maximum_velocity=2.0, distance_outlier=5.0, maximum_iteration=10,
                minimum_optimize_error=1e9, publish_range=True, publish_pose=True, publish_twist=True, publish_lidar=True)
-    node = la.LocalizationNode(ids, pos, **cfg)
+    node = la.LocalizationNode(ids, pos, **cfg, jacobian="analytic")
     ora = O.LocalizationOracle(ids, pos, jac_mode=O.JAC_ANALYTIC, **cfg)
     rng = np.random.default_rng(3)
     truth = np.array([0.4, -0.3, 1.1])
@@ -325,7 +326,7 @@ def test_uwb_pose_500_pose_window(gpu):
     pos = np.concatenate([anch, [[0.0, 0.0, 1.0]]])
     cfg = dict(trajectory_length=500, maximum_velocity=0.5, distance_outlier=1.0, maximum_iteration=10,
                minimum_optimize_error=1e9, publish_range=False, publish_pose=False)
-    node = la.LocalizationNode(ids, pos, **cfg)
+    node = la.LocalizationNode(ids, pos, **cfg, jacobian="analytic")
     ora = O.LocalizationOracle(ids, pos, jac_mode=O.JAC_ANALYTIC, **cfg)
     rng = np.random.default_rng(11)
     truth = np.array([0.0, 0.0, 1.0])
@@ -360,7 +361,7 @@ def test_relative_range_mode_moving_responders(gpu):
     pos = np.array([[3.0, -3.0, 0.5], [3.0, 3.0, 2.0], [-3.0, 0.0, 1.0], [0.2, 0.1, 1.0]])
     cfg = dict(trajectory_length=4, maximum_velocity=1.0, distance_outlier=5.0, maximum_iteration=10,
                minimum_optimize_error=1e9, publish_range=True, has_relative_range=True)
-    node = la.LocalizationNode(ids, pos.ravel(), **cfg)
+    node = la.LocalizationNode(ids, pos.ravel(), **cfg, jacobian="analytic")
     ora = O.LocalizationOracle(ids, pos.ravel(), jac_mode=O.JAC_ANALYTIC, **cfg)
     truth = pos.copy()
     rng = np.random.default_rng(5)
@@ -394,7 +395,7 @@ def test_rl_range_edges_match_oracle(gpu):
     #  iterations per message keep the comparison on the deterministic part: same graph, same factors, same LM steps.)
     cfg = dict(trajectory_length=5, maximum_velocity=2.0, maximum_iteration=4, minimum_optimize_error=1e9,
                has_relative_range=True, publish_relative_range=True)
-    node = la.LocalizationNode(ids, pos.ravel(), **cfg)
+    node = la.LocalizationNode(ids, pos.ravel(), **cfg, jacobian="analytic")
     ora = O.LocalizationOracle(ids, pos.ravel(), jac_mode=O.JAC_ANALYTIC, **cfg)
     rng = np.random.default_rng(8)
     truth = pos.copy()
@@ -494,8 +495,8 @@ def test_fleet_batch_equals_one_by_one(gpu, bag):
                minimum_optimize_error=2000.0, publish_range=True)
     N = 24
     rng = np.random.default_rng(0)
-    solo = [la.LocalizationNode(ids, pos, **cfg) for _ in range(N)]
-    fleet = [la.LocalizationNode(ids, pos, **cfg) for _ in range(N)]
+    solo = [la.LocalizationNode(ids, pos, **cfg, jacobian="analytic") for _ in range(N)]
+    fleet = [la.LocalizationNode(ids, pos, **cfg, jacobian="analytic") for _ in range(N)]
     for n in fleet:
         n.set_deferred(True)
     noise = rng.normal(0, 0.02, (N, 40))
@@ -521,7 +522,7 @@ def test_node_errors(gpu, bag):
     import localization_amd as la
     ids = list(bag["anchor_ids"]) + [200]
     pos = np.concatenate([bag["anchor_pos"], [[0.0, 0.0, 1.0]]])
-    node = la.LocalizationNode(ids, pos, trajectory_length=4, publish_range=True)
+    node = la.LocalizationNode(ids, pos, trajectory_length=4, publish_range=True, jacobian="analytic")
     with pytest.raises(la.LocalizationAmdError) as e:
         node.add_range(200, 177, 1.0, 3.0, 0.055)         # reference: std::map::at throws (localization.cpp:306)
     assert e.value.code == -4
@@ -569,3 +570,9 @@ def test_one_command_bag_replay_tool(gpu, bag, tmp_path):
     assert rep["solves"] == len(rt) and rep["published"] == int(pub.sum()) == len(logged)
     assert np.abs(logged[:, 1:4] - rt[pub.astype(bool), 1:4]).max() < 1e-5   # '%g' keeps 6 significant digits
     assert rep["ate_realtime"]["pairs"] > 100 and rep["ate_realtime"]["rmse"] < 0.25
+    # Localization::~Localization (localization.cpp:708-717): path[T/2 .. T-1] appended to the optimized log at shutdown
+    opt = ate.read_tum(rep["files"]["optimized"])
+    assert rep["optimized_rows_flushed_at_exit"] == 5 and len(opt) == rep["published"] + 5
+    tail = node.path(200)[5:10]
+    assert np.abs(opt[-5:, 0] - tail[:, 0]).max() < 1e-6 and np.abs(opt[-5:, 1:4] - tail[:, 1:4]).max() < 1e-5
+    assert np.abs(opt[-5, 1:4] - opt[-6, 1:4]).max() < 1e-5    # (path[T/2] was already logged by the last publish)

@@ -107,7 +107,7 @@ def test_all_ranges_gated_or_invalid(gpu):
     s["err"][:, :, 64:128] = 0.0          # invalid sigma: slot unused
     s["dist"][:, :, 128:160] = np.nan
     s["init"][:, 160:] = s["truth"][0][:, 160:] + 0.05   # the ordinary tags start near the truth (gate is on at once)
-    solver = la.SnapshotSolver(ANCHORS_8, B, maximum_iteration=10, distance_outlier=1.0, gate_warmup_epochs=0)
+    solver = la.SnapshotSolver(ANCHORS_8, B, maximum_iteration=10, distance_outlier=1.0, gate_warmup_epochs=0, jacobian="analytic")
     solver.set_positions(s["init"])
     pos, chi2, trials = solver.solve(s["dist"], s["err"])
     solver.close()
@@ -136,7 +136,7 @@ def test_full_size_properties(gpu):
     B, K = 65536, 4
     s = make_snapshot_stream(B, K, seed=21)
     def run(dist, err, init, lpi=2, split=False):
-        solver = la.SnapshotSolver(ANCHORS_8, B, maximum_iteration=10, distance_outlier=1.0, lanes_per_instance=lpi)
+        solver = la.SnapshotSolver(ANCHORS_8, B, maximum_iteration=10, distance_outlier=1.0, lanes_per_instance=lpi, jacobian="analytic")
         solver.set_positions(init)
         if split:
             outs = [solver.solve(dist[k:k + 1], err[k:k + 1]) for k in range(K)]
@@ -172,7 +172,7 @@ def test_device_resident_path_and_timing(gpu):
     from localization_amd.synthetic import ANCHORS_8, make_snapshot_stream_torch
     B, K = 8192, 8
     s = make_snapshot_stream_torch(B, K, seed=4, device=gpu)
-    solver = la.SnapshotSolver(ANCHORS_8, B, maximum_iteration=10)
+    solver = la.SnapshotSolver(ANCHORS_8, B, maximum_iteration=10, jacobian="analytic")
     solver.set_positions(s["init"])
     out_pos, out_chi2, out_trials = solver.alloc_outputs(K)
     solver.timing_begin(4)
@@ -180,7 +180,7 @@ def test_device_resident_path_and_timing(gpu):
     torch.cuda.synchronize()
     n, tot, avg = solver.timing_end()
     assert n == 1 and tot > 0
-    host = la.SnapshotSolver(ANCHORS_8, B, maximum_iteration=10)
+    host = la.SnapshotSolver(ANCHORS_8, B, maximum_iteration=10, jacobian="analytic")
     host.set_positions(s["init"])
     d = la.unpack_ranges(s["dist_tiles"].cpu().numpy(), 8); e = la.unpack_ranges(s["err_tiles"].cpu().numpy(), 8)
     pos, chi2, trials = host.solve(d, e)
@@ -201,10 +201,10 @@ def test_pipelined_host_path_equals_the_staged_one(gpu, B, K, M):
     s = make_snapshot_stream(B, K, seed=3)
     anchors = ANCHORS_8[:M]
     dist, err = s["dist"][:, :M], s["err"][:, :M]
-    a = la.SnapshotSolver(anchors, B, maximum_iteration=10, distance_outlier=1.0)
+    a = la.SnapshotSolver(anchors, B, maximum_iteration=10, distance_outlier=1.0, jacobian="analytic")
     a.set_positions(s["init"])
     ref = a.solve(dist, err)
-    b = la.SnapshotSolver(anchors, B, maximum_iteration=10, distance_outlier=1.0)
+    b = la.SnapshotSolver(anchors, B, maximum_iteration=10, distance_outlier=1.0, jacobian="analytic")
     b.set_positions(s["init"])
     got = b.solve_stream(dist, err)
     for x, y in zip(ref, got):
@@ -243,10 +243,33 @@ def test_degenerate_inputs_start_on_an_anchor_and_non_finite_ranges(gpu):
     d = s["dist"].copy(); e = s["err"].copy()
     d[0, 0, :8] = np.nan; d[1, 1, :8] = np.inf; d[2, 5, :8] = -np.inf
     e[0, 2, :8] = 0.0; e[1, 3, :8] = -1.0; e[2, 4, :8] = np.nan
-    sol = la.SnapshotSolver(ANCHORS_8, B, maximum_iteration=10, distance_outlier=1.0)
+    sol = la.SnapshotSolver(ANCHORS_8, B, maximum_iteration=10, distance_outlier=1.0, jacobian="analytic")
     sol.set_positions(s["init"])
     gp, gc, _ = sol.solve(d, e)
     rp, rc, _, _ = O.snapshot_batch(ANCHORS_8, d, e, s["init"], iterations=10, gate=1.0, jac_mode=O.JAC_ANALYTIC, gate_from_epoch=1)
     assert np.isfinite(gp).all() and np.isfinite(gc).all()
     assert np.abs(gp - rp).max() < 1e-9 and np.abs(gc - rc).max() < 1e-9 * max(1.0, np.abs(rc).max())
     sol.close()
+
+
+@pytest.mark.parametrize("lpi", [1, 4])
+def test_robust_chi2_is_a_sum_of_logs_that_does_not_overflow(gpu, lpi):
+    """g2o sums rho = log(1 + chi2_j) edge by edge; the kernels take ONE log of the product, which overflows once eight factors
+    exceed 1e38 each (|e| / sigma > 1e19: distance_err = 1e-23 here).  The guarded kernel falls back to the edge-by-edge sum for such a
+    wave and must follow the oracle's LM decisions; before the guard every trial scored inf and was rejected."""
+    import localization_amd as la
+    from localization_amd.synthetic import ANCHORS_8, make_snapshot_stream
+    from oracle import oracle as O
+    B, K = 64 + 5, 2
+    s = make_snapshot_stream(B, K, seed=3)
+    s["err"] = np.full_like(s["err"], 1e-23)
+    s["err"][:, :, ::2] = 0.055          # every second tag keeps physical sigmas: both kinds share a wave
+    solver = la.SnapshotSolver(ANCHORS_8, B, maximum_iteration=10, distance_outlier=0.0, jacobian="analytic", lanes_per_instance=lpi)
+    solver.set_positions(s["init"])
+    pos, chi2, trials = solver.solve(s["dist"], s["err"])
+    solver.close()
+    rp, rc, rt, _ = O.snapshot_batch(s["anchors"], s["dist"], s["err"], s["init"], iterations=10, gate=0.0, jac_mode=O.JAC_ANALYTIC)
+    assert np.isfinite(pos).all() and np.isfinite(rp).all()
+    assert (rt[:, 1::2] < 100).all() and (trials[:, 1::2] == rt[:, 1::2]).mean() > 0.9      # steps are accepted, not all rejected
+    assert np.abs(pos - rp).max() < 1e-6, np.abs(pos - rp).max()
+    assert np.abs(chi2 - rc).max() <= 1e-6 * np.abs(rc).max()

@@ -140,7 +140,7 @@ def test_window_analytic_kernel_vs_numeric_oracle_cfg5(gpu):
     import bench_window as bw
     B = 16
     wb, graphs, anchors, T = bw.build_pose64(B, np.random.default_rng(5))
-    solver = la.WindowSolver(anchors, B, *wb.caps, maximum_iteration=10, bw_max=8)
+    solver = la.WindowSolver(anchors, B, *wb.caps, maximum_iteration=10, bw_max=8, jacobian="analytic")
     solver.solve(wb)
     solver.close()
     _, want = bw.oracle_time(graphs, anchors, T, B)
@@ -164,7 +164,7 @@ def test_elimination_order_is_transparent(gpu):
     out = {}
     for natural in (False, True):
         wb.poses[:] = poses0
-        solver = la.WindowSolver(anchors, B, *wb.caps, maximum_iteration=10, bw_max=8, natural_order=natural)
+        solver = la.WindowSolver(anchors, B, *wb.caps, maximum_iteration=10, bw_max=8, natural_order=natural, jacobian="analytic")
         res = solver.solve(wb).copy()
         solver.close()
         out[natural] = (wb.poses.copy(), res)
@@ -173,7 +173,7 @@ def test_elimination_order_is_transparent(gpu):
     assert (blocks == 64 + 63).all() and (lev == 6).all(), (lev, blocks)
     assert (out[True][1][:, 7] % 65536 > 300).all()          # the caller's (time) order fills the 8-pose band
     wb2, _, anch2, T2 = bw.build(4, "uwb_only")
-    s2 = la.WindowSolver(anch2, 4, *wb2.caps, maximum_iteration=10, bw_max=1)
+    s2 = la.WindowSolver(anch2, 4, *wb2.caps, maximum_iteration=10, bw_max=1, jacobian="analytic")
     r2 = s2.solve(wb2)
     s2.close()
     assert (r2[:, 7] % 65536 == 19).all() and (r2[:, 7] // 65536 == 6).all(), r2[:, 7]
@@ -197,7 +197,7 @@ def test_singular_system_fails_like_g2o(gpu):
         for i in range(2): wb.add_range(i, k, k, 2.5, 0.0, anchor=True)
     before = wb.poses.copy()
     n, st = g.optimize(10, O.JAC_ANALYTIC)
-    solver = la.WindowSolver(ANCH, 2, 3, 6, 0, 0)
+    solver = la.WindowSolver(ANCH, 2, 3, 6, 0, 0, jacobian="analytic")
     res = solver.solve(wb)
     solver.close()
     assert st.terminated == 1 and st.lm_trials == 10 and n == 1
@@ -255,7 +255,7 @@ def test_cfg5_full_batch_properties(gpu):
     B = 16384
     wb, graphs, anchors, T = bw.build_pose64(B, np.random.default_rng(0), n_graphs=0)
     poses0 = wb.poses.copy()
-    solver = la.WindowSolver(anchors, B, *wb.caps, maximum_iteration=10, bw_max=8)
+    solver = la.WindowSolver(anchors, B, *wb.caps, maximum_iteration=10, bw_max=8, jacobian="analytic")
     res1 = solver.solve(wb).copy(); p1 = wb.poses.copy()
     wb.poses[:] = poses0
     solver.upload(wb)
@@ -300,7 +300,7 @@ def test_selfcalibration_arrowhead_graph(gpu):
     rng = np.random.default_rng(3)
     T, A, B = 24, 4, 6
     wb, graphs, anchors, nv = bw.build_selfcal(B, rng, T=T, A=A)
-    solver = la.WindowSolver(anchors, B, *wb.caps, maximum_iteration=10)
+    solver = la.WindowSolver(anchors, B, *wb.caps, maximum_iteration=10, jacobian="analytic")
     res = solver.solve(wb)
     solver.close()
     from oracle import oracle as O
@@ -332,7 +332,7 @@ def test_window_empty_and_partial_instances(gpu):
     wb.add_pose(1, [1.0, 2.0, 3.0])                       # pose without any edge
     v = wb.add_pose(2, [0.2, 0.1, 1.0]); wb.add_range(2, v, 0, 3.0, 100.0, anchor=True)
     before = wb.poses.copy()
-    solver = la.WindowSolver(ANCH, 4, 6, 12, 4, 4)
+    solver = la.WindowSolver(ANCH, 4, 6, 12, 4, 4, jacobian="analytic")
     res = solver.solve(wb)
     solver.close()
     assert np.array_equal(wb.poses[0], before[0]) and np.array_equal(wb.poses[1], before[1]) and np.array_equal(wb.poses[3], before[3])
@@ -345,7 +345,7 @@ def test_window_rejects_bad_indices(gpu):
     wb = la.WindowBatch(1, 4, 4, 0, 0)
     wb.add_pose(0, [0, 0, 1.0])
     wb.add_range(0, 0, 9, 1.0, 1.0, anchor=True)          # anchor 9 does not exist
-    solver = la.WindowSolver(ANCH, 1, 4, 4, 0, 0)
+    solver = la.WindowSolver(ANCH, 1, 4, 4, 0, 0, jacobian="analytic")
     with pytest.raises(la.LocalizationAmdError):
         solver.solve(wb)
     solver.close()
@@ -386,7 +386,7 @@ def test_several_edges_on_one_pair_of_poses(gpu):
         g.optimize(10, O.JAC_ANALYTIC)
         for k in range(T):
             want_t[i, k] = g.estimate(100 + k)[1]
-    solver = la.WindowSolver(ANCH, B, *wb.caps, maximum_iteration=10, bw_max=1)
+    solver = la.WindowSolver(ANCH, B, *wb.caps, maximum_iteration=10, bw_max=1, jacobian="analytic")
     res = solver.solve(wb)
     solver.close()
     assert (res[::2, 6] == 2 * (T - 1)).all() and (res[1::2, 6] == 3 * (T - 1)).all()   # every binary edge is on a shared pair
@@ -547,10 +547,10 @@ def test_skyline_window_matches_chain_kernel_600_poses(gpu):
                     if kk == k: wb.add_range(i, k, a, d, info, off, anchor=True)
                 for (k0, k1, d, info) in smooth:
                     if k1 == k: wb.add_range(i, k0, k1, d, info)
-    sky = la.WindowSolver(ANCH, B, T, nr_max, 0, 0, bw_max=1, chain_threshold=0)
+    sky = la.WindowSolver(ANCH, B, T, nr_max, 0, 0, bw_max=1, chain_threshold=0, jacobian="analytic")
     res_sky = sky.solve(wbs[0]).copy()
     sky.close()
-    chain = la.WindowSolver(ANCH, B, T, nr_max, 0, 0, bw_max=1, chain_threshold=1)
+    chain = la.WindowSolver(ANCH, B, T, nr_max, 0, 0, bw_max=1, chain_threshold=1, jacobian="analytic")
     res_chain = chain.solve(wbs[1]).copy()
     chain.close()
     assert (res_chain[:, 7] == T * 65536 + 2 * T - 1).all() and (res_sky[:, 7] == 0).all()   # (which kernel ran)
@@ -581,7 +581,7 @@ def test_chain_kernel_failed_cholesky_like_g2o(gpu):
                     if k1 == k: wb.add_range(i, k0, k1, d, info)
     before = wb.poses.copy()
     want = [oracle_solve_instance(wb, i, ANCH) for i in range(B)]
-    s = la.WindowSolver(ANCH, B, T, 2 * T, 0, 0, chain_threshold=1)
+    s = la.WindowSolver(ANCH, B, T, 2 * T, 0, 0, chain_threshold=1, jacobian="analytic")
     res = s.solve(wb).copy()
     s.close()
     assert (res[[0, 1, 3, 4], 7] == T * 65536 + 2 * T - 1).all()

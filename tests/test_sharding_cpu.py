@@ -27,6 +27,28 @@ def test_shard_bounds_cover_batch_exactly():
     assert shard_bounds(65536, 3, 8) == (24576, 32768)          # 8 192 tags per GPU at G = 8
 
 
+def test_shard_descriptor_of_the_c_abi():
+    """loc_shard_bounds / loc_shard_plan (include/localization_amd.h): the rule every caller shares — SURVEY §8(e)'s per-GPU slices."""
+    import localization_amd as la
+    from localization_amd.sharding import shard_plan
+    plan = shard_plan(16384, 8, 8)                                 # cfg5: 2 048 windows per GPU at G = 8
+    assert [(r, d, hi - lo) for r, d, lo, hi in plan] == [(r, r, 2048) for r in range(8)]
+    plan = shard_plan(1024, 8, 8)                                  # cfg4: 128 hypotheses per GPU
+    assert plan[3] == (3, 3, 384, 512)
+    plan = shard_plan(10, 4, 2)                                    # ragged: 3 3 3 1, two GPUs per node
+    assert [(d, lo, hi) for _, d, lo, hi in plan] == [(0, 0, 3), (1, 3, 6), (0, 6, 9), (1, 9, 10)]
+    assert shard_plan(2, 4, 4)[3][2:] == (2, 2)                    # trailing ranks may be empty
+    for bad in [(10, 4, 4), (10, -1, 4), (-1, 0, 4), (10, 0, 0)]:
+        with pytest.raises(la.LocalizationAmdError):
+            shard_bounds(*bad)
+    # the pure-arithmetic statement of the same rule
+    for total in [0, 1, 7, 65536, 100003]:
+        for world in [1, 2, 3, 8]:
+            per = -(-total // world)
+            for r in range(world):
+                assert shard_bounds(total, r, world) == (min(r * per, total), min(min(r * per, total) + per, total))
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
     return p

@@ -20,7 +20,7 @@ from localization_amd.synthetic import ANCHORS_8, make_snapshot_stream
 B = 65536
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 s = make_snapshot_stream(B, K, seed=0)
-solver = la.SnapshotSolver(ANCHORS_8, B, maximum_iteration=10, distance_outlier=1.0)
+solver = la.SnapshotSolver(ANCHORS_8, B, maximum_iteration=10, distance_outlier=1.0, jacobian="analytic")
 fp, dp = C.POINTER(C.c_float), C.POINTER(C.c_double)
 res = {"batch": B, "epochs": K, "bytes_over_pcie_per_update": 64 + 33}
 

@@ -8,7 +8,7 @@ for shape in ("uwb_only","uwb_imu"):
         w2 = la.WindowBatch(B, *wb.caps)
         for name in ("counts","poses","r_idx","r_val","p_idx","p_val","s_idx","s_val"):
             getattr(w2,name)[:] = getattr(wb,name)
-        s = la.WindowSolver(anchors, B, *wb.caps, maximum_iteration=10, bw_max=1, chain_threshold=th)
+        s = la.WindowSolver(anchors, B, *wb.caps, maximum_iteration=10, bw_max=1, chain_threshold=th, jacobian="analytic")
         res = s.solve(w2).copy(); s.close()
         outs.append((w2.poses.copy(), res))
     d = np.abs(outs[0][0]-outs[1][0]).reshape(B,-1).max(axis=1)

@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--range-topic", default=None, help="override topic/range (cfg/uwb_only.yaml names /lpsrange, the example bag publishes /uwb_endorange_info)")
     ap.add_argument("--truth-topic", default=None)
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--jacobian", default="numeric", choices=["numeric", "analytic"],
+                    help="numeric = g2o's central differences, the reference's configuration (default); analytic = the opt-in fast mode")
     a = ap.parse_args()
     import localization_amd as la
     from localization_amd import ate, bag
@@ -57,7 +59,7 @@ def main():
             sys.exit(f"cannot infer the moving tag: requesters {tag}; pass --uwb")
         cfg.nodes_id = sorted(anchors) + tag
         cfg.nodes_pos = [v for i in sorted(anchors) for v in anchors[i]] + [0.0, 0.0, 1.0]
-    node = la.LocalizationNode.from_config(cfg, device=a.device)
+    node = la.LocalizationNode.from_config(cfg, device=a.device, jacobian=a.jacobian)
     import time
     realtime, optimized, n_solved, lat = [], [], 0, []
     it = bag.replay(a.bag, node, range_topic, imu_topic)
@@ -70,6 +72,14 @@ def main():
         n_solved += 1
         if o["published"]:
             realtime.append(o["realtime"]); optimized.append(o["optimized"])
+    # Localization::~Localization (localization.cpp:708-717): at shutdown the second half of the window, path[T/2 .. T-1], is
+    # appended to the optimized log (path[T/2] therefore appears twice, as in the reference's file)
+    n_flushed = 0
+    if optimized:
+        path = node.path(cfg.nodes_id[-1])
+        T = int(cfg.trajectory_length)
+        for i in range(T // 2, min(T, len(path))):
+            optimized.append(path[i].copy()); n_flushed += 1
     prefix = a.prefix or os.path.splitext(a.bag)[0]
     os.makedirs(os.path.dirname(os.path.abspath(prefix)), exist_ok=True)
     header = [f"iteration_max:{cfg.maximum_iteration}", f"trajectory_length:{cfg.trajectory_length}", f"maximum_velocity:{cfg.maximum_velocity}"]
@@ -79,7 +89,7 @@ def main():
         ate.write_tum(files[name], np.array(rows).reshape(-1, 8), header=header)
     truth = [e for e in evs if e["kind"] == "truth" and (a.truth_topic is None or e["topic"] == a.truth_topic)]
     rep = {"bag": a.bag, "cfg": a.cfg, "range_topic": range_topic, "imu_topic": imu_topic, "nodes_id": cfg.nodes_id,
-           "solves": n_solved, "published": len(realtime), "files": files}
+           "solves": n_solved, "published": len(realtime), "optimized_rows_flushed_at_exit": n_flushed, "jacobian": a.jacobian, "files": files}
     if len(lat) > 1:   # the first one includes decoding the bag; the reference prints the same figure per solve (localization.cpp:191)
         l = np.array(lat[1:]) * 1e3
         rep["ms_per_solve_incl_feed"] = {"median": float(np.median(l)), "p99": float(np.percentile(l, 99)), "max": float(l.max()),
