@@ -266,7 +266,6 @@ def leg_cfg3(D, args):
     dist = torch.from_numpy(la.pack_ranges(s["dist"])).to(D.dev)
     err = torch.from_numpy(la.pack_ranges(s["err"])).to(D.dev)
     imu = torch.from_numpy(s["imu"]).to(D.dev)
-    f = la.FusionSolver(s["anchors"], B, antenna_offset=s["offset"], maximum_iteration=10, distance_outlier=3.0, device=D.local_rank)
     out_pose = torch.empty((E, 7, B), dtype=torch.float64, device=D.dev)
     out_chi2 = torch.empty((E, B), dtype=torch.float64, device=D.dev)
     kms = []
@@ -279,6 +278,13 @@ def leg_cfg3(D, args):
         torch.cuda.synchronize()
         kms.append(f.last_kernel_ms())
 
+    # the reference's configuration (numeric range Jacobians) first, then the analytic fast mode (`value`)
+    f = la.FusionSolver(s["anchors"], B, antenna_offset=s["offset"], maximum_iteration=10, distance_outlier=3.0, device=D.local_rank, jacobian="numeric")
+    D.timed(step, warmup, steps)
+    kern_ms_num = D.max_over_ranks(float(np.mean(kms[warmup:])))
+    f.close()
+    kms.clear()
+    f = la.FusionSolver(s["anchors"], B, antenna_offset=s["offset"], maximum_iteration=10, distance_outlier=3.0, device=D.local_rank, jacobian="analytic")
     elapsed = D.timed(step, warmup, steps)
     kern_ms = D.max_over_ranks(float(np.mean(kms[warmup:])))   # the slowest rank's kernel time: comparable with the wall-time legs
     upd = float(B) * E
@@ -286,7 +292,10 @@ def leg_cfg3(D, args):
            "metric": "localization updates/sec", "value": upd * D.world / (kern_ms * 1e-3), "unit": "updates/s", "steps": steps,
            "ms_per_step": elapsed / steps * 1e3, "value_note": "updates / kernel time (HIP events on the launch stream): the step also "
            "re-uploads the initial poses, which is not part of the hot path", "scaling": "weak", "dtype": "f64", "batch_per_gpu": B,
-           "epochs_per_step": E,
+           "epochs_per_step": E, "jacobian": "analytic",
+           "value_reference_config": float(B) * E * D.world / (kern_ms_num * 1e-3),
+           "reference_config": {"jacobian": "numeric (g2o central differences)", "kernel": "fusion_lm_kernel<JAC = numeric>", "kernel_ms_avg": kern_ms_num,
+                                "roofline_frac": ALGO_BYTES_CFG3 * float(B) * E / (kern_ms_num * 1e-3) / 1e9 / HBM_PEAK_GBS},
            "roofline": hbm_roofline("fusion_lm_kernel", ALGO_BYTES_CFG3 * upd, kern_ms, len(kms) - warmup, "248 B/update; VALU-issue bound")}
     if D.rank == 0 and D.world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
@@ -310,34 +319,41 @@ def _window_leg(D, args, wb, anchors, bw_max, name, workload, metric, unit, algo
     steps, warmup = max(2, min(args.steps, 5)), 1
     B = wb.B
     poses0 = wb.poses.copy()
-    solver = la.WindowSolver(anchors, B, *wb.caps, maximum_iteration=10, bw_max=bw_max, device=D.local_rank)
-    solver.upload(wb)
 
-    def step(i):
-        solver.solve_resident()
+    def run(jac):
+        """upload once, `steps` timed resident launches; leaves the solution of this mode in wb"""
+        solver = la.WindowSolver(anchors, B, *wb.caps, maximum_iteration=10, bw_max=bw_max, device=D.local_rank, jacobian=jac)
+        wb.poses[:] = poses0
+        solver.upload(wb)
+        for i in range(warmup):
+            solver.solve_resident()
+        D.barrier()
+        solver.timing_begin(steps)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            solver.solve_resident()
+        D.barrier()
+        el = D.max_over_ranks(time.perf_counter() - t0)
+        n_l, _, k_ms = solver.timing_end()
+        solver.download(wb)
+        kind = solver.last_kernel_kind()
+        solver.close()
+        return el, n_l, k_ms, kind
 
-    for i in range(warmup):
-        step(i)
-    D.barrier()
-    solver.timing_begin(steps)
-    t0 = time.perf_counter()
-    for i in range(warmup, warmup + steps):
-        step(i)
-    D.barrier()
-    elapsed = D.max_over_ranks(time.perf_counter() - t0)
-    n_launch, _, kern_ms = solver.timing_end()
-    solver.download(wb)
-    solver.close()
+    # the reference's configuration first (g2o's numeric range Jacobians), then the analytic fast mode (`value`, as in earlier rounds)
+    el_num, _, k_ms_num, kind_num = run("numeric")
+    poses_numeric = wb.poses[:, :, 9:].copy()
+    elapsed, n_launch, kern_ms, kind = run("analytic")
     res = {"workload": workload, "metric": metric, "value": float(total_instances) * steps / elapsed, "unit": unit, "steps": steps,
            "ms_per_step": elapsed / steps * 1e3, "scaling": "strong", "dtype": "f64", "instances_per_gpu": B,
-           "instances_total": int(total_instances), "mean_lm_trials": float(wb.result[:, 4].mean()),
+           "instances_total": int(total_instances), "jacobian": "analytic", "mean_lm_trials": float(wb.result[:, 4].mean()),
            "elimination_levels": float(wb.result[0, 7] // 65536), "factor_blocks": float(int(wb.result[0, 7]) % 65536),
            "root_supernode_poses": float(round((wb.result[0, 7] % 1.0) * 16)),
-           "roofline": hbm_roofline("window_lm_kernel", algo_bytes_per_instance * B, kern_ms, n_launch, name)}
-    nv0 = int(wb.counts[0, 0])
-    if nv0 > 1 and int(wb.result[0, 7]) == nv0 * 65536 + 2 * nv0 - 1 and not res["root_supernode_poses"]:
-        # (the signature of the one-lane-per-window kernel that large batches of chain windows take: pose order, n levels)
-        res["roofline"]["kernel"] = "chain_lm_kernel"
+           "value_reference_config": float(total_instances) * steps / el_num,
+           "reference_config": {"jacobian": "numeric (g2o central differences, delta = 1e-9: types_edge_se3range.h:45-74)", "kernel": kind_num,
+                                "ms_per_step": el_num / steps * 1e3, "kernel_ms_avg": k_ms_num,
+                                "roofline_frac": algo_bytes_per_instance * B / (k_ms_num * 1e-3) / 1e9 / HBM_PEAK_GBS},
+           "roofline": hbm_roofline(kind, algo_bytes_per_instance * B, kern_ms, n_launch, name)}
     tr = window_traffic(leg, D.world) if leg else None
     if tr and "stale" in tr:
         res["roofline"]["stale"] = tr["stale"]
@@ -361,9 +377,11 @@ def _window_leg(D, args, wb, anchors, bw_max, name, workload, metric, unit, algo
                                "sample": f"first {n_cpu} instances ({dt:.1f} s): oracle g2o restatement (dense Cholesky, numeric range Jacobians), 1 thread",
                                "max_abs_diff_vs_gpu_m": float(np.abs(wb.poses[:n_cpu, :, 9:] - want).max()),
                                "median_abs_diff_vs_gpu_m": float(np.median(np.abs(wb.poses[:n_cpu, :, 9:] - want).max(axis=(1, 2)))),
-                               "diff_note": "GPU leg: analytic range Jacobians; oracle: g2o's central differences (the reference's configuration). "
-                                            "The two modes take different LM accept/reject decisions on a few instances (tests/test_gpu_node_parity.py "
-                                            "holds numeric vs numeric and analytic vs analytic to 1e-5 / 1e-7 m)"}
+                               "max_abs_diff_vs_gpu_reference_config_m": float(np.abs(poses_numeric[:n_cpu] - want).max()),
+                               "median_abs_diff_vs_gpu_reference_config_m": float(np.median(np.abs(poses_numeric[:n_cpu] - want).max(axis=(1, 2)))),
+                               "diff_note": "oracle: g2o's central differences (the reference's configuration). *_vs_gpu_m: the analytic GPU leg; "
+                                            "*_reference_config_m: the numeric GPU leg (same mode on both sides).  Unconverged iterates of a few "
+                                            "instances follow different, equally valid LM accept / reject sequences (DESIGN.md §3)"}
         if parity_fn is not None and n_parity > 0:   # the same Jacobian mode on both sides
             same = parity_fn(n_parity)
             res["cpu_baseline"]["max_abs_diff_vs_gpu_same_jacobian_mode_m"] = float(np.abs(wb.poses[:n_parity, :, 9:] - same).max())
@@ -403,7 +421,7 @@ def leg_cfg1_windows(D, args):
     for name in ("counts", "poses", "r_idx", "r_val", "p_idx", "p_val", "s_idx", "s_val"):
         src = getattr(small, name)
         getattr(wb, name)[:] = np.resize(src, (n_mine,) + src.shape[1:])   # (cyclic repetition along the batch axis)
-    return _window_leg(D, args, wb, anchors, 1, "1360 B/window; the kernel is bound by instruction issue and LDS capacity (8 windows per CU), not bytes",
+    return _window_leg(D, args, wb, anchors, 1, "1360 B/window (30 f64 state in + out, 19 edges x (idx, measurement, information)); the lane-per-window kernels are bound by their workspace traffic",
                        "cfg/uwb_only.yaml's sliding window as a batch: 10 poses, 19 range edges (10 to anchors, 9 smoothness), Cauchy, 10 LM iterations",
                        "window solves/sec", "windows/s", 1360.0, total,
                        lambda n: bw.oracle_time(graphs, anchors, T, n)[1], 2048,
@@ -602,6 +620,13 @@ def main():
     if rank == 0:
         if legs:
             res["legs"] = legs
+        num = legs.get("cfg2_numeric", {})
+        # the same workload in the REFERENCE's configuration (EdgeSE3Range has no linearizeOplus: g2o's numeric Jacobians), at top level
+        res["value_reference_config"] = num.get("value")
+        res["reference_config"] = {"jacobian": "numeric (g2o central differences, delta = 1e-9)", "ms_per_step": num.get("ms_per_step"),
+                                   "roofline_frac": (num.get("roofline") or {}).get("frac"),
+                                   "note": "`value` is the analytic-Jacobian fast mode (opt-in through loc_snapshot_params.jacobian); every library "
+                                           "default is the numeric mode measured here"} if num else None
         print(json.dumps(res))
     D.close()
 

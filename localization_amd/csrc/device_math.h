@@ -57,13 +57,17 @@ __device__ __forceinline__ void sqrt_and_rsqrt_fast(double x, double& n, double&
 // log(1 + f) = f - hfsq + s (hfsq + R(s^2)), R a degree-7 minimax polynomial: < 1 ulp (checked against long-double log over
 // [1, 1e300], 7e6 samples: max 0.84 ulp).  About 40 instructions; the general-purpose library log is about 110, and it was a
 // fifth of every LM pass of the snapshot kernel.  inf and NaN pass through.
-__device__ __forceinline__ double fast_log_ge1(double x) {
+// log(x 2^k0): the same kernel for a value kept as (x, k0) — a running product whose exponent was taken out on the way so that it
+// cannot overflow (x 2^k0 >= 1 as for fast_log_ge1)
+__device__ __forceinline__ double fast_log_ge1_scaled(double x, int k0);
+__device__ __forceinline__ double fast_log_ge1(double x) { return fast_log_ge1_scaled(x, 0); }
+__device__ __forceinline__ double fast_log_ge1_scaled(double x, int k0) {
     constexpr double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
                      Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
                      Lg7 = 1.479819860511658591e-01;
     constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
     double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
-    int k = __builtin_amdgcn_frexp_exp(x);
+    int k = __builtin_amdgcn_frexp_exp(x) + k0;
     const int small = m < 0.70710678118654752440 ? 1 : 0;
     m = __builtin_amdgcn_ldexp(m, small);
     k -= small;

@@ -89,6 +89,7 @@ __device__ __forceinline__ Sys6 evaluate6(const Pose& X, const double (&ax)[M8],
     for (int i = 0; i < 6; ++i) s.b[i] = 0.0;
     s.chi = 0.0;
     double prod = 1.0;
+    int kexp = 0;
     const double* R = X.R;
     // antenna position p0 = R o + t (one lever arm for every range of the tag)
     const double p0x = R[0] * ox + R[1] * oy + R[2] * oz + X.t[0];
@@ -151,6 +152,7 @@ __device__ __forceinline__ Sys6 evaluate6(const Pose& X, const double (&ax)[M8],
             s.b[r] = __builtin_fma(-wJ[r], e, s.b[r]);
         }
         prod *= aux;
+        if (j == 3) { kexp = __builtin_amdgcn_frexp_exp(prod); prod = __builtin_amdgcn_frexp_mant(prod); }
         s.chi += chi;
     }
     // ---- rotation prior ---------------------------------------------------------------------------------------
@@ -187,29 +189,9 @@ __device__ __forceinline__ Sys6 evaluate6(const Pose& X, const double (&ax)[M8],
         s.b[3 + r] = bb;
     }
     s.chi += pchi;
-    // Cauchy on the ranges, plain chi2 on the prior.  Sum_j log(1 + chi_j) is ONE log of the product; where the
-    // product overflows (g2o's sum of logs stays finite: eight ranges with |e| / sigma > 1e19 each, never on physical data) the
-    // wave sums the logs edge by edge instead.
-    if (__builtin_expect(__any(!(prod <= DBL_MAX)), 0)) {
-        double ls = 0.0;
-#pragma unroll 1
-        for (int j = 0; j < M8; ++j) {
-            const double dj = ep[(2 * j) * EP_STRIDE], wj = ep[(2 * j + 1) * EP_STRIDE];
-            double e;
-            if (JAC == 0) {
-                const double ux = p0x - ax[j], uy = p0y - ay[j], uz = p0z - az[j];
-                double n, inv;
-                sqrt_and_rsqrt_fast(fmax(ux * ux + uy * uy + uz * uz, 1e-300), n, inv);
-                e = dj - n;
-            } else {
-                e = dj - norm_to_plain(P0, ax[j], ay[j], az[j]);
-            }
-            ls += fast_log_ge1(1.0 + e * (wj * e));
-        }
-        s.rchi = ((prod <= DBL_MAX) ? fast_log_ge1(prod) : ls) + pchi;
-    } else {
-        s.rchi = fast_log_ge1(prod) + pchi;
-    }
+    // Cauchy on the ranges, plain chi2 on the prior.  Sum_j log(1 + chi_j) is ONE log of the product, kept as (mantissa,
+    // exponent) with the exponent taken out after four factors (snapshot_kernel.hip: evaluate): no overflow for float32 inputs.
+    s.rchi = fast_log_ge1_scaled(prod, kexp) + pchi;
     return s;
 }
 

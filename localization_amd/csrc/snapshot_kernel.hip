@@ -95,6 +95,7 @@ __device__ __forceinline__ System evaluate(const double px, const double py, con
                                            const double (&d)[APL], double (&w)[APL], const double gate) {
     System s = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     double prod = 1.0;
+    int kexp = 0;
 #pragma unroll
     for (int j = 0; j < APL; ++j) {
         const double dx = px - ax[j], dy = py - ay[j], dz = pz - az[j];
@@ -128,31 +129,23 @@ __device__ __forceinline__ System evaluate(const double px, const double py, con
         s.h11 = __builtin_fma(wjy, jy, s.h11); s.h12 = __builtin_fma(wjy, jz, s.h12); s.h22 = __builtin_fma(wjz, jz, s.h22);
         s.b0 = __builtin_fma(-wjx, e, s.b0); s.b1 = __builtin_fma(-wjy, e, s.b1); s.b2 = __builtin_fma(-wjz, e, s.b2);
         prod *= aux;
+        if (APL > 4 && j == 3) { kexp = __builtin_amdgcn_frexp_exp(prod); prod = __builtin_amdgcn_frexp_mant(prod); }
         s.chi += chi;
     }
     s.h00 = group_sum<LPI>(s.h00); s.h01 = group_sum<LPI>(s.h01); s.h02 = group_sum<LPI>(s.h02);
     s.h11 = group_sum<LPI>(s.h11); s.h12 = group_sum<LPI>(s.h12); s.h22 = group_sum<LPI>(s.h22);
     s.b0 = group_sum<LPI>(s.b0); s.b1 = group_sum<LPI>(s.b1); s.b2 = group_sum<LPI>(s.b2);
     s.chi = group_sum<LPI>(s.chi);
-    // Sum_j log(1 + chi_j) as ONE log of the product.  The product overflows where g2o's sum of logs stays finite (eight ranges
-    // with |e| / sigma > 1e19 each): a wave that sees that — never on physical data — sums the logs edge by edge instead.
-    const double gp = group_prod<LPI>(prod);
-    if (__builtin_expect(__any(!(gp <= DBL_MAX)), 0)) {
-        double ls = 0.0;
-#pragma unroll 1
-        for (int j = 0; j < APL; ++j) {
-            const double dx = px - ax[j], dy = py - ay[j], dz = pz - az[j];
-            double n;
-            if constexpr (JAC == 0) { double inv; sqrt_and_rsqrt_fast(fmax(dx * dx + dy * dy + dz * dz, 1e-300), n, inv); }
-            else n = range_norm_plain(dx, dy, dz);
-            const double e = d[j] - n;
-            ls += fast_log_ge1(1.0 + e * (w[j] * e));
-        }
-        const double gs = group_sum<LPI>(ls);
-        s.rchi = (gp <= DBL_MAX) ? fast_log_ge1(gp) : gs;
-    } else {
-        s.rchi = fast_log_ge1(gp);
+    // Sum_j log(1 + chi_j) as ONE log of the product, kept as (mantissa, exponent) with the exponent taken out after every four
+    // factors: the product of four factors overflows only beyond |e| / sigma ~ 1e38 each — g2o's edge-by-edge sum of logs stays
+    // finite there too, but float32 distance_err and ranges (the wire format) cannot produce it.
+    if constexpr (LPI > 1) {
+        kexp += __builtin_amdgcn_frexp_exp(prod);
+        prod = __builtin_amdgcn_frexp_mant(prod);
+        prod = group_prod<LPI>(prod);
+        kexp = (int)group_sum<LPI>((double)kexp);
     }
+    s.rchi = fast_log_ge1_scaled(prod, kexp);
     return s;
 }
 
