@@ -19,13 +19,16 @@
 //
 // MI355X mapping.  The 6-DoF lane-per-window kernel (window_kernel.hip: chain_lm_kernel) is bound by HBM: 31 GB of workspace
 // traffic per 65 536 ten-pose windows.  Here a pose is 3 numbers and a block 3x3: the per-trial state shrinks from ~190 to ~36
-// doubles per pose, and the part that makes the round trip inside every LM trial — the factor G and y (written by the forward
-// sweep, read by the back-substitution) and the two translation buffers (state / trial state) — lives in LDS, laid out
-// [entry][lane] (a wave's ds_read_b64 is 512 contiguous bytes: conflict-free), when 15 doubles x nv_max x 64 lanes fit the
-// share of a CU that still leaves two waves per CU (nv_max <= 10: 76.8 KB per wave; G, y alone up to 17 poses).  H (6 + 3 per
+// doubles per pose and lane (~7 GB per 65 536 windows).  Everything is laid out [entry][lane] (every load of the wave is one
+// 512-byte line; a wave's ds_read_b64 is 512 contiguous bytes: conflict-free), in an HBM workspace or — for the factor (G, y) and /
+// or the two translation buffers (state / trial state) — in LDS, as far as that still lets every wave of the batch be resident at
+// once (launch_window_chain3: the kernel is bound by memory latency first, one wave per SIMD, so residency beats LDS; 65 536
+// ten-pose windows: translations in LDS 1.71 ms = 3.8e7 windows/s, all in HBM 1.98 ms, (G, y) + translations in LDS — two waves
+// per CU, two rounds — 2.33 ms; 16 384 windows fit with everything in LDS: 0.99 ms against 1.30 ms from HBM).  H (6 + 3 per
 // pose), the coupling block of each consecutive pair (rank-1 (w J_p) J_{p-1}^T as two 3-vectors when one edge joins the pair,
-// else 9 numbers) and the packed edges stay in an HBM workspace laid out [entry][lane] too (every load of the wave is one
-// 512-byte line), requested one pose ahead.
+// else 9 numbers) and the packed edges are requested one pose ahead.  Tried and dropped: scoring the trial state inside the
+// back-substitution (two dependent sweeps per trial instead of three) with H requested two poses ahead — 144 bytes of scratch
+// spills and no gain (1.77 ms): at 1 024 resident waves the kernel moves ~4 TB/s and is bound by that, not by the sweep count.
 #include "window_kernel.h"
 #include "device_math.h"
 
@@ -604,29 +607,48 @@ hipError_t launch_chain3_t(const WindowArgs& a, double* ws, size_t lds, hipStrea
 
 }  // namespace
 
-// LDS plan: (G, y) and the two translation buffers per lane when 64 lanes x 15 x nv_max doubles leave two waves per CU
-// (<= 78 KB per wave), (G, y) alone when that fits, else everything in the HBM slab.
-int window_chain3_lds_mode(const WindowCaps& c) {
-    const size_t budget = 78 * 1024;
-    if ((size_t)c.nv_max * (chain3w::NGY + chain3w::NT) * 64 * sizeof(double) <= budget) return 2;
-    if ((size_t)c.nv_max * chain3w::NGY * 64 * sizeof(double) <= budget) return 1;
+// LDS plan.  The kernel is bound by memory latency (one wave per SIMD, nothing else to hide a round trip behind), so what matters
+// first is that EVERY wave of the batch is resident at once; LDS comes second.  Candidates, richest first: (G, y) + translations
+// (15 doubles per pose and lane), (G, y) alone (9), the translations alone (6), nothing.  The first one whose footprint still lets
+// all ceil(B / 64) waves onto the chip's CUs at once is taken (measured on 65 536 ten-pose windows, 1 024 waves on 256 CUs:
+// everything in HBM 1.99 ms; (G, y) + translations in LDS — two waves per CU, so two rounds — 2.33 ms; (G, y) alone, three per
+// CU, 2.81 ms).  mode bits: 1 = (G, y) in LDS, 2 = translations in LDS.
+int window_chain3_lds_mode(const WindowCaps& c, long long B, int n_cus) {
+    const long long waves = (B + 63) / 64;
+    const size_t lds_cu = 160 * 1024;
+    const int cand[4] = {3, 1, 2, 0};
+    for (int m : cand) {
+        const size_t per_pose = (m & 1 ? chain3w::NGY : 0) + (m & 2 ? chain3w::NT : 0);
+        const size_t bytes = (size_t)c.nv_max * per_pose * 64 * sizeof(double);
+        if (bytes > lds_cu - 1024) continue;
+        const long long per_cu = bytes ? (long long)(lds_cu / (bytes + 256)) : 8;   // (8: two waves per SIMD at this kernel's register count)
+        if ((per_cu < 8 ? per_cu : 8) * n_cus >= waves) return m;
+    }
     return 0;
 }
 
 hipError_t launch_window_chain3(const WindowArgs& a, double* ws, hipStream_t stream) {
     if (a.B <= 0 || !ws || a.caps.ns_max < 0) return hipErrorInvalidValue;
-    static const int forced = [] { const char* v = getenv("LOCAMD_CHAIN3_LDS"); return v ? atoi(v) : -1; }();   // A/B runs: 0, 1, 2
-    int mode = window_chain3_lds_mode(a.caps);
-    if (forced >= 0 && forced < mode) mode = forced;
-    const size_t per_pose = mode == 2 ? chain3w::NGY + chain3w::NT : (mode == 1 ? chain3w::NGY : 0);
+    static std::atomic<int> n_cus{0};
+    if (!n_cus.load()) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        n_cus.store(n);
+    }
+    int mode = window_chain3_lds_mode(a.caps, a.B, n_cus.load());
+    if (const char* v = getenv("LOCAMD_CHAIN3_LDS")) mode = atoi(v) & 3;   // A/B runs (the footprint must fit: checked below)
+    const size_t per_pose = (mode & 1 ? chain3w::NGY : 0) + (mode & 2 ? chain3w::NT : 0);
     const size_t lds = (size_t)a.caps.nv_max * per_pose * 64 * sizeof(double);
-    const int sel = (a.jacobian ? 3 : 0) + mode;
+    if (lds > 160 * 1024 - 1024) return hipErrorInvalidValue;
+    const int sel = (a.jacobian ? 4 : 0) + mode;
     switch (sel) {
         case 0: return launch_chain3_t<0, false, false>(a, ws, lds, stream);
         case 1: return launch_chain3_t<0, true, false>(a, ws, lds, stream);
-        case 2: return launch_chain3_t<0, true, true>(a, ws, lds, stream);
-        case 3: return launch_chain3_t<1, false, false>(a, ws, lds, stream);
-        case 4: return launch_chain3_t<1, true, false>(a, ws, lds, stream);
+        case 2: return launch_chain3_t<0, false, true>(a, ws, lds, stream);
+        case 3: return launch_chain3_t<0, true, true>(a, ws, lds, stream);
+        case 4: return launch_chain3_t<1, false, false>(a, ws, lds, stream);
+        case 5: return launch_chain3_t<1, true, false>(a, ws, lds, stream);
+        case 6: return launch_chain3_t<1, false, true>(a, ws, lds, stream);
         default: return launch_chain3_t<1, true, true>(a, ws, lds, stream);
     }
 }

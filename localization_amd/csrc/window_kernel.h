@@ -53,7 +53,7 @@ hipError_t launch_window_chain(const WindowArgs& a, double* chain_ws, hipStream_
 
 // translation-only chain windows, one lane per window (chain3_kernel.hip)
 size_t window_chain3_workspace_doubles(const WindowCaps& c, long long B);
-int window_chain3_lds_mode(const WindowCaps& c);   // 0: all state in the HBM slab, 1: (G, y) in LDS, 2: (G, y) and the translations
+int window_chain3_lds_mode(const WindowCaps& c, long long B, int n_cus);   // bit 0: (G, y) in LDS, bit 1: the translations in LDS
 hipError_t launch_window_chain3(const WindowArgs& a, double* ws, hipStream_t stream);
 
 }  // namespace locamd
