@@ -222,9 +222,13 @@ int loc_window_set_chain_threshold(loc_window* w, int64_t min_batch);
  *            identity (what Robot::init, robot.cpp:47, and the default identity antenna offsets, localization.h:170, give:
  *            cfg/uwb_only.yaml on the example bag), priors without rotation information: the 6-DoF problem then reduces EXACTLY
  *            to 3x3 blocks (types_edge_se3range.cpp:105-114 does not see the rotation; SURVEY.md §8(a) note)
- * All three run the same LM and agree to the tolerances of DESIGN.md §3; result[6] / result[7] keep their meaning (the
+ *   ARROW3   arrow3_lm_kernel: one wave per window for TRANSLATION-ONLY windows that are a chain with a small dense border — a
+ *            trajectory whose poses range to up to 16 nodes that are unknowns themselves, held in the LAST pose slots (anchor
+ *            self-calibration, BASELINE config 4; "every node moves", localization.cpp:94-98): block-tridiagonal sweep + the
+ *            border's Schur complement on the f64 matrix cores; taken by windows of more than 64 poses (any batch size)
+ * All of them run the same LM and agree to the tolerances of DESIGN.md §3; result[6] / result[7] keep their meaning (the
  * lane-per-window kernels eliminate in pose order: result[7] = nv * 65536 + 2 nv - 1). */
-enum { LOC_WINDOW_KERNEL_NONE = -1, LOC_WINDOW_KERNEL_GENERAL = 0, LOC_WINDOW_KERNEL_CHAIN = 1, LOC_WINDOW_KERNEL_CHAIN3 = 2 };
+enum { LOC_WINDOW_KERNEL_NONE = -1, LOC_WINDOW_KERNEL_GENERAL = 0, LOC_WINDOW_KERNEL_CHAIN = 1, LOC_WINDOW_KERNEL_CHAIN3 = 2, LOC_WINDOW_KERNEL_ARROW3 = 3 };
 int loc_window_last_kernel_kind(const loc_window* w, int32_t* kind);
 /* Device-resident operation: upload n instances once (same host layouts as loc_window_solve_host), then run
  * loc_window_solve_resident any number of times — each launch starts from the uploaded estimates, is asynchronous on

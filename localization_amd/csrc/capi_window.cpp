@@ -34,6 +34,12 @@ struct loc_window {
     double* d_poses_in = nullptr;   // resident mode: the uploaded initial estimates (every resident solve starts from them)
     double* d_chain_ws = nullptr;   // chain windows (one lane per window, window_kernel.hip: chain_lm_kernel): its workspace
     double* d_chain3_ws = nullptr;  // translation-only chain windows (chain3_kernel.hip)
+    // translation-only chain + dense border windows (arrow3_kernel.hip): per-pose edge lists built on the host, its workspace
+    int32_t *d_anb = nullptr, *d_aeoff = nullptr, *d_aeperm = nullptr, *d_apoff = nullptr, *d_apperm = nullptr;
+    double* d_arrow_ws = nullptr;
+    int arrow_ws_nb = 0;            // border size d_arrow_ws was allocated for
+    int arrow_nb_max = 0;           // largest border of the batch whose lists are on the device
+    std::vector<int32_t> h_anb, h_aeoff, h_aeperm, h_apoff, h_apperm;
     int resident_topology = 0;      // LOC_WINDOW_KERNEL_* the uploaded batch qualifies for by its structure (the batch-size threshold is applied per solve)
     long long chain_min = -1;       // smallest batch that takes a lane-per-window kernel (-1: the default / LOCAMD_CHAIN_MIN_BATCH)
     long long n_resident = 0;
@@ -73,7 +79,7 @@ int loc_window_destroy(loc_window* w) {
     if (!w) return LOC_OK;
     (void)hipSetDevice(w->device);
     void* ptrs[] = {w->d_anchors, w->d_counts, w->d_ridx, w->d_pidx, w->d_sidx, w->d_poses, w->d_rval, w->d_pval, w->d_sval, w->d_result, w->d_workspace, w->d_poses_in,
-                    w->d_chain_ws, w->d_chain3_ws};
+                    w->d_chain_ws, w->d_chain3_ws, w->d_anb, w->d_aeoff, w->d_aeperm, w->d_apoff, w->d_apperm, w->d_arrow_ws};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : w->ev) (void)hipEventDestroy(e);
     if (w->h_stage) (void)hipHostFree(w->h_stage);
@@ -191,57 +197,160 @@ static long long chain_min_batch() {
     static const long long v = [] { const char* e = getenv("LOCAMD_CHAIN_MIN_BATCH"); return e ? atoll(e) : 12288LL; }();
     return v;
 }
-// what the batch qualifies for BY ITS STRUCTURE: LOC_WINDOW_KERNEL_GENERAL, _CHAIN (block-tridiagonal, 6-DoF) or _CHAIN3
-static int batch_topology(const loc_window* w, int64_t n, const int32_t* counts, const double* poses, const int32_t* r_idx, const double* r_val,
+// translation-only (the exact 3-DoF reduction, chain3_kernel.hip / arrow3_kernel.hip): no EdgeSE3, every lever arm zero, every
+// rotation the identity, priors with an identity measurement rotation and no rotation information
+static bool translation_only(const loc_window* w, int64_t n, const int32_t* counts, const double* poses, const double* r_val, const double* p_val) {
+    const locamd::WindowCaps& c = w->caps;
+    static const double I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (w->n_anchors > 500000) return false;   // (the packed endpoint word of chain3 holds 2^19 anchors)
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t* cn = counts + i * 4;
+        if (cn[3] != 0 || cn[0] > 1048575) return false;
+        for (int e = 0; e < cn[1]; ++e) {
+            const double* v = r_val + ((size_t)i * c.nr_max + e) * 5;
+            if (v[2] != 0.0 || v[3] != 0.0 || v[4] != 0.0) return false;
+        }
+        for (int p = 0; p < cn[0]; ++p)
+            if (std::memcmp(poses + ((size_t)i * c.nv_max + p) * 12, I9, sizeof(I9)) != 0) return false;
+        for (int e = 0; e < cn[2]; ++e) {
+            const double* v = p_val + ((size_t)i * c.np_max + e) * 18;
+            if (std::memcmp(v, I9, sizeof(I9)) != 0 || v[15] != 0.0 || v[16] != 0.0 || v[17] != 0.0) return false;
+        }
+    }
+    return true;
+}
+
+// CHAIN + BORDER ("arrowhead": BASELINE config 4, anchor self-calibration — a tag trajectory whose poses range to a few nodes that
+// are unknowns themselves, localization.cpp:94-98).  The border of an instance = its last nb pose slots, nb = the smallest number
+// such that every pose-to-pose edge between NON-consecutive slots has an endpoint there; the other poses form the chain (one edge
+// per consecutive pair at most).  Builds the per-pose edge lists arrow3_lm_kernel walks: a chain pose owns its edges to anchors,
+// to border poses and to the previous chain pose; a border pose owns those to lower-slot border poses and to anchors.
+static bool build_arrow_aux(loc_window* w, int64_t n, const int32_t* counts, const int32_t* r_idx, const int32_t* p_idx) {
+    const locamd::WindowCaps& c = w->caps;
+    int nb_max = 0;
+    w->h_anb.assign((size_t)n, 0);
+    w->h_aeoff.assign((size_t)n * (c.nv_max + 1), 0);
+    w->h_aeperm.assign((size_t)n * (c.nr_max > 0 ? c.nr_max : 1), 0);
+    w->h_apoff.assign((size_t)n * (c.nv_max + 1), 0);
+    w->h_apperm.assign((size_t)n * (c.np_max > 0 ? c.np_max : 1), 0);
+    std::vector<int32_t> owner, fill, pairs;
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t* cn = counts + i * 4;
+        const int nv = cn[0], nr = cn[1], np = cn[2];
+        const int32_t* ri = r_idx + (size_t)i * c.nr_max * 2;
+        int nb = 0;
+        for (int e = 0; e < nr; ++e) {
+            const int v0 = ri[2 * e], v1 = ri[2 * e + 1];
+            if (v1 < 0) continue;
+            const int hi = v0 > v1 ? v0 : v1, lo = v0 > v1 ? v1 : v0;
+            if (hi - lo != 1 && nv - hi > nb) nb = nv - hi;
+        }
+        if (nb < 1 || nb > 16 || nv - nb < 2) return false;
+        const int nc = nv - nb;
+        owner.assign((size_t)(nr > 0 ? nr : 1), 0);
+        pairs.assign((size_t)nc, 0);
+        int32_t* eoff = w->h_aeoff.data() + (size_t)i * (c.nv_max + 1);
+        for (int e = 0; e < nr; ++e) {
+            const int v0 = ri[2 * e], v1 = ri[2 * e + 1];
+            int o;
+            if (v1 < 0) o = v0;
+            else {
+                const int hi = v0 > v1 ? v0 : v1, lo = v0 > v1 ? v1 : v0;
+                if (hi < nc) { o = hi; if (++pairs[hi] > 1) return false; }   // chain-chain (consecutive by the choice of nb): one per pair
+                else if (lo < nc) o = lo;                                         // chain-border: the chain pose
+                else o = hi;                                                      // border-border: the later one
+            }
+            owner[e] = o;
+            ++eoff[o + 1];
+        }
+        for (int v = 0; v < nv; ++v) eoff[v + 1] += eoff[v];
+        fill.assign(eoff, eoff + nv);
+        int32_t* eperm = w->h_aeperm.data() + (size_t)i * c.nr_max;
+        for (int e = 0; e < nr; ++e) eperm[fill[owner[e]]++] = e;   // (stable: a pose's edges keep their creation order)
+        int32_t* poff = w->h_apoff.data() + (size_t)i * (c.nv_max + 1);
+        const int32_t* pi = p_idx + (size_t)i * c.np_max;
+        for (int e = 0; e < np; ++e) ++poff[pi[e] + 1];
+        for (int v = 0; v < nv; ++v) poff[v + 1] += poff[v];
+        fill.assign(poff, poff + nv);
+        int32_t* pperm = w->h_apperm.data() + (size_t)i * c.np_max;
+        for (int e = 0; e < np; ++e) pperm[fill[pi[e]]++] = e;
+        w->h_anb[i] = nb;
+        if (nb > nb_max) nb_max = nb;
+    }
+    if (locamd::window_arrow3_lds_bytes(c, nb_max) > 160 * 1024 - 512) return false;
+    w->arrow_nb_max = nb_max;
+    return true;
+}
+static hipError_t upload_arrow_aux(loc_window* w, int64_t n, hipStream_t st) {
+    const locamd::WindowCaps& c = w->caps;
+    const size_t B = (size_t)w->B;
+    hipError_t e;
+    if (!w->d_anb) {
+        if ((e = hipMalloc((void**)&w->d_anb, B * sizeof(int32_t))) != hipSuccess ||
+            (e = hipMalloc((void**)&w->d_aeoff, B * (c.nv_max + 1) * sizeof(int32_t))) != hipSuccess ||
+            (e = hipMalloc((void**)&w->d_aeperm, B * (c.nr_max > 0 ? c.nr_max : 1) * sizeof(int32_t))) != hipSuccess ||
+            (e = hipMalloc((void**)&w->d_apoff, B * (c.nv_max + 1) * sizeof(int32_t))) != hipSuccess ||
+            (e = hipMalloc((void**)&w->d_apperm, B * (c.np_max > 0 ? c.np_max : 1) * sizeof(int32_t))) != hipSuccess) return e;
+    }
+    if (!w->d_arrow_ws || w->arrow_ws_nb < w->arrow_nb_max) {
+        if (w->d_arrow_ws) (void)hipFree(w->d_arrow_ws);
+        w->d_arrow_ws = nullptr;
+        if ((e = hipMalloc((void**)&w->d_arrow_ws, B * locamd::window_arrow3_workspace_doubles(c, w->arrow_nb_max) * sizeof(double))) != hipSuccess) return e;
+        w->arrow_ws_nb = w->arrow_nb_max;
+    }
+    const size_t N = (size_t)n;
+    if ((e = hipMemcpyAsync(w->d_anb, w->h_anb.data(), N * sizeof(int32_t), hipMemcpyHostToDevice, st)) != hipSuccess ||
+        (e = hipMemcpyAsync(w->d_aeoff, w->h_aeoff.data(), N * (c.nv_max + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st)) != hipSuccess ||
+        (e = hipMemcpyAsync(w->d_aeperm, w->h_aeperm.data(), N * (c.nr_max > 0 ? c.nr_max : 1) * sizeof(int32_t), hipMemcpyHostToDevice, st)) != hipSuccess ||
+        (e = hipMemcpyAsync(w->d_apoff, w->h_apoff.data(), N * (c.nv_max + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st)) != hipSuccess ||
+        (e = hipMemcpyAsync(w->d_apperm, w->h_apperm.data(), N * (c.np_max > 0 ? c.np_max : 1) * sizeof(int32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+    return hipStreamSynchronize(st);   // (the host vectors may be rebuilt by the next call)
+}
+
+// what the batch qualifies for BY ITS STRUCTURE: LOC_WINDOW_KERNEL_GENERAL, _CHAIN (block-tridiagonal, 6-DoF), _CHAIN3 or _ARROW3
+// (for _ARROW3 the edge lists are left in w->h_a*)
+static int batch_topology(loc_window* w, int64_t n, const int32_t* counts, const double* poses, const int32_t* r_idx, const double* r_val,
                           const int32_t* p_idx, const double* p_val, const int32_t* s_idx) {
     const locamd::WindowCaps& c = w->caps;
-    for (int64_t i = 0; i < n; ++i) {
+    bool chain = true;
+    for (int64_t i = 0; i < n && chain; ++i) {
         const int32_t* cn = counts + i * 4;
         int last = 0;
         for (int e = 0; e < cn[3]; ++e) {   // EdgeSE3 factors: between consecutive poses, ordered by their later pose (addTwistEdge)
             const int32_t* ix = s_idx + ((size_t)i * c.ns_max + e) * 4;
             const int key = ix[1] > ix[0] ? ix[1] : ix[0];
-            if (key < last || (ix[0] - ix[1] != 1 && ix[1] - ix[0] != 1)) return LOC_WINDOW_KERNEL_GENERAL;
+            if (key < last || (ix[0] - ix[1] != 1 && ix[1] - ix[0] != 1)) { chain = false; break; }
             last = key;
         }
         last = 0;
-        for (int e = 0; e < cn[1]; ++e) {
+        for (int e = 0; e < cn[1] && chain; ++e) {
             const int32_t* ix = r_idx + ((size_t)i * c.nr_max + e) * 2;
             const int key = ix[1] > ix[0] ? ix[1] : ix[0];
-            if (key < last) return LOC_WINDOW_KERNEL_GENERAL;
+            if (key < last) chain = false;
             last = key;
-            if (ix[1] >= 0 && ix[0] - ix[1] != 1 && ix[1] - ix[0] != 1) return LOC_WINDOW_KERNEL_GENERAL;
+            if (ix[1] >= 0 && ix[0] - ix[1] != 1 && ix[1] - ix[0] != 1) chain = false;
         }
         last = 0;
-        for (int e = 0; e < cn[2]; ++e) {
+        for (int e = 0; e < cn[2] && chain; ++e) {
             const int32_t v = p_idx[(size_t)i * c.np_max + e];
-            if (v < last) return LOC_WINDOW_KERNEL_GENERAL;
+            if (v < last) chain = false;
             last = v;
         }
     }
-    // Translation-only (the exact 3-DoF reduction, chain3_kernel.hip): no EdgeSE3, every lever arm zero, every rotation the
-    // identity, priors with an identity measurement rotation and no rotation information.
-    static const double I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    for (int64_t i = 0; i < n; ++i) {
-        const int32_t* cn = counts + i * 4;
-        if (cn[3] != 0 || cn[0] > 1048575) return LOC_WINDOW_KERNEL_CHAIN;
-        for (int e = 0; e < cn[1]; ++e) {
-            const double* v = r_val + ((size_t)i * c.nr_max + e) * 5;
-            if (v[2] != 0.0 || v[3] != 0.0 || v[4] != 0.0) return LOC_WINDOW_KERNEL_CHAIN;
-        }
-        for (int p = 0; p < cn[0]; ++p)
-            if (std::memcmp(poses + ((size_t)i * c.nv_max + p) * 12, I9, sizeof(I9)) != 0) return LOC_WINDOW_KERNEL_CHAIN;
-        for (int e = 0; e < cn[2]; ++e) {
-            const double* v = p_val + ((size_t)i * c.np_max + e) * 18;
-            if (std::memcmp(v, I9, sizeof(I9)) != 0 || v[15] != 0.0 || v[16] != 0.0 || v[17] != 0.0) return LOC_WINDOW_KERNEL_CHAIN;
-        }
+    if (chain) return translation_only(w, n, counts, poses, r_val, p_val) ? LOC_WINDOW_KERNEL_CHAIN3 : LOC_WINDOW_KERNEL_CHAIN;
+    if (c.ns_max == 0 || true) {
+        // (LOCAMD_ARROW3: 0 = never, 1 = whenever the batch qualifies; default: windows of more than 64 poses — below that the
+        //  wave-per-window kernel keeps everything in LDS and is the better choice)
+        const char* v = getenv("LOCAMD_ARROW3");
+        const bool want = v ? v[0] == '1' : c.nv_max > 64;
+        if (want && translation_only(w, n, counts, poses, r_val, p_val) && build_arrow_aux(w, n, counts, r_idx, p_idx)) return LOC_WINDOW_KERNEL_ARROW3;
     }
-    if (w->n_anchors > 500000) return LOC_WINDOW_KERNEL_CHAIN;   // (the packed endpoint word of chain3 holds 2^19 anchors)
-    return LOC_WINDOW_KERNEL_CHAIN3;
+    return LOC_WINDOW_KERNEL_GENERAL;
 }
 // the kernel a batch of n windows with that structure takes NOW (threshold, ordering override, LOCAMD_CHAIN3=0 for A/B runs)
 static int pick_kernel(const loc_window* w, int64_t n, int topology) {
     const long long mn = w->chain_min >= 0 ? w->chain_min : chain_min_batch();
+    if (topology == LOC_WINDOW_KERNEL_ARROW3) return w->natural_order ? LOC_WINDOW_KERNEL_GENERAL : LOC_WINDOW_KERNEL_ARROW3;   // (one wave per window: any batch size)
     if (topology == LOC_WINDOW_KERNEL_GENERAL || mn <= 0 || n < mn || w->natural_order) return LOC_WINDOW_KERNEL_GENERAL;
     if (topology == LOC_WINDOW_KERNEL_CHAIN3) {   // LOCAMD_CHAIN3=0: the 6-DoF kernel on a translation-only batch (A/B runs, tests; read per call)
         const char* v = getenv("LOCAMD_CHAIN3");
@@ -251,6 +360,12 @@ static int pick_kernel(const loc_window* w, int64_t n, int topology) {
 }
 static hipError_t launch_any(loc_window* w, const locamd::WindowArgs& a, hipStream_t st, int kind) {
     w->last_kind = kind;
+    if (kind == LOC_WINDOW_KERNEL_ARROW3) {
+        locamd::ArrowAux x;
+        x.nb = w->d_anb; x.e_off = w->d_aeoff; x.e_perm = w->d_aeperm; x.p_off = w->d_apoff; x.p_perm = w->d_apperm;
+        x.ws = w->d_arrow_ws; x.nb_max = w->arrow_nb_max;
+        return locamd::launch_window_arrow3(a, x, st);
+    }
     if (kind == LOC_WINDOW_KERNEL_CHAIN3) {
         if (!w->d_chain3_ws) {
             hipError_t e = hipMalloc((void**)&w->d_chain3_ws, locamd::window_chain3_workspace_doubles(w->caps, w->B) * sizeof(double));
@@ -328,7 +443,9 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
             a.anchors = w->d_anchors; a.workspace = w->d_workspace;
             a.n_anchors = w->n_anchors; a.B = (int)n; a.iterations = w->iterations; a.caps = c;
             LOC_HIP(hipEventRecord(w->ev0, st));
-            hipError_t e = launch_any(w, a, st, pick_kernel(w, n, batch_topology(w, n, counts, poses, r_idx, r_val, p_idx, p_val, s_idx)));
+            const int kind = pick_kernel(w, n, batch_topology(w, n, counts, poses, r_idx, r_val, p_idx, p_val, s_idx));
+            if (kind == LOC_WINDOW_KERNEL_ARROW3) LOC_HIP(upload_arrow_aux(w, n, st));
+            hipError_t e = launch_any(w, a, st, kind);
             if (e != hipSuccess) return locamd_fail_hip(e, "launch_window");
             LOC_HIP(hipEventRecord(w->ev1, st));
             LOC_HIP(hipMemcpyAsync(h, d, off[2], hipMemcpyDeviceToHost, st));  // [poses | result]
@@ -361,6 +478,7 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
     a.workspace = w->d_workspace;
     a.n_anchors = w->n_anchors; a.B = (int)n; a.iterations = w->iterations; a.caps = c;
     const int kind = pick_kernel(w, n, batch_topology(w, n, counts, poses, r_idx, r_val, p_idx, p_val, s_idx));
+    if (kind == LOC_WINDOW_KERNEL_ARROW3) LOC_HIP(upload_arrow_aux(w, n, st));
     LOC_HIP(hipEventRecord(w->ev0, st));
     hipError_t e = launch_any(w, a, st, kind);
     if (e != hipSuccess) return locamd_fail_hip(e, "launch_window");
@@ -407,6 +525,7 @@ int loc_window_upload(loc_window* w, int64_t n, const int32_t* counts, const dou
     w->n_resident = n;
     w->resident_solved = false;
     w->resident_topology = batch_topology(w, n, counts, poses, r_idx, r_val, p_idx, p_val, s_idx);
+    if (w->resident_topology == LOC_WINDOW_KERNEL_ARROW3) LOC_HIP(upload_arrow_aux(w, n, w->stream));
     int max_anchor = 0;   // anchors referenced: v1 = -1 - anchor
     for (int64_t i = 0; i < n; ++i)
         for (int e = 0; e < counts[i * 4 + 1]; ++e) {

@@ -56,4 +56,19 @@ size_t window_chain3_workspace_doubles(const WindowCaps& c, long long B);
 int window_chain3_lds_mode(const WindowCaps& c, long long B, int n_cus);   // bit 0: (G, y) in LDS, bit 1: the translations in LDS
 hipError_t launch_window_chain3(const WindowArgs& a, double* ws, hipStream_t stream);
 
+// translation-only chain + dense border windows, one wave per window (arrow3_kernel.hip); the per-pose edge lists are built on
+// the host once per upload (capi_window.cpp: build_arrow_aux)
+struct ArrowAux {
+    const int32_t* nb;      // [B] border poses of each instance (its last nb pose slots)
+    const int32_t* e_off;   // [B][nv_max + 1] CSR offsets of the range edges by OWNER pose (a chain pose owns its edges to anchors, to
+    const int32_t* e_perm;  // [B][nr_max]     border poses and to the previous chain pose; a border pose those to lower-slot border poses / anchors)
+    const int32_t* p_off;   // [B][nv_max + 1] priors by pose
+    const int32_t* p_perm;  // [B][np_max]
+    double* ws;             // [B][window_arrow3_workspace_doubles]
+    int nb_max;             // largest border in the batch (<= 16)
+};
+size_t window_arrow3_workspace_doubles(const WindowCaps& c, int nb_max);
+size_t window_arrow3_lds_bytes(const WindowCaps& c, int nb_max);
+hipError_t launch_window_arrow3(const WindowArgs& a, const ArrowAux& x, hipStream_t stream);
+
 }  // namespace locamd

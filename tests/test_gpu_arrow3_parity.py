@@ -1,0 +1,155 @@
+"""GPU parity of arrow3_lm_kernel (arrow3_kernel.hip) — translation-only windows that are a chain with a small dense border:
+BASELINE config 4's anchor self-calibration shape — against the 6-DoF oracle (the g2o restatement with full poses and a dense
+solve) and against the general wave-per-window kernel on the same graphs.
+
+Tolerances (fp64 on both sides, the reference's fixed 10 iterations): analytic vs analytic 1e-6 m (the Schur-complement order of
+the sums differs from both the oracle's dense Cholesky and the general kernel's nested dissection; poorly observed anchor
+hypotheses amplify last-bit differences), numeric vs numeric 1e-4 m — the bounds test_selfcalibration_cfg4_real_shape has used
+for this shape since round 1.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FIXED = np.array([[4.0, -4.0, 0.5], [-4.0, 4.0, 2.5]])   # two surveyed anchors next to the unknown ones
+
+
+def _copy_batch(la, wb):
+    out = la.WindowBatch(wb.B, *wb.caps)
+    for name in ("counts", "poses", "r_idx", "r_val", "p_idx", "p_val", "s_idx", "s_val"):
+        getattr(out, name)[:] = getattr(wb, name)
+    return out
+
+
+def _arrow_batch(la, rng, B, T, A, rich):
+    """Hypotheses in build_selfcal's slot order (tag poses first, unknown anchors last).  rich: ragged trajectory lengths and border
+    sizes, a missing smoothness link, doubled (pose, anchor) ranges, ranges to surveyed anchors, ranges between unknown anchors,
+    z priors on some tag poses."""
+    nr_max = T * (A + 2) + A * A + 4
+    wb = la.WindowBatch(B, T + A, nr_max, A + T, 0)
+    true_anchors = np.column_stack([rng.uniform(-4, 4, A), rng.uniform(-4, 4, A), rng.uniform(0, 3, A)])
+    tt = np.cumsum(rng.normal(0, 0.05, (T, 3)), axis=0) + np.array([0.0, 0.0, 1.2])
+    for i in range(B):
+        Ti = T - (3 * i) % 7 if rich else T
+        Ai = max(A - i % 3, 1) if rich else A
+        hyp = true_anchors[:Ai] + rng.normal(0, 1.0, (Ai, 3))
+        et = tt[:Ti] + rng.normal(0, 0.05, (Ti, 3))
+        for k in range(Ti): wb.add_pose(i, et[k])
+        for a in range(Ai):
+            wb.add_pose(i, hyp[a]); wb.add_prior(i, Ti + a, hyp[a], np.eye(3), np.array([1.0, 1.0, 1.0, 0, 0, 0]))
+        for k in range(Ti):
+            for a in range(Ai):
+                if rich and (k + a + i) % 11 == 0:
+                    continue                                                  # a missed range
+                d = float(np.float32(np.linalg.norm(tt[k] - true_anchors[a]) + rng.normal(0, 0.03)))
+                if rich and (k + a) % 13 == 5:
+                    wb.add_range(i, Ti + a, k, d, 1 / 0.055 ** 2)             # stored the other way round
+                else:
+                    wb.add_range(i, k, Ti + a, d, 1 / 0.055 ** 2)
+                if rich and (k * 7 + a) % 29 == 3:
+                    wb.add_range(i, k, Ti + a, d + 0.01, 0.5 / 0.055 ** 2)    # a second range on the same (pose, anchor) pair
+            if rich and k % 5 == 0:
+                f = k % 2
+                wb.add_range(i, k, f, float(np.float32(np.linalg.norm(tt[k] - FIXED[f]) + rng.normal(0, 0.03))), 1 / 0.055 ** 2, anchor=True)
+            if k and not (rich and i % 4 == 1 and k == Ti // 2):
+                wb.add_range(i, k - 1, k, 0.0, 1 / (5.0 / 32 / 3) ** 2)
+            if rich and k % 9 == 4:
+                wb.add_prior(i, k, np.array([et[k, 0], et[k, 1], tt[k, 2]]), np.eye(3), np.array([0, 0, 1 / 0.05, 0, 0, 0.0]))
+        if rich:
+            for a in range(1, Ai):                                            # ranges between unknown anchors; one pair twice
+                b = (a * 5 + i) % a
+                wb.add_range(i, Ti + a, Ti + b, float(np.linalg.norm(true_anchors[a] - true_anchors[b]) + rng.normal(0, 0.03)), 1 / 0.055 ** 2)
+            if Ai > 1:
+                wb.add_range(i, Ti, Ti + 1, float(np.linalg.norm(true_anchors[0] - true_anchors[1])), 1 / 0.1 ** 2)
+            wb.add_range(i, Ti + Ai - 1, 0, float(np.linalg.norm(true_anchors[Ai - 1] - FIXED[0])), 1 / 0.055 ** 2, anchor=True)
+    return wb
+
+
+@pytest.mark.parametrize("T,A,rich,jac", [
+    (24, 4, False, "analytic"),     # the miniature of config 4
+    (24, 4, True, "analytic"),      # ragged everything (see _arrow_batch)
+    (24, 4, True, "numeric"),       # the reference's Jacobian mode
+    (70, 6, True, "analytic"),      # two chunks of chain poses, two row tiles of border rows
+    (40, 12, True, "analytic"),     # 36 border rows: three row tiles
+    (130, 3, False, "numeric"),
+])
+def test_arrow3_kernel_matches_6dof_oracle_and_general_kernel(gpu, T, A, rich, jac):
+    import localization_amd as la
+    from oracle import oracle as O
+    from _oracle_window import oracle_solve_instance
+    B = 7
+    rng = np.random.default_rng(100 * T + A + len(jac))
+    wb = _arrow_batch(la, rng, B, T, A, rich)
+    before = wb.poses.copy()
+    ref = _copy_batch(la, wb)
+    mode = O.JAC_ANALYTIC if jac == "analytic" else O.JAC_NUMERIC_G2O
+    want = [oracle_solve_instance(wb, i, FIXED, jac_mode=mode) for i in range(B)]
+    os.environ["LOCAMD_ARROW3"] = "0"
+    try:
+        g = la.WindowSolver(FIXED, B, *wb.caps, jacobian=jac)
+        res_g = g.solve(ref).copy()
+        assert g.last_kernel_kind() == "window_lm_kernel"
+        g.close()
+        os.environ["LOCAMD_ARROW3"] = "1"
+        s = la.WindowSolver(FIXED, B, *wb.caps, jacobian=jac)
+        res = s.solve(wb).copy()
+        assert s.last_kernel_kind() == "arrow3_lm_kernel"
+        # resident path: the same bits
+        wb2 = _copy_batch(la, wb); wb2.poses[:] = before
+        s.upload(wb2); s.solve_resident(); s.download(wb2)
+        assert s.last_kernel_kind() == "arrow3_lm_kernel"
+        s.close()
+    finally:
+        del os.environ["LOCAMD_ARROW3"]
+    tol = 1e-6 if jac == "analytic" else 1e-4
+    for i in range(B):
+        nv = int(wb.counts[i, 0])
+        poses, chi, st = want[i]
+        assert np.array_equal(wb.poses[i, :nv, :9], before[i, :nv, :9])
+        d = np.abs(wb.poses[i, :nv] - poses).max()
+        dg = np.abs(ref.poses[i, :nv] - poses).max()          # the general kernel's own distance from the oracle
+        # numeric vs numeric: the difference quotients (delta = 1e-9) of a poorly observed hypothesis (two or three ranged anchors, a
+        # metre off) amplify the last bits of ANY two implementations — the wave-per-window kernel is just as far from the oracle
+        # on those instances (1e-2 m on the worst one here); the bound is that kernel's own distance
+        lim = tol if jac == "analytic" else max(tol, 3.0 * dg)
+        assert d < lim, (i, d, dg)
+        crel, cgrel = abs(res[i, 0] - chi) / max(1.0, abs(chi)), abs(res_g[i, 0] - chi) / max(1.0, abs(chi))
+        assert crel <= (1e-6 if jac == "analytic" else max(1e-3, 5.0 * cgrel)), (i, res[i, 0], chi)
+        assert res[i, 3] == st.outer_iterations
+        assert np.array_equal(wb2.poses[i, :nv], wb.poses[i, :nv])
+    assert np.array_equal(wb2.result, res)
+    if jac == "analytic":
+        assert np.abs(wb.poses - ref.poses).max() < tol
+    assert np.array_equal(res[:, 6], res_g[:, 6])                 # pose-to-pose edges that share their pair with another edge
+    assert (res[:, 4] != res_g[:, 4]).mean() < 0.3               # LM trial counts (rejections happen on these graphs: ties do occur)
+
+
+def test_arrow3_is_taken_by_large_translation_only_arrowheads_only(gpu):
+    import localization_amd as la
+    rng = np.random.default_rng(1)
+    big = _arrow_batch(la, rng, 2, 70, 4, False)        # 74 poses: beyond the wave-per-window kernel's in-LDS range
+    s = la.WindowSolver(FIXED, 2, *big.caps, jacobian="analytic")
+
+    def kind(mut):
+        wb = _copy_batch(la, big)
+        mut(wb)
+        s.solve(wb)
+        return s.last_kernel_kind()
+
+    assert kind(lambda wb: None) == "arrow3_lm_kernel"
+    def lever(wb): wb.r_val[1, 5, 2:5] = (0.0, 0.01, 0.0)
+    def turned(wb): wb.poses[0, 3, :9] = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1.0]]).reshape(9)
+    def rot_info(wb): wb.p_val[0, 0, 15] = 1e-3
+    def second_link(wb): wb.add_range(0, 10, 11, 0.01, 50.0)           # two edges on one consecutive chain pair
+    def long_link(wb): wb.add_range(0, 10, 40, 1.0, 50.0)              # a loop closure inside the chain: the border would be 34 poses
+    for mut in (lever, turned, rot_info, second_link, long_link):
+        assert kind(mut) == "window_lm_kernel", mut.__name__
+    s.close()
+    small = _arrow_batch(la, rng, 2, 24, 4, False)      # 28 poses: the wave-per-window kernel keeps it in LDS
+    s = la.WindowSolver(FIXED, 2, *small.caps, jacobian="analytic")
+    s.solve(small)
+    assert s.last_kernel_kind() == "window_lm_kernel"
+    s.close()

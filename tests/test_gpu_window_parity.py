@@ -226,6 +226,7 @@ def test_selfcalibration_cfg4_real_shape(gpu):
         wb.poses[:] = poses0
         solver = la.WindowSolver(anchors, B, *wb.caps, maximum_iteration=10, bw_max=nv - 1, jacobian=jac)
         res = solver.solve(wb).copy()
+        assert solver.last_kernel_kind() == "arrow3_lm_kernel"   # (translation-only chain + border of 10: arrow3_kernel.hip)
         solver.close()
         assert np.isfinite(wb.poses).all()
         worst = 0.0
