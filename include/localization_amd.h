@@ -223,9 +223,10 @@ int loc_window_set_chain_threshold(loc_window* w, int64_t min_batch);
  *            cfg/uwb_only.yaml on the example bag), priors without rotation information: the 6-DoF problem then reduces EXACTLY
  *            to 3x3 blocks (types_edge_se3range.cpp:105-114 does not see the rotation; SURVEY.md §8(a) note)
  *   ARROW3   arrow3_lm_kernel: one wave per window for TRANSLATION-ONLY windows that are a chain with a small dense border — a
- *            trajectory whose poses range to up to 16 nodes that are unknowns themselves, held in the LAST pose slots (anchor
- *            self-calibration, BASELINE config 4; "every node moves", localization.cpp:94-98): block-tridiagonal sweep + the
- *            border's Schur complement on the f64 matrix cores; taken by windows of more than 64 poses (any batch size)
+ *            trajectory whose poses range to up to 12 nodes that are unknowns themselves, held in the LAST pose slots (anchor
+ *            self-calibration, BASELINE config 4; "every node moves", localization.cpp:94-98): the chain cut into four segments
+ *            (one wave each), block-tridiagonal sweeps + the border's Schur complement on the f64 matrix cores; taken by
+ *            windows of more than 64 poses (any batch size)
  * All of them run the same LM and agree to the tolerances of DESIGN.md §3; result[6] / result[7] keep their meaning (the
  * lane-per-window kernels eliminate in pose order: result[7] = nv * 65536 + 2 nv - 1). */
 enum { LOC_WINDOW_KERNEL_NONE = -1, LOC_WINDOW_KERNEL_GENERAL = 0, LOC_WINDOW_KERNEL_CHAIN = 1, LOC_WINDOW_KERNEL_CHAIN3 = 2, LOC_WINDOW_KERNEL_ARROW3 = 3 };

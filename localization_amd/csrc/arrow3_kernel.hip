@@ -1,7 +1,7 @@
 // gfx950 (MI355X / CDNA4): TRANSLATION-ONLY windows that are a CHAIN with a small dense BORDER — BASELINE config 4, anchor
 // self-calibration: one tag trajectory (a chain of poses tied by the zero-range smoothness edges of Robot::new_vertex,
 // robot.cpp:75-110, localization.cpp:338-340) whose every pose ranges to a handful of nodes that are unknowns themselves
-// ("every node moves" when topic/relative_range exists, localization.cpp:94-98; addRLRangeEdge, :378-436).  One WAVE per instance.
+// ("every node moves" when topic/relative_range exists, localization.cpp:94-98; addRLRangeEdge, :378-436).  FOUR waves (one workgroup) per instance.
 //
 // Same problem, same LM as every other kernel here (g2o's Levenberg-Marquardt; Localization::solve(),
 // localization.cpp:164-170; EdgeSE3Range, types_edge_se3range.cpp:105-114; Cauchy kernels, :608-627).  Translation-only means what
@@ -17,14 +17,27 @@
 //              along, lane = border row: F_p = (B_p - F_{p-1} W_p^T) G_p^-T (three numbers per lane, in registers), r_b -= F_p y_p;
 //   Schur      S = C + lambda I - sum_p F_p F_p^T: a (3 nb) x (3 n) x (3 nb) SYRK — the one GEMM-shaped piece, on the f64 matrix
 //              cores (v_mfma_f64_16x16x4_f64), four poses per step, accumulators in registers for the whole sweep;
-//   border     dense Cholesky of S in LDS (<= 48 x 48), the right-hand side riding along as one more row; back-substitution;
+//   border     dense Cholesky of S in LDS (<= 45 x 45, lower triangle packed), the right-hand side riding along as one more row;
 //   chain      z = L^-1 (b_c - B^T x_b), x_c = L^-T z: two more sweeps over the chain that touch only 3x3 data.
-// F is never stored (it would be 184 KB per instance and trial); B is (dense 3x3 blocks in an HBM workspace, streamed: 720 bytes
-// per chain pose, read twice per trial).  What the sequential sweeps touch lives in LDS (24 doubles per chain pose + the border's
-// dense arrays: 68 KB for 256 + 10 poses), what only lane-parallel phases touch (translations, the stale step, edge tables) in HBM
-// with coalesced access.  Linearisation and trial scoring are lane-parallel over chain poses through per-pose edge lists the
-// host builds once per upload (capi_window.cpp: build_arrow_aux); sums over a border pose's many edges are reduced in one fixed
-// order (bit-reproducible, no atomics).
+// F is never stored (it would be 184 KB per instance and trial); B is (dense 3x3 blocks in an HBM workspace, streamed: 3 D doubles
+// per chain row, read twice per trial).  What the sequential sweeps touch lives in LDS (26 doubles per chain row + the border's
+// dense arrays), what only thread-parallel phases touch (translations, the stale step, edge records) in HBM with coalesced access.
+//
+// Four waves.  A single wave issues one f64 instruction per ~8 cycles, and a 256-pose sweep is ~130 instructions per pose, so the
+// sequential sweeps, not bytes, bound one instance.  The host therefore cuts the chain into up to four SEGMENTS at separator poses
+// that JOIN THE BORDER (one level of nested dissection: 256 + 10 poses become 4 x ~63 chain rows + 13 border poses): every wave
+// sweeps its own segment with its own MFMA accumulators, the partial Schur complements are subtracted in wave order
+// (bit-reproducible), the dense factorisation and all thread-parallel phases (linearisation, trial scoring, B^T x, the update) run
+// on all 256 threads.  Rows (chain rows segment by segment, then border rows) walk host-packed edge records
+// [chunk of 64 rows][slot][lane] — coalesced, no index chasing; sums over a border pose's many edges are reduced in one fixed
+// order (no atomics; 32 loads in flight per wave).  The border's dense factorisation runs on the whole block, one border pose
+// (three columns) per step.  Measured on config 4 (256 + 10 poses, 16 LM trials per solve, 128 hypotheses = one GPU's share):
+// window_lm_kernel 15.1 ms; this kernel with one wave per instance 6.9 ms; four waves + separators 3.0 ms; + blocked dense
+// factorisation, g kept from the forward sweep, the reduction's loads in flight: 2.7 ms (all 1 024 hypotheses on one GPU: 11.5 ms,
+// 8.9e4 solves/s against 8.5e3).  Cycle shares now (tools/dev/probe_arrow3.py, -DLOCAMD_ARROW_TIMING): forward sweep + Schur
+// 28 %, linearisation 22 %, chain z / x sweeps 17 %, dense factorisation 13 %, B^T x 8 %, trial scoring 7 %.  Tried and dropped:
+// B transposed to [border row][component][chain row] (coalesced for the thread-parallel phases, but the forward sweep's 39 lanes
+// then touch 39 cache lines per load: the sweep +20 %, the whole solve +7 %).
 #include "window_kernel.h"
 #include "device_math.h"
 
@@ -36,15 +49,17 @@
 
 namespace locamd {
 
-// doubles of HBM workspace per instance: translations (two buffers) + stale step, B rows, per-(pose, border) contributions
+constexpr int ARROW_NW = 4;   // waves per instance = segments the chain is cut into at most
+
+// doubles of HBM workspace per instance: chain translations (two buffers) + the stale step, B rows, per-(row, border pose) shares
 static __host__ __device__ inline size_t window_arrow3_workspace_doubles_dev(const WindowCaps& c, int nb_max) {
     return (size_t)c.nv_max * 9 + (size_t)c.nv_max * 3 * nb_max * 3 + (size_t)c.nv_max * nb_max * 9;
 }
 size_t window_arrow3_workspace_doubles(const WindowCaps& c, int nb_max) { return window_arrow3_workspace_doubles_dev(c, nb_max); }
 // doubles of LDS per instance
 static __host__ __device__ inline size_t arrow3_lds_doubles(int nv_max, int nb_max) {
-    const int D = 3 * nb_max, D16 = 16 * ((D + 15) / 16);
-    return (size_t)nv_max * 24 + 2 * (size_t)(D + 1) * D + 4 * (size_t)D + 4 * (size_t)D16 * 3 + 6 * (size_t)nb_max + (size_t)nb_max * nb_max / 2 + 8;
+    const size_t D = 3 * (size_t)nb_max, D16 = 16 * ((D + 15) / 16);
+    return (size_t)nv_max * 28 + D * (D + 1) / 2 + (D + 1) * (D + 2) / 2 + 3 * D + ARROW_NW * D + ARROW_NW * 4 * D16 * 3 + 6 * (size_t)nb_max + 16;
 }
 size_t window_arrow3_lds_bytes(const WindowCaps& c, int nb_max) { return arrow3_lds_doubles(c.nv_max, nb_max) * sizeof(double); }
 
@@ -53,8 +68,15 @@ namespace {
 extern __shared__ double ldsA[];
 #ifdef LOCAMD_ARROW_TIMING   // diagnostic build: cycle stamps of the phases go to result[1..7] (never benchmarked, never shipped)
 #define AT_DECL long long at_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long at_t = clock64()
-#define AT(slot) do { const long long t_ = clock64(); at_[slot] += t_ - at_t; at_t = t_; } while (0)
+#if LOCAMD_ARROW_TIMING == 2   // the phases of the linearisation instead of the solve's
+#define AT(slot) do { at_t = clock64(); } while (0)
+#define AT2(slot) do { const long long t_ = clock64(); at_[slot] += t_ - at_t; at_t = t_; } while (0)
 #else
+#define AT(slot) do { const long long t_ = clock64(); at_[slot] += t_ - at_t; at_t = t_; } while (0)
+#define AT2(slot) do {} while (0)
+#endif
+#else
+#define AT2(slot) do {} while (0)
 #define AT_DECL do {} while (0)
 #define AT(slot) do {} while (0)
 #endif
@@ -125,21 +147,41 @@ __device__ __forceinline__ double range_jac_numericA(const double* p0, const dou
 // where one instance's arrays live
 struct ArrowCtx {
     // LDS (doubles)
-    double *HD, *HB, *CU, *CV, *GG, *ZZ;   // per chain pose: 6, 3, 3, 3, 6, 3
-    double *C0, *S;                        // (D + 1) x D each (S: row D carries the right-hand side)
-    double *bB, *xB, *xsB, *scr;           // D each
-    double *FX;                            // [4][D16][3]
+    double *PK;                            // per chain row: H_qq (6), b_q (3), coupling u (3), v (3), pad: 16
+    double *GZ;                            // per chain row: factor (3 strict-lower + 3 reciprocal pivots), y / z / x (3), g = G_{q-1}^-1 v_q (3): 12
+    double *C0, *S;                        // border block, lower triangle packed: C0 D rows; S D + 1 rows (row D: the right-hand side)
+    double *bB, *xB, *xsB;                 // D each
+    double *RA;                            // [NW][D] the segments' shares of the border's right-hand side
+    double *FX;                            // [NW][4][D16][3]
     double *TB;                            // [2][nb][3] border translations (state / trial state)
-    int* paircnt;                          // [nb][nb] edges per border pair (result[6] bookkeeping)
+    double *red;                           // block reductions
     // HBM
-    double *TT;                            // [2][nv][3] chain + border translations (border entries unused)
-    double *XS;                            // [nv][3] the solver's x (stale when a factorisation fails)
-    double *BB;                            // [n][D][3]  B_p rows: (border row r, chain component k)
-    double *CS;                            // [n][nb][9] per (chain pose, border pose): its share of H_aa (6) and b_a (3)
-    const int32_t *e_off, *e_perm, *p_off, *p_perm, *r_idx, *p_idx;
-    const double *r_val, *p_val;
-    int nv, n, nb, D, D16, nr, np, lane;
+    double *TT;                            // [2][n][3] chain translations by row
+    double *XS;                            // [n][3] the solver's x (stale when a factorisation fails)
+    double *BB;                            // [n][D][3]  B_q rows: (border row r, chain component k) — the layout the forward sweep streams (lane = r)
+    double *CS;                            // [nb][9][npad] per (border pose, entry, row): that row's share of H_bb (6) and b_b (3)
+    size_t npad;
+    const double *rec, *prec;              // host-packed edge / prior records of this instance
+    const int32_t* seg;                    // seg[0 .. nseg]: chain rows of segment s = [seg[s], seg[s + 1])
+    int n, nb, D, D16, rows, nseg, jmax, jpmax, tid, lane, wv;
 };
+__device__ __forceinline__ int tri(int R, int C) { return R * (R + 1) / 2 + C; }
+
+// reductions over the block's four waves: every thread gets the same bits (wave order)
+__device__ __forceinline__ double block_sum(const ArrowCtx& c, double v) {
+    const double w = wave_sum(v);
+    __syncthreads();
+    if (c.lane == 0) c.red[c.wv] = w;
+    __syncthreads();
+    return ((c.red[0] + c.red[1]) + c.red[2]) + c.red[3];
+}
+__device__ __forceinline__ double block_max(const ArrowCtx& c, double v) {
+    const double w = wave_max(v);
+    __syncthreads();
+    if (c.lane == 0) c.red[c.wv] = w;
+    __syncthreads();
+    return fmax(fmax(c.red[0], c.red[1]), fmax(c.red[2], c.red[3]));
+}
 
 struct EdgeTerms { double J0[3], J1[3], wr, wre, chi, rho; };
 
@@ -175,460 +217,498 @@ __device__ __forceinline__ EdgeTerms range_terms(const double* p0, const double*
     return t;
 }
 
-// Every edge evaluated at translation buffer `buf`: chi sums always; FULL: H, b, B, C as well.  Returns through references the
-// robust cost, chi2 over all edges, the largest diagonal entry of H and (FULL) the edges sharing their pair with another edge.
+// Every edge evaluated at translation buffer `buf`, one thread per ROW (chain rows, then border rows), a wave per chunk of 64 rows:
+// chi sums always; FULL: H, b, B, C as well.  A row walks its host-packed records [chunk][slot][lane] (coalesced).
 template <bool FULL, int JAC>
 __device__ __forceinline__ void arrow_edges(const WindowArgs& a, const ArrowCtx& c, int buf, double& robust_chi, double& plain_chi,
-                                            double& max_diag, int& shared_edges) {
-    const int lane = c.lane, n = c.n, nb = c.nb, D = c.D;
-    const double* T = c.TT + (size_t)buf * c.nv * 3;
+                                            double& max_diag, int& shared_edges
+#ifdef LOCAMD_ARROW_TIMING
+                                            , long long* at_, long long& at_t
+#endif
+                                            ) {
+    const int lane = c.lane, n = c.n, nb = c.nb, D = c.D, rows = c.rows, tid = c.tid;
+    const double* T = c.TT + (size_t)buf * n * 3;
     const double* TB = c.TB + buf * nb * 3;
     double rsum = 0.0, csum = 0.0;
     int nshared = 0;
     if (FULL) {
-        for (int i = lane; i < (D + 1) * D; i += 64) c.C0[i] = 0.0;
-        for (int i = lane; i < D; i += 64) c.bB[i] = 0.0;
-        for (int i = lane; i < nb * nb; i += 64) c.paircnt[i] = 0;
-        wsync();
+        for (int i = tid; i < D * (D + 1) / 2; i += 64 * ARROW_NW) c.C0[i] = 0.0;
+        __syncthreads();
     }
-    // ---- chain poses, lane-parallel: own edges = to anchors, to border poses, and the edge to the previous chain pose -----------
-    for (int p0 = 0; p0 < n; p0 += 64) {
-        const int p = p0 + lane;
-        if (p < n) {
-            double tp[3] = {T[3 * p], T[3 * p + 1], T[3 * p + 2]};
-            double hd[6] = {0, 0, 0, 0, 0, 0}, hb[3] = {0, 0, 0}, cu[3] = {0, 0, 0}, cv[3] = {0, 0, 0}, cp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-            unsigned mask = 0, dup = 0;
-            int ndup = 0;
-            const int e0 = c.e_off[p], e1 = c.e_off[p + 1];
-            for (int idx = e0; idx < e1; ++idx) {
-                const int e = c.e_perm[idx];
-                const int v0 = c.r_idx[2 * e], v1 = c.r_idx[2 * e + 1];
-                const double meas = c.r_val[5 * e], info = c.r_val[5 * e + 1];
-                const bool own0 = v0 == p;
-                const int other = own0 ? v1 : v0;
-                double po[3];
-                if (other < 0) { const double* an = a.anchors + (size_t)(-1 - other) * 3; po[0] = an[0]; po[1] = an[1]; po[2] = an[2]; }
-                else if (other < n) { po[0] = T[3 * other]; po[1] = T[3 * other + 1]; po[2] = T[3 * other + 2]; }
-                else { const double* tb = TB + 3 * (other - n); po[0] = tb[0]; po[1] = tb[1]; po[2] = tb[2]; }
-                const EdgeTerms t = own0 ? range_terms<FULL, JAC>(tp, po, other >= 0, meas, info) : range_terms<FULL, JAC>(po, tp, true, meas, info);
-                rsum += t.rho;
-                csum += t.chi;
-                if (FULL) {
-                    double Jo[3], Jx[3];   // own / other endpoint
+    for (int ch = c.wv; ch * 64 < rows; ch += ARROW_NW) {
+        const int r = ch * 64 + lane;
+        const bool valid = r < rows, is_chain = r < n;
+        const int ob = r - n;   // border index of a border row
+        double tp[3] = {0.0, 0.0, 0.0}, tq[3] = {0.0, 0.0, 0.0};   // own translation, the previous chain row's
+        if (valid) {
+            if (is_chain) {
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) { Jo[k] = own0 ? t.J0[k] : t.J1[k]; Jx[k] = own0 ? t.J1[k] : t.J0[k]; }
+                for (int k = 0; k < 3; ++k) { tp[k] = T[3 * r + k]; tq[k] = r > 0 ? T[3 * (r - 1) + k] : 0.0; }
+            } else {
 #pragma unroll
-                    for (int r = 0; r < 3; ++r) {
+                for (int k = 0; k < 3; ++k) tp[k] = TB[3 * ob + k];
+            }
+        }
+        double hd[6] = {0, 0, 0, 0, 0, 0}, hb[3] = {0, 0, 0}, cu[3] = {0, 0, 0}, cv[3] = {0, 0, 0}, cp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned mask = 0, dup = 0;
+        int ndup = 0;
+        const double* rec = c.rec + ((size_t)ch * c.jmax * 64 + lane) * 3;
+        double nr0 = rec[0], nr1 = rec[1], nr2 = rec[2];
+        for (int j = 0; j < c.jmax; ++j) {
+            const double code_d = nr0, meas = nr1, info = nr2;
+            if (j + 1 < c.jmax) { const double* rn = rec + (size_t)(j + 1) * 64 * 3; nr0 = rn[0]; nr1 = rn[1]; nr2 = rn[2]; }
+            if (!valid || code_d < 0.0) continue;
+            const int code = (int)code_d;
+            const bool own0 = code & 1;
+            const int kind = (code >> 1) & 3, idx = code >> 3;
+            double po[3];
+            if (kind == 0) { const double* an = a.anchors + (size_t)idx * 3; po[0] = an[0]; po[1] = an[1]; po[2] = an[2]; }
+            else if (kind == 1) { po[0] = tq[0]; po[1] = tq[1]; po[2] = tq[2]; }
+            else { const double* tb = TB + 3 * idx; po[0] = tb[0]; po[1] = tb[1]; po[2] = tb[2]; }
+            const EdgeTerms t = own0 ? range_terms<FULL, JAC>(tp, po, kind != 0, meas, info) : range_terms<FULL, JAC>(po, tp, true, meas, info);
+            rsum += t.rho;
+            csum += t.chi;
+            if (FULL) {
+                double Jo[3], Jx[3];   // own / other endpoint
 #pragma unroll
-                        for (int cc = 0; cc <= r; ++cc) hd[r * (r + 1) / 2 + cc] += t.wr * Jo[r] * Jo[cc];
-                        hb[r] += Jo[r] * t.wre;
+                for (int k = 0; k < 3; ++k) { Jo[k] = own0 ? t.J0[k] : t.J1[k]; Jx[k] = own0 ? t.J1[k] : t.J0[k]; }
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr) {
+#pragma unroll
+                    for (int cc = 0; cc <= rr; ++cc) hd[rr * (rr + 1) / 2 + cc] += t.wr * Jo[rr] * Jo[cc];
+                    hb[rr] += Jo[rr] * t.wre;
+                }
+                if (kind == 2) {
+                    double* cs = c.CS + (size_t)idx * 9 * c.npad + r;
+                    const bool again = (mask >> idx) & 1u;
+                    double blk[9], own9[9];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) blk[3 * i + k] = t.wr * Jx[i] * Jo[k];   // row = the OTHER (border) pose's component, column = own component
+#pragma unroll
+                    for (int rr = 0; rr < 3; ++rr) {
+#pragma unroll
+                        for (int cc = 0; cc <= rr; ++cc) own9[rr * (rr + 1) / 2 + cc] = t.wr * Jx[rr] * Jx[cc];
+                        own9[6 + rr] = Jx[rr] * t.wre;
                     }
-                    if (other >= n) {
-                        const int ab = other - n;
-                        double* bb = c.BB + ((size_t)p * D + 3 * ab) * 3;
-                        double* cs = c.CS + ((size_t)p * nb + ab) * 9;
-                        const bool again = (mask >> ab) & 1u;
-                        double blk[9], own9[9];
+                    if (is_chain) {
+                        double* bb = c.BB + ((size_t)r * D + 3 * idx) * 3;
+                        if (again) {
+#pragma unroll
+                            for (int k = 0; k < 9; ++k) bb[k] += blk[k];
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 9; ++k) bb[k] = blk[k];
+                        }
+                    } else {   // block (own border pose ob, other border pose idx < ob) of C: rows = own components, columns = the other's
 #pragma unroll
                         for (int i = 0; i < 3; ++i)
 #pragma unroll
-                            for (int k = 0; k < 3; ++k) blk[3 * i + k] = t.wr * Jx[i] * Jo[k];   // row = border component, column = chain component
+                            for (int k = 0; k < 3; ++k) c.C0[tri(3 * ob + k, 3 * idx + i)] += blk[3 * i + k];
+                    }
+                    if (again) {
 #pragma unroll
-                        for (int r = 0; r < 3; ++r) {
+                        for (int k = 0; k < 9; ++k) cs[k * c.npad] += own9[k];
+                        ndup += 1;
+                        dup |= 1u << idx;
+                    } else {
 #pragma unroll
-                            for (int cc = 0; cc <= r; ++cc) own9[r * (r + 1) / 2 + cc] = t.wr * Jx[r] * Jx[cc];
-                            own9[6 + r] = Jx[r] * t.wre;
-                        }
-                        if (again) {
+                        for (int k = 0; k < 9; ++k) cs[k * c.npad] = own9[k];
+                    }
+                    mask |= 1u << idx;
+                } else if (kind == 1) {   // the edge to the previous chain row (one per pair: checked on the host)
 #pragma unroll
-                            for (int k = 0; k < 9; ++k) { bb[k] += blk[k]; cs[k] += own9[k]; }
-                            ndup += 1;
-                            dup |= 1u << ab;
-                        } else {
+                    for (int k = 0; k < 3; ++k) { cu[k] = t.wr * Jo[k]; cv[k] = Jx[k]; }
 #pragma unroll
-                            for (int k = 0; k < 9; ++k) { bb[k] = blk[k]; cs[k] = own9[k]; }
-                        }
-                        mask |= 1u << ab;
-                    } else if (other >= 0) {   // the edge to the previous chain pose (one per pair: checked on the host)
+                    for (int rr = 0; rr < 3; ++rr) {
 #pragma unroll
-                        for (int k = 0; k < 3; ++k) { cu[k] = t.wr * Jo[k]; cv[k] = Jx[k]; }
-#pragma unroll
-                        for (int r = 0; r < 3; ++r) {
-#pragma unroll
-                            for (int cc = 0; cc <= r; ++cc) cp[r * (r + 1) / 2 + cc] = t.wr * Jx[r] * Jx[cc];
-                            cp[6 + r] = Jx[r] * t.wre;
-                        }
+                        for (int cc = 0; cc <= rr; ++cc) cp[rr * (rr + 1) / 2 + cc] = t.wr * Jx[rr] * Jx[cc];
+                        cp[6 + rr] = Jx[rr] * t.wre;
                     }
                 }
             }
-            const int q0 = c.p_off[p], q1 = c.p_off[p + 1];
-            for (int idx = q0; idx < q1; ++idx) {   // priors: e = t + Z^-1.t, diagonal translation information, no robust kernel
-                const int e = c.p_perm[idx];
-                double chi = 0.0;
+        }
+        const double* prec = c.prec + ((size_t)ch * c.jpmax * 64 + lane) * 7;
+        for (int j = 0; j < c.jpmax; ++j) {   // priors: e = t + Z^-1.t, diagonal translation information, no robust kernel
+            const double* pr = prec + (size_t)j * 64 * 7;
+            if (!valid || pr[0] <= 0.0) continue;
+            double chi = 0.0;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const double er = tp[k] + c.p_val[18 * e + 9 + k], wd = c.p_val[18 * e + 12 + k];
-                    chi += er * (wd * er);
-                    if (FULL) { hd[k * (k + 1) / 2 + k] += wd; hb[k] += -wd * er; }
-                }
-                rsum += chi;
-                csum += chi;
+            for (int k = 0; k < 3; ++k) {
+                const double er = tp[k] + pr[1 + k], wd = pr[4 + k];
+                chi += er * (wd * er);
+                if (FULL) { hd[k * (k + 1) / 2 + k] += wd; hb[k] += -wd * er; }
             }
-            if (FULL) {
-                for (int ab = 0; ab < nb; ++ab)
-                    if (!((mask >> ab) & 1u)) {
-                        double* bb = c.BB + ((size_t)p * D + 3 * ab) * 3;
-                        double* cs = c.CS + ((size_t)p * nb + ab) * 9;
+            rsum += chi;
+            csum += chi;
+        }
+        if (FULL && valid) {
+            for (int xb = 0; xb < nb; ++xb) {
+                double* cs = c.CS + (size_t)xb * 9 * c.npad + r;
+                if (!is_chain && xb == ob) {   // a border row's own share of its own diagonal block and b
 #pragma unroll
-                        for (int k = 0; k < 9; ++k) { bb[k] = 0.0; cs[k] = 0.0; }
+                    for (int k = 0; k < 6; ++k) cs[k * c.npad] = hd[k];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) cs[(6 + k) * c.npad] = hb[k];
+                } else if (!((mask >> xb) & 1u)) {
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) cs[k * c.npad] = 0.0;
+                    if (is_chain) {
+                        double* bb = c.BB + ((size_t)r * D + 3 * xb) * 3;
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) bb[k] = 0.0;
                     }
-                nshared += ndup + __popc(dup);
+                }
+            }
+            nshared += ndup + __popc(dup);
+            if (is_chain) {
+                double* pk = c.PK + 16 * r;
+                double* gz = c.GZ + 12 * r;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) { c.HD[6 * p + k] = hd[k]; c.GG[6 * p + k] = cp[k]; }
+                for (int k = 0; k < 6; ++k) pk[k] = hd[k];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) { c.HB[3 * p + k] = hb[k]; c.CU[3 * p + k] = cu[k]; c.CV[3 * p + k] = cv[k]; c.ZZ[3 * p + k] = cp[6 + k]; }
+                for (int k = 0; k < 3; ++k) { pk[6 + k] = hb[k]; pk[9 + k] = cu[k]; pk[12 + k] = cv[k]; }
+#pragma unroll
+                for (int k = 0; k < 9; ++k) gz[k] = cp[k];
             }
         }
     }
     if (FULL) {
-        __threadfence_block();
-        wsync();
-        // the edge (p, p + 1) also belongs to pose p: its share was left in pose p + 1's (G, z) slots
-        for (int p0 = 0; p0 < n; p0 += 64) {
-            const int p = p0 + lane;
-            if (p + 1 < n) {
+        __syncthreads();
+        AT2(1);
+        // the edge (q, q + 1) also belongs to row q: its share was left in row q + 1's (G, z) slots (zero across a segment boundary:
+        // there the neighbour is a separator, i.e. a border pose)
+        for (int q = tid; q + 1 < n; q += 64 * ARROW_NW) {
 #pragma unroll
-                for (int k = 0; k < 6; ++k) c.HD[6 * p + k] += c.GG[6 * (p + 1) + k];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) c.HB[3 * p + k] += c.ZZ[3 * (p + 1) + k];
-            }
+            for (int k = 0; k < 9; ++k) c.PK[16 * q + k] += c.GZ[12 * (q + 1) + k];
         }
-        // a border pose's diagonal block and b: the sum over the chain of the shares left in CS, one fixed order (four partial sums)
-        for (int t0 = 0; t0 < nb * 9; t0 += 64) {
-            const int t = t0 + lane;
-            if (t < nb * 9) {
-                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-                const double* col = c.CS + t;
-                const size_t st = (size_t)nb * 9;
-                int p = 0;
-                for (; p + 3 < n; p += 4) { s0 += col[p * st]; s1 += col[(p + 1) * st]; s2 += col[(p + 2) * st]; s3 += col[(p + 3) * st]; }
-                for (; p < n; ++p) s0 += col[p * st];
-                const double s = (s0 + s1) + (s2 + s3);
-                const int ab = t / 9, k = t % 9;
-                if (k < 6) {
-                    const int r = k < 1 ? 0 : (k < 3 ? 1 : 2), cc = k - r * (r + 1) / 2;
-                    c.C0[(3 * ab + r) * D + 3 * ab + cc] = s;
-                } else {
-                    c.bB[3 * ab + k - 6] = s;
-                }
-            }
-        }
-        wsync();
-    }
-    // ---- edges and priors owned by border poses (border-border ranges, border-anchor ranges, priors): few; one lane, in order -----
-    if (lane == 0) {
-        for (int o = n; o < c.nv; ++o) {
-            const int ob = o - n;
-            const double to[3] = {TB[3 * ob], TB[3 * ob + 1], TB[3 * ob + 2]};
-            for (int idx = c.e_off[o]; idx < c.e_off[o + 1]; ++idx) {
-                const int e = c.e_perm[idx];
-                const int v0 = c.r_idx[2 * e], v1 = c.r_idx[2 * e + 1];
-                const double meas = c.r_val[5 * e], info = c.r_val[5 * e + 1];
-                const bool own0 = v0 == o;
-                const int other = own0 ? v1 : v0;
-                double po[3];
-                if (other < 0) { const double* an = a.anchors + (size_t)(-1 - other) * 3; po[0] = an[0]; po[1] = an[1]; po[2] = an[2]; }
-                else { const double* tb = TB + 3 * (other - n); po[0] = tb[0]; po[1] = tb[1]; po[2] = tb[2]; }
-                const EdgeTerms t = own0 ? range_terms<FULL, JAC>(to, po, other >= 0, meas, info) : range_terms<FULL, JAC>(po, to, true, meas, info);
-                rsum += t.rho;
-                csum += t.chi;
-                if (FULL) {
-                    double Jo[3], Jx[3];
+        AT2(2);
+        // a border pose's diagonal block and b: the sum over all rows of the shares left in CS — one wave per (border pose, entry),
+        // lane partial sums over its rows then the DPP tree: one fixed order
+        for (int t0 = 8 * c.wv; t0 < nb * 9; t0 += 8 * ARROW_NW) {   // (eight sums' loads in flight before the first DPP tree)
+            double sp[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            for (int ck0 = 0; ck0 * 64 < rows; ck0 += 4) {   // 32 independent loads, then the sums (fixed order)
+                double v[8][4];
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) { Jo[k] = own0 ? t.J0[k] : t.J1[k]; Jx[k] = own0 ? t.J1[k] : t.J0[k]; }
-                    for (int r = 0; r < 3; ++r) {
-                        for (int cc = 0; cc <= r; ++cc) c.C0[(3 * ob + r) * D + 3 * ob + cc] += t.wr * Jo[r] * Jo[cc];
-                        c.bB[3 * ob + r] += Jo[r] * t.wre;
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) {
+                        const int p = (ck0 + c4) * 64 + lane;
+                        v[u][c4] = (t0 + u < nb * 9 && p < rows) ? c.CS[(size_t)(t0 + u) * c.npad + p] : 0.0;
                     }
-                    if (other >= 0) {   // the other border pose has the smaller slot (the owner is the later one)
-                        const int xb = other - n;
-                        for (int r = 0; r < 3; ++r) {
-                            for (int cc = 0; cc <= r; ++cc) c.C0[(3 * xb + r) * D + 3 * xb + cc] += t.wr * Jx[r] * Jx[cc];
-                            c.bB[3 * xb + r] += Jx[r] * t.wre;
-                            for (int cc = 0; cc < 3; ++cc) c.C0[(3 * ob + r) * D + 3 * xb + cc] += t.wr * Jo[r] * Jx[cc];
-                        }
-                        const int cnt = ++c.paircnt[ob * nb + xb];
-                        if (cnt == 2) nshared += 2; else if (cnt > 2) nshared += 1;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sp[u] += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double sv = wave_sum(sp[u]);
+                const int t = t0 + u;
+                if (lane == 0 && t < nb * 9) {
+                    const int xb = t / 9, k = t % 9;
+                    if (k < 6) {
+                        const int rr = k < 1 ? 0 : (k < 3 ? 1 : 2), cc = k - rr * (rr + 1) / 2;
+                        c.C0[tri(3 * xb + rr, 3 * xb + cc)] = sv;
+                    } else {
+                        c.bB[3 * xb + k - 6] = sv;
                     }
                 }
             }
-            for (int idx = c.p_off[o]; idx < c.p_off[o + 1]; ++idx) {
-                const int e = c.p_perm[idx];
-                double chi = 0.0;
-                for (int k = 0; k < 3; ++k) {
-                    const double er = to[k] + c.p_val[18 * e + 9 + k], wd = c.p_val[18 * e + 12 + k];
-                    chi += er * (wd * er);
-                    if (FULL) { c.C0[(3 * ob + k) * D + 3 * ob + k] += wd; c.bB[3 * ob + k] += -wd * er; }
-                }
-                rsum += chi;
-                csum += chi;
-            }
         }
+        __syncthreads();
+        AT2(3);
     }
-    wsync();
-    robust_chi = wave_sum(rsum);
-    plain_chi = wave_sum(csum);
+    robust_chi = block_sum(c, rsum);
+    plain_chi = block_sum(c, csum);
     if (FULL) {
         double md = 0.0;
-        for (int p = lane; p < n; p += 64) md = fmax(md, fmax(fabs(c.HD[6 * p]), fmax(fabs(c.HD[6 * p + 2]), fabs(c.HD[6 * p + 5]))));
-        for (int r = lane; r < D; r += 64) md = fmax(md, fabs(c.C0[r * D + r]));
-        max_diag = wave_max(md);
-        shared_edges = (int)wave_sum((double)nshared);
+        for (int q = tid; q < n; q += 64 * ARROW_NW) md = fmax(md, fmax(fabs(c.PK[16 * q]), fmax(fabs(c.PK[16 * q + 2]), fabs(c.PK[16 * q + 5]))));
+        for (int r = tid; r < D; r += 64 * ARROW_NW) md = fmax(md, fabs(c.C0[tri(r, r)]));
+        max_diag = block_max(c, md);
+        shared_edges = (int)block_sum(c, (double)nshared);
+        AT2(4);
     }
 }
 
 // (H + lambda I) x = b, the step applied to the other translation buffer.  Returns false when a pivot fails (then the stale x is
-// applied: SURVEY A.6); scale_sum = g2o's computeScale sum.
+// applied: SURVEY A.6); scale_sum = g2o's computeScale sum.  All threads of the block call it.
 template <int NTI>
 __device__ __forceinline__ bool arrow_solve(const ArrowCtx& c, double lambda, int buf, double& scale_sum
 #ifdef LOCAMD_ARROW_TIMING
                                             , long long* at_, long long& at_t
 #endif
                                             ) {
-    const int lane = c.lane, n = c.n, nb = c.nb, D = c.D, D16 = c.D16;
+    const int lane = c.lane, n = c.n, nb = c.nb, D = c.D, D16 = c.D16, tid = c.tid, wv = c.wv;
     constexpr int NACC = NTI * (NTI + 1) / 2;
     v4f64 acc[NACC];
 #pragma unroll
     for (int t = 0; t < NACC; ++t) acc[t] = v4f64{0.0, 0.0, 0.0, 0.0};
     const int li = lane & 15, lk = lane >> 4;
-    // ---- forward sweep over the chain (every lane runs the 3x3 recurrence; lane r < D carries border row r) -----------------------
-    double l10 = 0.0, l20 = 0.0, l21 = 0.0, ig0 = 0.0, ig1 = 0.0, ig2 = 0.0, y0 = 0.0, y1 = 0.0, y2 = 0.0;
-    double F0 = 0.0, F1 = 0.0, F2 = 0.0, racc = 0.0;
     bool ok = true;
     const bool brow = lane < D;
-    const double* Brow = c.BB + (size_t)lane * 3;
-    const size_t bst = (size_t)D * 3;
-    double nb_[4][3];   // the next four poses' B rows of this lane, in flight
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) nb_[j][k] = (brow && j < n) ? Brow[(size_t)j * bst + k] : 0.0;
-    for (int p0 = 0; p0 < n; p0 += 4) {
-        double cb[4][3];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) cb[j][k] = nb_[j][k];
+    const bool sweeps = wv < c.nseg;
+    const int s0 = sweeps ? c.seg[wv] : 0, s1 = sweeps ? c.seg[wv + 1] : 0;
+    // ---- forward sweep over this wave's segment (every lane runs the 3x3 recurrence; lane r < D carries border row r) ---------------
+    {
+        double l10 = 0.0, l20 = 0.0, l21 = 0.0, ig0 = 0.0, ig1 = 0.0, ig2 = 0.0, y0 = 0.0, y1 = 0.0, y2 = 0.0;
+        double F0 = 0.0, F1 = 0.0, F2 = 0.0, racc = 0.0;
+        const double* Brow = c.BB + (size_t)lane * 3;
+        const size_t bst = (size_t)D * 3;
+        double* FX = c.FX + (size_t)wv * 4 * D16 * 3;
+        double nb_[4][3];   // the next four rows' B entries of this lane, in flight
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) nb_[j][k] = (brow && p0 + 4 + j < n) ? Brow[(size_t)(p0 + 4 + j) * bst + k] : 0.0;
+            for (int k = 0; k < 3; ++k) nb_[j][k] = (brow && s0 + j < s1) ? Brow[(size_t)(s0 + j) * bst + k] : 0.0;
+        for (int p0 = s0; p0 < s1; p0 += 4) {
+            double cb[4][3];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int p = p0 + j;
-            double o0 = 0.0, o1 = 0.0, o2 = 0.0;
-            if (p < n) {
-                const double* hd = c.HD + 6 * p;
-                const double u0 = c.CU[3 * p], u1 = c.CU[3 * p + 1], u2 = c.CU[3 * p + 2];
-                const double v0 = c.CV[3 * p], v1 = c.CV[3 * p + 1], v2 = c.CV[3 * p + 2];
-                // g = G_{p-1}^-1 v: W_p = u g^T
-                const double g0 = v0 * ig0;
-                const double g1 = __builtin_fma(-g0, l10, v1) * ig1;
-                const double g2 = __builtin_fma(-g1, l21, __builtin_fma(-g0, l20, v2)) * ig2;
-                const double gg = g0 * g0 + g1 * g1 + g2 * g2, gy = g0 * y0 + g1 * y1 + g2 * y2;
-                const double su0 = gg * u0, su1 = gg * u1, su2 = gg * u2;
-                double a00 = __builtin_fma(-su0, u0, hd[0] + lambda), a10 = __builtin_fma(-su1, u0, hd[1]), a11 = __builtin_fma(-su1, u1, hd[2] + lambda);
-                double a20 = __builtin_fma(-su2, u0, hd[3]), a21 = __builtin_fma(-su2, u1, hd[4]), a22 = __builtin_fma(-su2, u2, hd[5] + lambda);
-                double r0 = __builtin_fma(-u0, gy, c.HB[3 * p]), r1 = __builtin_fma(-u1, gy, c.HB[3 * p + 1]), r2 = __builtin_fma(-u2, gy, c.HB[3 * p + 2]);
-                // border row: f = B_p[r] - (F_{p-1}[r] . g) u   (with the PREVIOUS pose's F), then F = f G_p^-T
-                const double fg = F0 * g0 + F1 * g1 + F2 * g2;
-                const double f0 = __builtin_fma(-fg, u0, cb[j][0]), f1 = __builtin_fma(-fg, u1, cb[j][1]), f2 = __builtin_fma(-fg, u2, cb[j][2]);
-                // 3x3 Cholesky (right-looking, reciprocal square roots of the pivots)
-                ig0 = pivot_rsqrtA(a00);
-                a10 *= ig0; a20 *= ig0;
-                a11 = __builtin_fma(-a10, a10, a11); a21 = __builtin_fma(-a20, a10, a21); a22 = __builtin_fma(-a20, a20, a22);
-                ig1 = pivot_rsqrtA(a11);
-                a21 *= ig1;
-                a22 = __builtin_fma(-a21, a21, a22);
-                ig2 = pivot_rsqrtA(a22);
-                ok = ok && ((ig0 + ig1) + ig2 < DBL_MAX);
-                l10 = a10; l20 = a20; l21 = a21;
-                y0 = r0 * ig0;
-                y1 = __builtin_fma(-y0, l10, r1) * ig1;
-                y2 = __builtin_fma(-y1, l21, __builtin_fma(-y0, l20, r2)) * ig2;
-                F0 = f0 * ig0;
-                F1 = __builtin_fma(-F0, l10, f1) * ig1;
-                F2 = __builtin_fma(-F1, l21, __builtin_fma(-F0, l20, f2)) * ig2;
-                racc = __builtin_fma(F0, y0, __builtin_fma(F1, y1, __builtin_fma(F2, y2, racc)));
-                if (lane == 0) {
-                    double* gg_ = c.GG + 6 * p;
-                    gg_[0] = l10; gg_[1] = l20; gg_[2] = l21; gg_[3] = ig0; gg_[4] = ig1; gg_[5] = ig2;
-                    c.ZZ[3 * p] = y0; c.ZZ[3 * p + 1] = y1; c.ZZ[3 * p + 2] = y2;
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) cb[j][k] = nb_[j][k];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) nb_[j][k] = (brow && p0 + 4 + j < s1) ? Brow[(size_t)(p0 + 4 + j) * bst + k] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = p0 + j;
+                double o0 = 0.0, o1 = 0.0, o2 = 0.0;
+                if (p < s1) {
+                    const double* pk = c.PK + 16 * p;
+                    const double u0 = pk[9], u1 = pk[10], u2 = pk[11], v0 = pk[12], v1 = pk[13], v2 = pk[14];
+                    // g = G_{p-1}^-1 v: W_p = u g^T
+                    const double g0 = v0 * ig0;
+                    const double g1 = __builtin_fma(-g0, l10, v1) * ig1;
+                    const double g2 = __builtin_fma(-g1, l21, __builtin_fma(-g0, l20, v2)) * ig2;
+                    const double gg = g0 * g0 + g1 * g1 + g2 * g2, gy = g0 * y0 + g1 * y1 + g2 * y2;
+                    const double su0 = gg * u0, su1 = gg * u1, su2 = gg * u2;
+                    double a00 = __builtin_fma(-su0, u0, pk[0] + lambda), a10 = __builtin_fma(-su1, u0, pk[1]), a11 = __builtin_fma(-su1, u1, pk[2] + lambda);
+                    double a20 = __builtin_fma(-su2, u0, pk[3]), a21 = __builtin_fma(-su2, u1, pk[4]), a22 = __builtin_fma(-su2, u2, pk[5] + lambda);
+                    const double r0 = __builtin_fma(-u0, gy, pk[6]), r1 = __builtin_fma(-u1, gy, pk[7]), r2 = __builtin_fma(-u2, gy, pk[8]);
+                    // border row: f = B_p[r] - (F_{p-1}[r] . g) u   (with the PREVIOUS row's F), then F = f G_p^-T
+                    const double fg = F0 * g0 + F1 * g1 + F2 * g2;
+                    const double f0 = __builtin_fma(-fg, u0, cb[j][0]), f1 = __builtin_fma(-fg, u1, cb[j][1]), f2 = __builtin_fma(-fg, u2, cb[j][2]);
+                    // 3x3 Cholesky (right-looking, reciprocal square roots of the pivots)
+                    ig0 = pivot_rsqrtA(a00);
+                    a10 *= ig0; a20 *= ig0;
+                    a11 = __builtin_fma(-a10, a10, a11); a21 = __builtin_fma(-a20, a10, a21); a22 = __builtin_fma(-a20, a20, a22);
+                    ig1 = pivot_rsqrtA(a11);
+                    a21 *= ig1;
+                    a22 = __builtin_fma(-a21, a21, a22);
+                    ig2 = pivot_rsqrtA(a22);
+                    ok = ok && ((ig0 + ig1) + ig2 < DBL_MAX);
+                    l10 = a10; l20 = a20; l21 = a21;
+                    y0 = r0 * ig0;
+                    y1 = __builtin_fma(-y0, l10, r1) * ig1;
+                    y2 = __builtin_fma(-y1, l21, __builtin_fma(-y0, l20, r2)) * ig2;
+                    F0 = f0 * ig0;
+                    F1 = __builtin_fma(-F0, l10, f1) * ig1;
+                    F2 = __builtin_fma(-F1, l21, __builtin_fma(-F0, l20, f2)) * ig2;
+                    racc = __builtin_fma(F0, y0, __builtin_fma(F1, y1, __builtin_fma(F2, y2, racc)));
+                    if (lane == 0) {
+                        double* gz = c.GZ + 12 * p;
+                        gz[0] = l10; gz[1] = l20; gz[2] = l21; gz[3] = ig0; gz[4] = ig1; gz[5] = ig2; gz[6] = y0; gz[7] = y1; gz[8] = y2;
+                        gz[9] = g0; gz[10] = g1; gz[11] = g2;
+                    }
+                    o0 = brow ? F0 : 0.0; o1 = brow ? F1 : 0.0; o2 = brow ? F2 : 0.0;
                 }
-                o0 = brow ? F0 : 0.0; o1 = brow ? F1 : 0.0; o2 = brow ? F2 : 0.0;
+                if (lane < D16) { double* fx = FX + ((size_t)j * D16 + lane) * 3; fx[0] = o0; fx[1] = o1; fx[2] = o2; }
             }
-            if (lane < D16) { double* fx = c.FX + ((size_t)j * D16 + lane) * 3; fx[0] = o0; fx[1] = o1; fx[2] = o2; }
+            wsync();
+            // P += F F^T over these four rows' twelve columns: three k-steps (one per component), lane (row li of a tile, chain row lk)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                double fr[NTI];
+#pragma unroll
+                for (int ti = 0; ti < NTI; ++ti) fr[ti] = FX[((size_t)lk * D16 + 16 * ti + li) * 3 + i];
+                int t = 0;
+#pragma unroll
+                for (int ti = 0; ti < NTI; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj <= ti; ++tj) { acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[ti], fr[tj], acc[t], 0, 0, 0); ++t; }
+            }
+            wsync();
         }
-        wsync();
-        // P += F F^T over these four poses' twelve columns: three k-steps (one per component), lane (row li of a tile, pose lk)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            double fr[NTI];
-#pragma unroll
-            for (int ti = 0; ti < NTI; ++ti) fr[ti] = c.FX[((size_t)lk * D16 + 16 * ti + li) * 3 + i];
+        if (brow) c.RA[wv * D + lane] = sweeps ? racc : 0.0;
+    }
+    __syncthreads();
+    AT(2);
+    // ---- S = C + lambda I - sum of the segments' F F^T (lower triangle, packed); row D = b_b - sum of the segments' F y ---------------
+    for (int i = tid; i < D * (D + 1) / 2; i += 64 * ARROW_NW) c.S[i] = c.C0[i];
+    for (int r = tid; r < D; r += 64 * ARROW_NW) c.S[tri(D, r)] = c.bB[r] - (((c.RA[r] + c.RA[D + r]) + c.RA[2 * D + r]) + c.RA[3 * D + r]);
+    __syncthreads();
+    for (int r = tid; r < D; r += 64 * ARROW_NW) c.S[tri(r, r)] += lambda;
+    for (int turn = 0; turn < c.nseg; ++turn) {   // (wave order: bit-reproducible)
+        if (wv == turn) {
             int t = 0;
 #pragma unroll
             for (int ti = 0; ti < NTI; ++ti)
 #pragma unroll
-                for (int tj = 0; tj <= ti; ++tj) { acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[ti], fr[tj], acc[t], 0, 0, 0); ++t; }
-        }
-        wsync();
-    }
-    AT(2);
-    // ---- S = C + lambda I - P (lower triangle); row D = the border's right-hand side b_b - sum F y --------------------------------
-    {
-        int t = 0;
+                for (int tj = 0; tj <= ti; ++tj) {
 #pragma unroll
-        for (int ti = 0; ti < NTI; ++ti)
-#pragma unroll
-            for (int tj = 0; tj <= ti; ++tj) {
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int R = 16 * ti + lk + 4 * v, C = 16 * tj + li;
-                    if (C <= R && R < D) c.S[R * D + C] = c.C0[R * D + C] + (R == C ? lambda : 0.0) - acc[t][v];
+                    for (int v = 0; v < 4; ++v) {
+                        const int R = 16 * ti + lk + 4 * v, C = 16 * tj + li;
+                        if (C <= R && R < D) c.S[tri(R, C)] -= acc[t][v];
+                    }
+                    ++t;
                 }
-                ++t;
-            }
-        if (brow) c.S[D * D + lane] = c.bB[lane] - racc;
-    }
-    wsync();
-    // ---- dense Cholesky of S, lane = row (row D: the right-hand side, which leaves the loop as y_b) ---------------------------------
-    for (int j = 0; j < D; ++j) {
-        const double g = pivot_rsqrtA(c.S[j * D + j]);
-        ok = ok && (g < DBL_MAX);
-        double lij = 0.0;
-        if (lane > j && lane <= D) { lij = c.S[lane * D + j] * g; c.S[lane * D + j] = lij; }
-        if (lane == j) c.S[j * D + j] = g;   // (the diagonal keeps the reciprocal pivot)
-        wsync();
-        if (lane > j && lane <= D) {
-            const int cend = lane < D ? lane : D - 1;
-            for (int cc = j + 1; cc <= cend; ++cc) c.S[lane * D + cc] = __builtin_fma(-lij, c.S[cc * D + j], c.S[lane * D + cc]);
         }
-        wsync();
+        __syncthreads();
+    }
+    // ---- dense Cholesky of S by the whole block, one border pose (three columns) per step: every thread factors the step's 3x3
+    //      diagonal block itself, one thread per row below solves its row against it, then the trailing update (rank 3) — two
+    //      barriers per border pose.  Row D, the right-hand side, leaves the loop as y_b; reciprocal pivots in RA[0 .. D). ----------
+    {
+        const int ti = tid >> 4, tc = tid & 15;
+        for (int J = 0; J < nb; ++J) {
+            const int j0 = 3 * J;
+            double d00 = c.S[tri(j0, j0)], d10 = c.S[tri(j0 + 1, j0)], d11 = c.S[tri(j0 + 1, j0 + 1)];
+            double d20 = c.S[tri(j0 + 2, j0)], d21 = c.S[tri(j0 + 2, j0 + 1)], d22 = c.S[tri(j0 + 2, j0 + 2)];
+            const double g0 = pivot_rsqrtA(d00);
+            d10 *= g0; d20 *= g0;
+            d11 = __builtin_fma(-d10, d10, d11); d21 = __builtin_fma(-d20, d10, d21); d22 = __builtin_fma(-d20, d20, d22);
+            const double g1 = pivot_rsqrtA(d11);
+            d21 *= g1;
+            d22 = __builtin_fma(-d21, d21, d22);
+            const double g2 = pivot_rsqrtA(d22);
+            ok = ok && ((g0 + g1) + g2 < DBL_MAX);
+            __syncthreads();   // (everybody has read the diagonal block)
+            if (tid == 0) { c.S[tri(j0 + 1, j0)] = d10; c.S[tri(j0 + 2, j0)] = d20; c.S[tri(j0 + 2, j0 + 1)] = d21; c.RA[j0] = g0; c.RA[j0 + 1] = g1; c.RA[j0 + 2] = g2; }
+            if (tid > j0 + 2 && tid <= D) {   // row tid of the panel: w <- w G^-T
+                double w0 = c.S[tri(tid, j0)], w1 = c.S[tri(tid, j0 + 1)], w2 = c.S[tri(tid, j0 + 2)];
+                w0 *= g0;
+                w1 = __builtin_fma(-w0, d10, w1) * g1;
+                w2 = __builtin_fma(-w1, d21, __builtin_fma(-w0, d20, w2)) * g2;
+                c.S[tri(tid, j0)] = w0; c.S[tri(tid, j0 + 1)] = w1; c.S[tri(tid, j0 + 2)] = w2;
+            }
+            __syncthreads();
+            for (int i = j0 + 3 + ti; i <= D; i += 16) {
+                const double a0 = c.S[tri(i, j0)], a1 = c.S[tri(i, j0 + 1)], a2 = c.S[tri(i, j0 + 2)];
+                const int cend = i < D ? i : D - 1;
+                for (int cc = j0 + 3 + tc; cc <= cend; cc += 16)
+                    c.S[tri(i, cc)] = __builtin_fma(-a2, c.S[tri(cc, j0 + 2)], __builtin_fma(-a1, c.S[tri(cc, j0 + 1)], __builtin_fma(-a0, c.S[tri(cc, j0)], c.S[tri(i, cc)])));
+            }
+            __syncthreads();
+        }
+    }
+    // any segment's or the border's pivot failed?
+    {
+        __syncthreads();
+        if (lane == 0) c.red[8 + wv] = ok ? 0.0 : 1.0;
+        __syncthreads();
+        ok = (c.red[8] + c.red[9] + c.red[10] + c.red[11]) == 0.0;
     }
     if (!ok) {
         // g2o leaves x alone when the factorisation fails and LM applies that stale x all the same
         double sc = 0.0;
-        double* Tn = c.TT + (size_t)(1 - buf) * c.nv * 3;
-        const double* To = c.TT + (size_t)buf * c.nv * 3;
-        for (int i = lane; i < 3 * n; i += 64) { const double dx = c.XS[i]; sc += dx * (lambda * dx + c.HB[i]); Tn[i] = To[i] + dx; }
-        for (int r = lane; r < D; r += 64) { const double dx = c.xsB[r]; sc += dx * (lambda * dx + c.bB[r]); c.TB[(1 - buf) * nb * 3 + r] = c.TB[buf * nb * 3 + r] + dx; }
+        double* Tn = c.TT + (size_t)(1 - buf) * n * 3;
+        const double* To = c.TT + (size_t)buf * n * 3;
+        for (int i = tid; i < 3 * n; i += 64 * ARROW_NW) { const double dx = c.XS[i]; sc += dx * (lambda * dx + c.PK[16 * (i / 3) + 6 + i % 3]); Tn[i] = To[i] + dx; }
+        for (int r = tid; r < D; r += 64 * ARROW_NW) { const double dx = c.xsB[r]; sc += dx * (lambda * dx + c.bB[r]); c.TB[(1 - buf) * nb * 3 + r] = c.TB[buf * nb * 3 + r] + dx; }
         __threadfence_block();
-        wsync();
-        scale_sum = wave_sum(sc);
+        scale_sum = block_sum(c, sc);
         return false;
     }
-    // x_b = L^-T y_b
     AT(3);
-    if (brow) c.xB[lane] = c.S[D * D + lane];
-    wsync();
-    for (int j = D - 1; j >= 0; --j) {
-        const double xj = c.xB[j] * c.S[j * D + j];
+    // x_b = L^-T y_b (one wave)
+    if (wv == 0) {
+        if (brow) c.xB[lane] = c.S[tri(D, lane)];
         wsync();
-        if (lane == j) c.xB[j] = xj;
-        if (lane < j) c.xB[lane] = __builtin_fma(-c.S[j * D + lane], xj, c.xB[lane]);
-        wsync();
-    }
-    AT(3);
-    // ---- chain: rhs'_p = b_p - B_p^T x_b (lane-parallel), then z = L^-1 rhs', x = L^-T z (two sweeps) -----------------------------
-    for (int p0 = 0; p0 < n; p0 += 64) {
-        const int p = p0 + lane;
-        if (p < n) {
-            double s0 = c.HB[3 * p], s1 = c.HB[3 * p + 1], s2 = c.HB[3 * p + 2];
-            const double* bp = c.BB + (size_t)p * bst;
-            for (int r = 0; r < D; ++r) {
-                const double xr = c.xB[r];
-                s0 = __builtin_fma(-bp[3 * r], xr, s0); s1 = __builtin_fma(-bp[3 * r + 1], xr, s1); s2 = __builtin_fma(-bp[3 * r + 2], xr, s2);
-            }
-            c.ZZ[3 * p] = s0; c.ZZ[3 * p + 1] = s1; c.ZZ[3 * p + 2] = s2;
+        for (int j = D - 1; j >= 0; --j) {
+            const double xj = c.xB[j] * c.RA[j];
+            wsync();
+            if (lane == j) c.xB[j] = xj;
+            if (lane < j) c.xB[lane] = __builtin_fma(-c.S[tri(j, lane)], xj, c.xB[lane]);
+            wsync();
         }
     }
-    wsync();
+    __syncthreads();
+    AT(3);
+    // ---- chain: rhs'_q = b_q - B_q^T x_b (one thread per row), then per segment z = L^-1 rhs', x = L^-T z -------------------------------
+    for (int q = tid; q < n; q += 64 * ARROW_NW) {
+        double t0 = c.PK[16 * q + 6], t1 = c.PK[16 * q + 7], t2 = c.PK[16 * q + 8];
+        const double* bp = c.BB + (size_t)q * D * 3;
+        for (int r = 0; r < D; ++r) {
+            const double xr = c.xB[r];
+            t0 = __builtin_fma(-bp[3 * r], xr, t0); t1 = __builtin_fma(-bp[3 * r + 1], xr, t1); t2 = __builtin_fma(-bp[3 * r + 2], xr, t2);
+        }
+        c.GZ[12 * q + 6] = t0; c.GZ[12 * q + 7] = t1; c.GZ[12 * q + 8] = t2;
+    }
+    __syncthreads();
     AT(4);
-    {
-        double pl10 = 0.0, pl20 = 0.0, pl21 = 0.0, pi0 = 0.0, pi1 = 0.0, pi2 = 0.0, z0 = 0.0, z1 = 0.0, z2 = 0.0;
-        for (int p = 0; p < n; ++p) {
-            const double* gg_ = c.GG + 6 * p;
-            const double v0 = c.CV[3 * p], v1 = c.CV[3 * p + 1], v2 = c.CV[3 * p + 2];
-            const double g0 = v0 * pi0;
-            const double g1 = __builtin_fma(-g0, pl10, v1) * pi1;
-            const double g2 = __builtin_fma(-g1, pl21, __builtin_fma(-g0, pl20, v2)) * pi2;
-            const double gz = g0 * z0 + g1 * z1 + g2 * z2;
-            const double r0 = __builtin_fma(-c.CU[3 * p], gz, c.ZZ[3 * p]), r1 = __builtin_fma(-c.CU[3 * p + 1], gz, c.ZZ[3 * p + 1]), r2 = __builtin_fma(-c.CU[3 * p + 2], gz, c.ZZ[3 * p + 2]);
-            pl10 = gg_[0]; pl20 = gg_[1]; pl21 = gg_[2]; pi0 = gg_[3]; pi1 = gg_[4]; pi2 = gg_[5];
-            z0 = r0 * pi0;
-            z1 = __builtin_fma(-z0, pl10, r1) * pi1;
-            z2 = __builtin_fma(-z1, pl21, __builtin_fma(-z0, pl20, r2)) * pi2;
-            if (lane == 0) { c.ZZ[3 * p] = z0; c.ZZ[3 * p + 1] = z1; c.ZZ[3 * p + 2] = z2; }
+    if (sweeps) {
+        double z0 = 0.0, z1 = 0.0, z2 = 0.0;
+        for (int p = s0; p < s1; ++p) {
+            const double* gz = c.GZ + 12 * p;
+            const double* pk = c.PK + 16 * p;
+            const double gz_ = gz[9] * z0 + gz[10] * z1 + gz[11] * z2;   // g_p . z_{p-1}
+            const double r0 = __builtin_fma(-pk[9], gz_, gz[6]), r1 = __builtin_fma(-pk[10], gz_, gz[7]), r2 = __builtin_fma(-pk[11], gz_, gz[8]);
+            z0 = r0 * gz[3];
+            z1 = __builtin_fma(-z0, gz[0], r1) * gz[4];
+            z2 = __builtin_fma(-z1, gz[2], __builtin_fma(-z0, gz[1], r2)) * gz[5];
+            if (lane == 0) { c.GZ[12 * p + 6] = z0; c.GZ[12 * p + 7] = z1; c.GZ[12 * p + 8] = z2; }
         }
         wsync();
-        // x_p = G_p^-T (z_p - g_{p+1} (u_{p+1} . x_{p+1})), g_{p+1} = G_p^-1 v_{p+1}
-        double x0 = 0.0, x1 = 0.0, x2 = 0.0, nu0 = 0.0, nu1 = 0.0, nu2 = 0.0, nv0 = 0.0, nv1 = 0.0, nv2 = 0.0;
-        for (int p = n - 1; p >= 0; --p) {
-            const double* gg_ = c.GG + 6 * p;
-            const double a10 = gg_[0], a20 = gg_[1], a21 = gg_[2], i0 = gg_[3], i1 = gg_[4], i2 = gg_[5];
-            const double g0 = nv0 * i0;
-            const double g1 = __builtin_fma(-g0, a10, nv1) * i1;
-            const double g2 = __builtin_fma(-g1, a21, __builtin_fma(-g0, a20, nv2)) * i2;
+        // x_p = G_p^-T (z_p - g_{p+1} (u_{p+1} . x_{p+1}))
+        double x0 = 0.0, x1 = 0.0, x2 = 0.0, nu0 = 0.0, nu1 = 0.0, nu2 = 0.0, ng0 = 0.0, ng1 = 0.0, ng2 = 0.0;
+        for (int p = s1 - 1; p >= s0; --p) {
+            const double* gz = c.GZ + 12 * p;
+            const double* pk = c.PK + 16 * p;
+            const double a10 = gz[0], a20 = gz[1], a21 = gz[2], i0 = gz[3], i1 = gz[4], i2 = gz[5];
             const double ux = nu0 * x0 + nu1 * x1 + nu2 * x2;
-            double t0 = __builtin_fma(-g0, ux, c.ZZ[3 * p]), t1 = __builtin_fma(-g1, ux, c.ZZ[3 * p + 1]), t2 = __builtin_fma(-g2, ux, c.ZZ[3 * p + 2]);
+            double t0 = __builtin_fma(-ng0, ux, gz[6]), t1 = __builtin_fma(-ng1, ux, gz[7]), t2 = __builtin_fma(-ng2, ux, gz[8]);
             x2 = t2 * i2;
             t1 = __builtin_fma(-a21, x2, t1); t0 = __builtin_fma(-a20, x2, t0);
             x1 = t1 * i1;
             t0 = __builtin_fma(-a10, x1, t0);
             x0 = t0 * i0;
-            nu0 = c.CU[3 * p]; nu1 = c.CU[3 * p + 1]; nu2 = c.CU[3 * p + 2];
-            nv0 = c.CV[3 * p]; nv1 = c.CV[3 * p + 1]; nv2 = c.CV[3 * p + 2];
-            if (lane == 0) { c.ZZ[3 * p] = x0; c.ZZ[3 * p + 1] = x1; c.ZZ[3 * p + 2] = x2; }
+            nu0 = pk[9]; nu1 = pk[10]; nu2 = pk[11]; ng0 = gz[9]; ng1 = gz[10]; ng2 = gz[11];
+            if (lane == 0) { c.GZ[12 * p + 6] = x0; c.GZ[12 * p + 7] = x1; c.GZ[12 * p + 8] = x2; }
         }
-        wsync();
     }
+    __syncthreads();
     AT(5);
     // ---- the step: t' = t + x (VertexSE3::oplus with R = I), x kept for a later failed solve, computeScale -------------------------
     {
         double sc = 0.0;
-        double* Tn = c.TT + (size_t)(1 - buf) * c.nv * 3;
-        const double* To = c.TT + (size_t)buf * c.nv * 3;
-        for (int i = lane; i < 3 * n; i += 64) { const double dx = c.ZZ[i]; c.XS[i] = dx; sc += dx * (lambda * dx + c.HB[i]); Tn[i] = To[i] + dx; }
-        for (int r = lane; r < D; r += 64) { const double dx = c.xB[r]; c.xsB[r] = dx; sc += dx * (lambda * dx + c.bB[r]); c.TB[(1 - buf) * nb * 3 + r] = c.TB[buf * nb * 3 + r] + dx; }
+        double* Tn = c.TT + (size_t)(1 - buf) * n * 3;
+        const double* To = c.TT + (size_t)buf * n * 3;
+        for (int i = tid; i < 3 * n; i += 64 * ARROW_NW) {
+            const double dx = c.GZ[12 * (i / 3) + 6 + i % 3];
+            c.XS[i] = dx; sc += dx * (lambda * dx + c.PK[16 * (i / 3) + 6 + i % 3]); Tn[i] = To[i] + dx;
+        }
+        for (int r = tid; r < D; r += 64 * ARROW_NW) { const double dx = c.xB[r]; c.xsB[r] = dx; sc += dx * (lambda * dx + c.bB[r]); c.TB[(1 - buf) * nb * 3 + r] = c.TB[buf * nb * 3 + r] + dx; }
         __threadfence_block();
-        wsync();
-        scale_sum = wave_sum(sc);
+        scale_sum = block_sum(c, sc);
     }
     AT(6);
     return true;
 }
 
 template <int JAC, int NTI>
-__global__ void __launch_bounds__(64, 1) arrow3_lm_kernel(const WindowArgs a, const ArrowAux x) {
-    const int lane = threadIdx.x;
+__global__ void __launch_bounds__(64 * ARROW_NW, 1) arrow3_lm_kernel(const WindowArgs a, const ArrowAux x) {
+    const int tid = threadIdx.x;
     const long long inst = blockIdx.x;
     const WindowCaps& cp = a.caps;
     ArrowCtx c;
-    c.lane = lane;
-    c.nv = a.counts[inst * 4 + 0]; c.nr = a.counts[inst * 4 + 1]; c.np = a.counts[inst * 4 + 2];
-    c.nb = x.nb[inst]; c.n = c.nv - c.nb; c.D = 3 * c.nb; c.D16 = 16 * ((3 * x.nb_max + 15) / 16);   // (FX rows: the batch's tile count)
-    const int nv = c.nv, n = c.n, nb = c.nb, D = c.D;
+    c.tid = tid; c.lane = tid & 63; c.wv = tid >> 6;
+    const int32_t* hdr = x.hdr + inst * 8;
+    const int nv = a.counts[inst * 4 + 0];
+    c.nb = hdr[0]; c.nseg = hdr[1]; c.n = hdr[2]; c.seg = hdr + 3; c.D = 3 * c.nb; c.rows = c.n + c.nb;
+    const int Dm = 3 * x.nb_max, D16m = 16 * ((Dm + 15) / 16);
+    c.D16 = D16m;   // (FX rows: the batch's tile count)
+    c.jmax = x.jmax; c.jpmax = x.jpmax;
+    const int n = c.n, nb = c.nb, D = c.D;
     {   // LDS carve-up (sized by the batch's capacities: arrow3_lds_doubles)
         double* q = ldsA;
-        c.HD = q; q += (size_t)cp.nv_max * 6; c.HB = q; q += (size_t)cp.nv_max * 3; c.CU = q; q += (size_t)cp.nv_max * 3;
-        c.CV = q; q += (size_t)cp.nv_max * 3; c.GG = q; q += (size_t)cp.nv_max * 6; c.ZZ = q; q += (size_t)cp.nv_max * 3;
-        const int Dm = 3 * x.nb_max, D16m = 16 * ((Dm + 15) / 16);
-        c.C0 = q; q += (size_t)(Dm + 1) * Dm; c.S = q; q += (size_t)(Dm + 1) * Dm;
-        c.bB = q; q += Dm; c.xB = q; q += Dm; c.xsB = q; q += Dm; c.scr = q; q += Dm;
-        c.FX = q; q += (size_t)4 * D16m * 3;
+        c.PK = q; q += (size_t)cp.nv_max * 16; c.GZ = q; q += (size_t)cp.nv_max * 12;
+        c.C0 = q; q += (size_t)Dm * (Dm + 1) / 2; c.S = q; q += (size_t)(Dm + 1) * (Dm + 2) / 2;
+        c.bB = q; q += Dm; c.xB = q; q += Dm; c.xsB = q; q += Dm;
+        c.RA = q; q += (size_t)ARROW_NW * Dm;
+        c.FX = q; q += (size_t)ARROW_NW * 4 * D16m * 3;
         c.TB = q; q += (size_t)6 * x.nb_max;
-        c.paircnt = reinterpret_cast<int*>(q);
+        c.red = q;
     }
     {
         double* w = x.ws + (size_t)inst * window_arrow3_workspace_doubles_dev(cp, x.nb_max);
@@ -636,29 +716,34 @@ __global__ void __launch_bounds__(64, 1) arrow3_lm_kernel(const WindowArgs a, co
         c.XS = w; w += (size_t)cp.nv_max * 3;
         c.BB = w; w += (size_t)cp.nv_max * 3 * x.nb_max * 3;
         c.CS = w;
+        c.npad = (size_t)cp.nv_max;
     }
-    c.e_off = x.e_off + (size_t)inst * (cp.nv_max + 1); c.e_perm = x.e_perm + (size_t)inst * cp.nr_max;
-    c.p_off = x.p_off + (size_t)inst * (cp.nv_max + 1); c.p_perm = x.p_perm + (size_t)inst * cp.np_max;
-    c.r_idx = a.r_idx + (size_t)inst * cp.nr_max * 2; c.r_val = a.r_val + (size_t)inst * cp.nr_max * 5;
-    c.p_idx = a.p_idx + (size_t)inst * cp.np_max; c.p_val = a.p_val + (size_t)inst * cp.np_max * 18;
-    // TT is laid out [2][nv][3] with the INSTANCE's nv
+    c.rec = x.rec + (size_t)inst * x.nchunk * x.jmax * 64 * 3;
+    c.prec = x.prec + (size_t)inst * x.nchunk * x.jpmax * 64 * 7;
+    const int32_t* rslot = x.rslot + (size_t)inst * cp.nv_max;
     const double* gin = a.poses_in + (size_t)inst * cp.nv_max * 12;
     double* gout = a.poses + (size_t)inst * cp.nv_max * 12;
-    for (int i = lane; i < 3 * nv; i += 64) { c.TT[i] = gin[(i / 3) * 12 + 9 + i % 3]; c.XS[i] = 0.0; }
-    for (int r = lane; r < D; r += 64) { c.TB[r] = gin[(n + r / 3) * 12 + 9 + r % 3]; c.xsB[r] = 0.0; }
+    for (int i = tid; i < 3 * n; i += 64 * ARROW_NW) { c.TT[i] = gin[rslot[i / 3] * 12 + 9 + i % 3]; c.XS[i] = 0.0; }
+    for (int r = tid; r < D; r += 64 * ARROW_NW) { c.TB[r] = gin[rslot[n + r / 3] * 12 + 9 + r % 3]; c.xsB[r] = 0.0; }
+    for (int i = tid; i < ARROW_NW * Dm; i += 64 * ARROW_NW) c.RA[i] = 0.0;
+    if (tid < 16) c.red[tid] = 0.0;
     __threadfence_block();
-    wsync();
+    __syncthreads();
     constexpr double tau = 1e-5, good_lo = 1.0 / 3.0, good_hi = 2.0 / 3.0;
     constexpr int max_trials = 10;
     double lambda = 0.0, ni = 2.0, cur_chi = 0.0, last_plain = 0.0;
     int it = 0, trials = 0, terminated = 0, buf = 0, shared_edges = 0;
     AT_DECL;
-    const bool active = nv > 0 && c.nr + c.np > 0 && a.iterations > 0;
+    const bool active = nv > 0 && a.counts[inst * 4 + 1] + a.counts[inst * 4 + 2] > 0 && a.iterations > 0;
     if (active) {
         for (; it < a.iterations;) {
             double plain, md, chi_lin;
             AT(0);
+#ifdef LOCAMD_ARROW_TIMING
+            arrow_edges<true, JAC>(a, c, buf, chi_lin, plain, md, shared_edges, at_, at_t);
+#else
             arrow_edges<true, JAC>(a, c, buf, chi_lin, plain, md, shared_edges);
+#endif
             AT(1);
             cur_chi = chi_lin;
             last_plain = plain;
@@ -675,7 +760,11 @@ __global__ void __launch_bounds__(64, 1) arrow3_lm_kernel(const WindowArgs a, co
                 ++trials;
                 double temp_chi, plain2, md2;
                 int us;
+#ifdef LOCAMD_ARROW_TIMING
+                arrow_edges<false, JAC>(a, c, 1 - buf, temp_chi, plain2, md2, us, at_, at_t);
+#else
                 arrow_edges<false, JAC>(a, c, 1 - buf, temp_chi, plain2, md2, us);
+#endif
                 AT(7);
                 last_plain = plain2;
                 if (!ok) temp_chi = DBL_MAX;
@@ -698,17 +787,17 @@ __global__ void __launch_bounds__(64, 1) arrow3_lm_kernel(const WindowArgs a, co
             if (q == max_trials || rho == 0.0) { terminated = 1; break; }
         }
     }
-    wsync();
+    __syncthreads();
     {
-        const double* T = c.TT + (size_t)buf * nv * 3;
-        for (int i = lane; i < 12 * nv; i += 64) {
-            const int p = i / 12, k = i % 12;
-            gout[i] = k < 9 ? gin[i] : (p < n ? T[3 * p + k - 9] : c.TB[buf * nb * 3 + 3 * (p - n) + k - 9]);
+        const double* T = c.TT + (size_t)buf * n * 3;
+        for (int i = tid; i < 12 * c.rows; i += 64 * ARROW_NW) {
+            const int r = i / 12, k = i % 12, slot = rslot[r];
+            gout[slot * 12 + k] = k < 9 ? gin[slot * 12 + k] : (r < n ? T[3 * r + k - 9] : c.TB[buf * nb * 3 + 3 * (r - n) + k - 9]);
         }
-        if (lane == 0) {
+        if (tid == 0) {
             double* res = a.result + (size_t)inst * 8;
             res[0] = last_plain; res[1] = cur_chi; res[2] = lambda; res[3] = (double)it; res[4] = (double)trials;
-            res[5] = (double)terminated; res[6] = (double)shared_edges; res[7] = (double)(2 * 65536 + n + nb) + nb / 16.0;
+            res[5] = (double)terminated; res[6] = (double)shared_edges; res[7] = (double)(2 * 65536 + c.rows) + nb / 16.0;
 #ifdef LOCAMD_ARROW_TIMING
             for (int k = 1; k < 8; ++k) res[k] = (double)at_[k];
 #endif
@@ -728,14 +817,14 @@ hipError_t launch_arrow3_t(const WindowArgs& a, const ArrowAux& x, size_t lds, h
         if (e != hipSuccess) return e;
         attr_set.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL((arrow3_lm_kernel<JAC, NTI>), dim3((unsigned)a.B), dim3(64), lds, stream, a, x);
+    hipLaunchKernelGGL((arrow3_lm_kernel<JAC, NTI>), dim3((unsigned)a.B), dim3(64 * ARROW_NW), lds, stream, a, x);
     return hipGetLastError();
 }
 
 }  // namespace
 
 hipError_t launch_window_arrow3(const WindowArgs& a, const ArrowAux& x, hipStream_t stream) {
-    if (a.B <= 0 || !x.ws || x.nb_max < 1 || x.nb_max > 16) return hipErrorInvalidValue;
+    if (a.B <= 0 || !x.ws || x.nb_max < 1 || x.nb_max > 15 || x.jmax < 1 || x.jpmax < 1) return hipErrorInvalidValue;
     const size_t lds = window_arrow3_lds_bytes(a.caps, x.nb_max);
     if (lds > 160 * 1024 - 512) return hipErrorInvalidValue;
     const int nti = (3 * x.nb_max + 15) / 16;

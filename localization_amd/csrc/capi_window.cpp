@@ -35,11 +35,13 @@ struct loc_window {
     double* d_chain_ws = nullptr;   // chain windows (one lane per window, window_kernel.hip: chain_lm_kernel): its workspace
     double* d_chain3_ws = nullptr;  // translation-only chain windows (chain3_kernel.hip)
     // translation-only chain + dense border windows (arrow3_kernel.hip): per-pose edge lists built on the host, its workspace
-    int32_t *d_anb = nullptr, *d_aeoff = nullptr, *d_aeperm = nullptr, *d_apoff = nullptr, *d_apperm = nullptr;
-    double* d_arrow_ws = nullptr;
+    int32_t *d_ahdr = nullptr, *d_arslot = nullptr;
+    double *d_arec = nullptr, *d_aprec = nullptr, *d_arrow_ws = nullptr;
+    size_t arec_cap = 0, aprec_cap = 0;   // doubles allocated
     int arrow_ws_nb = 0;            // border size d_arrow_ws was allocated for
-    int arrow_nb_max = 0;           // largest border of the batch whose lists are on the device
-    std::vector<int32_t> h_anb, h_aeoff, h_aeperm, h_apoff, h_apperm;
+    int arrow_nb_max = 0, arrow_jmax = 0, arrow_jpmax = 0;   // of the batch whose records are on the device
+    std::vector<int32_t> h_ahdr, h_arslot;
+    std::vector<double> h_arec, h_aprec;
     int resident_topology = 0;      // LOC_WINDOW_KERNEL_* the uploaded batch qualifies for by its structure (the batch-size threshold is applied per solve)
     long long chain_min = -1;       // smallest batch that takes a lane-per-window kernel (-1: the default / LOCAMD_CHAIN_MIN_BATCH)
     long long n_resident = 0;
@@ -79,7 +81,7 @@ int loc_window_destroy(loc_window* w) {
     if (!w) return LOC_OK;
     (void)hipSetDevice(w->device);
     void* ptrs[] = {w->d_anchors, w->d_counts, w->d_ridx, w->d_pidx, w->d_sidx, w->d_poses, w->d_rval, w->d_pval, w->d_sval, w->d_result, w->d_workspace, w->d_poses_in,
-                    w->d_chain_ws, w->d_chain3_ws, w->d_anb, w->d_aeoff, w->d_aeperm, w->d_apoff, w->d_apperm, w->d_arrow_ws};
+                    w->d_chain_ws, w->d_chain3_ws, w->d_ahdr, w->d_arslot, w->d_arec, w->d_aprec, w->d_arrow_ws};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : w->ev) (void)hipEventDestroy(e);
     if (w->h_stage) (void)hipHostFree(w->h_stage);
@@ -221,76 +223,147 @@ static bool translation_only(const loc_window* w, int64_t n, const int32_t* coun
 }
 
 // CHAIN + BORDER ("arrowhead": BASELINE config 4, anchor self-calibration — a tag trajectory whose poses range to a few nodes that
-// are unknowns themselves, localization.cpp:94-98).  The border of an instance = its last nb pose slots, nb = the smallest number
+// are unknowns themselves, localization.cpp:94-98).  The border of an instance = its last nb0 pose slots, nb0 = the smallest number
 // such that every pose-to-pose edge between NON-consecutive slots has an endpoint there; the other poses form the chain (one edge
-// per consecutive pair at most).  Builds the per-pose edge lists arrow3_lm_kernel walks: a chain pose owns its edges to anchors,
-// to border poses and to the previous chain pose; a border pose owns those to lower-slot border poses and to anchors.
-static bool build_arrow_aux(loc_window* w, int64_t n, const int32_t* counts, const int32_t* r_idx, const int32_t* p_idx) {
+// per consecutive pair at most).  The chain is cut into up to four segments at separator poses, which join the border (one level of
+// nested dissection: arrow3_lm_kernel sweeps the segments with one wave each).  Rows = chain rows segment by segment, then border
+// rows (separators first, then the original border in slot order).  A chain row owns its edges to anchors, to border poses and
+// to the previous chain row; a border row those to lower-index border poses and to anchors.  Every row's edges (creation order)
+// and priors are packed as records [chunk of 64 rows][slot][lane].
+static bool build_arrow_aux(loc_window* w, int64_t n, const int32_t* counts, const int32_t* r_idx, const double* r_val, const int32_t* p_idx,
+                            const double* p_val) {
     const locamd::WindowCaps& c = w->caps;
-    int nb_max = 0;
-    w->h_anb.assign((size_t)n, 0);
-    w->h_aeoff.assign((size_t)n * (c.nv_max + 1), 0);
-    w->h_aeperm.assign((size_t)n * (c.nr_max > 0 ? c.nr_max : 1), 0);
-    w->h_apoff.assign((size_t)n * (c.nv_max + 1), 0);
-    w->h_apperm.assign((size_t)n * (c.np_max > 0 ? c.np_max : 1), 0);
-    std::vector<int32_t> owner, fill, pairs;
+    const int NW = 4;
+    const int nchunk = (c.nv_max + 63) / 64;
+    w->h_ahdr.assign((size_t)n * 8, 0);
+    w->h_arslot.assign((size_t)n * c.nv_max, 0);
+    std::vector<int32_t> cls, nedge, nprior, pairs;
+    std::vector<int> seps;
+    // pass 1: structure, record counts
+    int nb_max = 0, jmax = 1, jpmax = 1;
     for (int64_t i = 0; i < n; ++i) {
         const int32_t* cn = counts + i * 4;
         const int nv = cn[0], nr = cn[1], np = cn[2];
         const int32_t* ri = r_idx + (size_t)i * c.nr_max * 2;
-        int nb = 0;
+        int nb0 = 0;
         for (int e = 0; e < nr; ++e) {
             const int v0 = ri[2 * e], v1 = ri[2 * e + 1];
             if (v1 < 0) continue;
             const int hi = v0 > v1 ? v0 : v1, lo = v0 > v1 ? v1 : v0;
-            if (hi - lo != 1 && nv - hi > nb) nb = nv - hi;
+            if (hi - lo != 1 && nv - hi > nb0) nb0 = nv - hi;
         }
-        if (nb < 1 || nb > 16 || nv - nb < 2) return false;
-        const int nc = nv - nb;
-        owner.assign((size_t)(nr > 0 ? nr : 1), 0);
-        pairs.assign((size_t)nc, 0);
-        int32_t* eoff = w->h_aeoff.data() + (size_t)i * (c.nv_max + 1);
+        if (nb0 < 1 || nb0 > 12 || nv - nb0 < 2) return false;
+        const int n0 = nv - nb0;
+        int nseg = n0 / 24;
+        if (nseg > NW) nseg = NW;
+        if (nseg < 1) nseg = 1;
+        const int nb = nb0 + nseg - 1, nc = n0 - (nseg - 1);
+        cls.assign((size_t)nv, 0);
+        seps.clear();
+        for (int k = 1; k < nseg; ++k) seps.push_back((int)((long long)k * n0 / nseg));
+        int32_t* hdr = w->h_ahdr.data() + (size_t)i * 8;
+        int32_t* rslot = w->h_arslot.data() + (size_t)i * c.nv_max;
+        hdr[0] = nb; hdr[1] = nseg; hdr[2] = nc; hdr[3] = 0;
+        int q = 0, si = 0;
+        for (int v = 0; v < n0; ++v) {
+            if (si < (int)seps.size() && v == seps[si]) { cls[v] = -1 - si; rslot[nc + si] = v; ++si; hdr[3 + si] = q; continue; }
+            cls[v] = q; rslot[q] = v; ++q;
+        }
+        for (int s2 = nseg; s2 <= NW; ++s2) hdr[3 + s2] = nc;   // (segments nseg .. NW-1 are empty)
+        for (int v = n0; v < nv; ++v) { const int b = (nseg - 1) + (v - n0); cls[v] = -1 - b; rslot[nc + b] = v; }
+        // owners
+        nedge.assign((size_t)nv, 0); nprior.assign((size_t)nv, 0); pairs.assign((size_t)nc + 1, 0);
         for (int e = 0; e < nr; ++e) {
             const int v0 = ri[2 * e], v1 = ri[2 * e + 1];
-            int o;
-            if (v1 < 0) o = v0;
+            int row;
+            if (v1 < 0) row = cls[v0] >= 0 ? cls[v0] : nc + (-1 - cls[v0]);
             else {
-                const int hi = v0 > v1 ? v0 : v1, lo = v0 > v1 ? v1 : v0;
-                if (hi < nc) { o = hi; if (++pairs[hi] > 1) return false; }   // chain-chain (consecutive by the choice of nb): one per pair
-                else if (lo < nc) o = lo;                                         // chain-border: the chain pose
-                else o = hi;                                                      // border-border: the later one
+                const int c0 = cls[v0], c1 = cls[v1];
+                if (c0 >= 0 && c1 >= 0) {
+                    if (c0 - c1 != 1 && c1 - c0 != 1) return false;   // (cannot happen: non-consecutive edges end in the border)
+                    row = c0 > c1 ? c0 : c1;
+                    if (++pairs[row] > 1) return false;                // one edge per consecutive chain pair
+                } else if (c0 >= 0) row = c0;
+                else if (c1 >= 0) row = c1;
+                else row = nc + ((-1 - c0) > (-1 - c1) ? (-1 - c0) : (-1 - c1));
             }
-            owner[e] = o;
-            ++eoff[o + 1];
+            if (++nedge[row] > jmax) jmax = nedge[row];
         }
-        for (int v = 0; v < nv; ++v) eoff[v + 1] += eoff[v];
-        fill.assign(eoff, eoff + nv);
-        int32_t* eperm = w->h_aeperm.data() + (size_t)i * c.nr_max;
-        for (int e = 0; e < nr; ++e) eperm[fill[owner[e]]++] = e;   // (stable: a pose's edges keep their creation order)
-        int32_t* poff = w->h_apoff.data() + (size_t)i * (c.nv_max + 1);
         const int32_t* pi = p_idx + (size_t)i * c.np_max;
-        for (int e = 0; e < np; ++e) ++poff[pi[e] + 1];
-        for (int v = 0; v < nv; ++v) poff[v + 1] += poff[v];
-        fill.assign(poff, poff + nv);
-        int32_t* pperm = w->h_apperm.data() + (size_t)i * c.np_max;
-        for (int e = 0; e < np; ++e) pperm[fill[pi[e]]++] = e;
-        w->h_anb[i] = nb;
+        for (int e = 0; e < np; ++e) {
+            const int cv = cls[pi[e]], row = cv >= 0 ? cv : nc + (-1 - cv);
+            if (++nprior[row] > jpmax) jpmax = nprior[row];
+        }
         if (nb > nb_max) nb_max = nb;
     }
+    if (jmax > 64 || jpmax > 16 || nb_max > 15) return false;
     if (locamd::window_arrow3_lds_bytes(c, nb_max) > 160 * 1024 - 512) return false;
-    w->arrow_nb_max = nb_max;
+    // pass 2: the records
+    const size_t rec_per = (size_t)nchunk * jmax * 64 * 3, prec_per = (size_t)nchunk * jpmax * 64 * 7;
+    w->h_arec.assign((size_t)n * rec_per, -1.0);
+    w->h_aprec.assign((size_t)n * prec_per, 0.0);
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t* cn = counts + i * 4;
+        const int nv = cn[0], nr = cn[1], np = cn[2];
+        const int32_t* ri = r_idx + (size_t)i * c.nr_max * 2;
+        const double* rv = r_val + (size_t)i * c.nr_max * 5;
+        const int32_t* hdr = w->h_ahdr.data() + (size_t)i * 8;
+        const int32_t* rslot = w->h_arslot.data() + (size_t)i * c.nv_max;
+        const int nb = hdr[0], nc = hdr[2];
+        cls.assign((size_t)nv, 0);
+        for (int r = 0; r < nc + nb; ++r) cls[rslot[r]] = r < nc ? r : -1 - (r - nc);
+        nedge.assign((size_t)nv, 0); nprior.assign((size_t)nv, 0);
+        double* rec = w->h_arec.data() + (size_t)i * rec_per;
+        for (int e = 0; e < nr; ++e) {
+            const int v0 = ri[2 * e], v1 = ri[2 * e + 1];
+            int row, kind, idx, own0;
+            if (v1 < 0) { row = cls[v0] >= 0 ? cls[v0] : nc + (-1 - cls[v0]); kind = 0; idx = -1 - v1; own0 = 1; }
+            else {
+                const int c0 = cls[v0], c1 = cls[v1];
+                if (c0 >= 0 && c1 >= 0) { row = c0 > c1 ? c0 : c1; kind = 1; idx = 0; own0 = c0 > c1; }
+                else if (c0 >= 0) { row = c0; kind = 2; idx = -1 - c1; own0 = 1; }
+                else if (c1 >= 0) { row = c1; kind = 2; idx = -1 - c0; own0 = 0; }
+                else {
+                    const int b0 = -1 - c0, b1 = -1 - c1;
+                    if (b0 == b1) return false;
+                    row = nc + (b0 > b1 ? b0 : b1); kind = 2; idx = b0 > b1 ? b1 : b0; own0 = b0 > b1;
+                }
+            }
+            double* q = rec + (((size_t)(row / 64) * jmax + nedge[row]++) * 64 + row % 64) * 3;
+            q[0] = (double)((idx << 3) | (kind << 1) | own0); q[1] = rv[5 * e]; q[2] = rv[5 * e + 1];
+        }
+        const int32_t* pi = p_idx + (size_t)i * c.np_max;
+        const double* pv = p_val + (size_t)i * c.np_max * 18;
+        double* prec = w->h_aprec.data() + (size_t)i * prec_per;
+        for (int e = 0; e < np; ++e) {
+            const int cv = cls[pi[e]], row = cv >= 0 ? cv : nc + (-1 - cv);
+            double* q = prec + (((size_t)(row / 64) * jpmax + nprior[row]++) * 64 + row % 64) * 7;
+            q[0] = 1.0;
+            for (int k = 0; k < 3; ++k) { q[1 + k] = pv[18 * e + 9 + k]; q[4 + k] = pv[18 * e + 12 + k]; }
+        }
+    }
+    w->arrow_nb_max = nb_max; w->arrow_jmax = jmax; w->arrow_jpmax = jpmax;
     return true;
 }
 static hipError_t upload_arrow_aux(loc_window* w, int64_t n, hipStream_t st) {
     const locamd::WindowCaps& c = w->caps;
-    const size_t B = (size_t)w->B;
+    const size_t B = (size_t)w->B, N = (size_t)n;
     hipError_t e;
-    if (!w->d_anb) {
-        if ((e = hipMalloc((void**)&w->d_anb, B * sizeof(int32_t))) != hipSuccess ||
-            (e = hipMalloc((void**)&w->d_aeoff, B * (c.nv_max + 1) * sizeof(int32_t))) != hipSuccess ||
-            (e = hipMalloc((void**)&w->d_aeperm, B * (c.nr_max > 0 ? c.nr_max : 1) * sizeof(int32_t))) != hipSuccess ||
-            (e = hipMalloc((void**)&w->d_apoff, B * (c.nv_max + 1) * sizeof(int32_t))) != hipSuccess ||
-            (e = hipMalloc((void**)&w->d_apperm, B * (c.np_max > 0 ? c.np_max : 1) * sizeof(int32_t))) != hipSuccess) return e;
+    if (!w->d_ahdr) {
+        if ((e = hipMalloc((void**)&w->d_ahdr, B * 8 * sizeof(int32_t))) != hipSuccess ||
+            (e = hipMalloc((void**)&w->d_arslot, B * c.nv_max * sizeof(int32_t))) != hipSuccess) return e;
+    }
+    if (w->arec_cap < w->h_arec.size()) {
+        if (w->d_arec) (void)hipFree(w->d_arec);
+        w->d_arec = nullptr; w->arec_cap = 0;
+        if ((e = hipMalloc((void**)&w->d_arec, w->h_arec.size() / N * B * sizeof(double))) != hipSuccess) return e;
+        w->arec_cap = w->h_arec.size() / N * B;
+    }
+    if (w->aprec_cap < w->h_aprec.size()) {
+        if (w->d_aprec) (void)hipFree(w->d_aprec);
+        w->d_aprec = nullptr; w->aprec_cap = 0;
+        if ((e = hipMalloc((void**)&w->d_aprec, w->h_aprec.size() / N * B * sizeof(double))) != hipSuccess) return e;
+        w->aprec_cap = w->h_aprec.size() / N * B;
     }
     if (!w->d_arrow_ws || w->arrow_ws_nb < w->arrow_nb_max) {
         if (w->d_arrow_ws) (void)hipFree(w->d_arrow_ws);
@@ -298,12 +371,10 @@ static hipError_t upload_arrow_aux(loc_window* w, int64_t n, hipStream_t st) {
         if ((e = hipMalloc((void**)&w->d_arrow_ws, B * locamd::window_arrow3_workspace_doubles(c, w->arrow_nb_max) * sizeof(double))) != hipSuccess) return e;
         w->arrow_ws_nb = w->arrow_nb_max;
     }
-    const size_t N = (size_t)n;
-    if ((e = hipMemcpyAsync(w->d_anb, w->h_anb.data(), N * sizeof(int32_t), hipMemcpyHostToDevice, st)) != hipSuccess ||
-        (e = hipMemcpyAsync(w->d_aeoff, w->h_aeoff.data(), N * (c.nv_max + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st)) != hipSuccess ||
-        (e = hipMemcpyAsync(w->d_aeperm, w->h_aeperm.data(), N * (c.nr_max > 0 ? c.nr_max : 1) * sizeof(int32_t), hipMemcpyHostToDevice, st)) != hipSuccess ||
-        (e = hipMemcpyAsync(w->d_apoff, w->h_apoff.data(), N * (c.nv_max + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st)) != hipSuccess ||
-        (e = hipMemcpyAsync(w->d_apperm, w->h_apperm.data(), N * (c.np_max > 0 ? c.np_max : 1) * sizeof(int32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(w->d_ahdr, w->h_ahdr.data(), N * 8 * sizeof(int32_t), hipMemcpyHostToDevice, st)) != hipSuccess ||
+        (e = hipMemcpyAsync(w->d_arslot, w->h_arslot.data(), N * c.nv_max * sizeof(int32_t), hipMemcpyHostToDevice, st)) != hipSuccess ||
+        (e = hipMemcpyAsync(w->d_arec, w->h_arec.data(), w->h_arec.size() * sizeof(double), hipMemcpyHostToDevice, st)) != hipSuccess ||
+        (e = hipMemcpyAsync(w->d_aprec, w->h_aprec.data(), w->h_aprec.size() * sizeof(double), hipMemcpyHostToDevice, st)) != hipSuccess) return e;
     return hipStreamSynchronize(st);   // (the host vectors may be rebuilt by the next call)
 }
 
@@ -338,12 +409,12 @@ static int batch_topology(loc_window* w, int64_t n, const int32_t* counts, const
         }
     }
     if (chain) return translation_only(w, n, counts, poses, r_val, p_val) ? LOC_WINDOW_KERNEL_CHAIN3 : LOC_WINDOW_KERNEL_CHAIN;
-    if (c.ns_max == 0 || true) {
+    {
         // (LOCAMD_ARROW3: 0 = never, 1 = whenever the batch qualifies; default: windows of more than 64 poses — below that the
         //  wave-per-window kernel keeps everything in LDS and is the better choice)
         const char* v = getenv("LOCAMD_ARROW3");
         const bool want = v ? v[0] == '1' : c.nv_max > 64;
-        if (want && translation_only(w, n, counts, poses, r_val, p_val) && build_arrow_aux(w, n, counts, r_idx, p_idx)) return LOC_WINDOW_KERNEL_ARROW3;
+        if (want && translation_only(w, n, counts, poses, r_val, p_val) && build_arrow_aux(w, n, counts, r_idx, r_val, p_idx, p_val)) return LOC_WINDOW_KERNEL_ARROW3;
     }
     return LOC_WINDOW_KERNEL_GENERAL;
 }
@@ -362,8 +433,8 @@ static hipError_t launch_any(loc_window* w, const locamd::WindowArgs& a, hipStre
     w->last_kind = kind;
     if (kind == LOC_WINDOW_KERNEL_ARROW3) {
         locamd::ArrowAux x;
-        x.nb = w->d_anb; x.e_off = w->d_aeoff; x.e_perm = w->d_aeperm; x.p_off = w->d_apoff; x.p_perm = w->d_apperm;
-        x.ws = w->d_arrow_ws; x.nb_max = w->arrow_nb_max;
+        x.hdr = w->d_ahdr; x.rslot = w->d_arslot; x.rec = w->d_arec; x.prec = w->d_aprec;
+        x.ws = w->d_arrow_ws; x.nb_max = w->arrow_nb_max; x.jmax = w->arrow_jmax; x.jpmax = w->arrow_jpmax; x.nchunk = (w->caps.nv_max + 63) / 64;
         return locamd::launch_window_arrow3(a, x, st);
     }
     if (kind == LOC_WINDOW_KERNEL_CHAIN3) {

@@ -56,16 +56,17 @@ size_t window_chain3_workspace_doubles(const WindowCaps& c, long long B);
 int window_chain3_lds_mode(const WindowCaps& c, long long B, int n_cus);   // bit 0: (G, y) in LDS, bit 1: the translations in LDS
 hipError_t launch_window_chain3(const WindowArgs& a, double* ws, hipStream_t stream);
 
-// translation-only chain + dense border windows, one wave per window (arrow3_kernel.hip); the per-pose edge lists are built on
-// the host once per upload (capi_window.cpp: build_arrow_aux)
+// translation-only chain + dense border windows (arrow3_kernel.hip): four waves per window.  The host cuts the chain into up to
+// four segments at separator poses (which join the border), orders the rows (chain rows by segment, then border rows) and packs
+// every row's edges and priors as records [chunk of 64 rows][slot][lane] once per upload (capi_window.cpp: build_arrow_aux).
 struct ArrowAux {
-    const int32_t* nb;      // [B] border poses of each instance (its last nb pose slots)
-    const int32_t* e_off;   // [B][nv_max + 1] CSR offsets of the range edges by OWNER pose (a chain pose owns its edges to anchors, to
-    const int32_t* e_perm;  // [B][nr_max]     border poses and to the previous chain pose; a border pose those to lower-slot border poses / anchors)
-    const int32_t* p_off;   // [B][nv_max + 1] priors by pose
-    const int32_t* p_perm;  // [B][np_max]
+    const int32_t* hdr;     // [B][8]  nb (border poses incl. separators), nseg, n (chain rows), seg[0 .. 4] (chain rows of segment s: [seg[s], seg[s+1]))
+    const int32_t* rslot;   // [B][nv_max] pose slot of row r (rows 0 .. n-1: chain, n .. n+nb-1: border)
+    const double* rec;      // [B][nchunk][jmax][64][3]  code, measurement, information; code < 0: none; else (index << 3) | (kind << 1) | own-is-endpoint-0,
+                            //                           kind 0: fixed anchor `index`, 1: the previous chain row, 2: border pose `index`
+    const double* prec;     // [B][nchunk][jpmax][64][7] flag (> 0: a prior), Z^-1.t (3), information diagonal (3)
     double* ws;             // [B][window_arrow3_workspace_doubles]
-    int nb_max;             // largest border in the batch (<= 16)
+    int nb_max, jmax, jpmax, nchunk;
 };
 size_t window_arrow3_workspace_doubles(const WindowCaps& c, int nb_max);
 size_t window_arrow3_lds_bytes(const WindowCaps& c, int nb_max);
