@@ -152,7 +152,8 @@ int loc_snapshot_timing_end(loc_snapshot* s, int32_t* n_launches, double* total_
  * Batched sliding-window graph solver — the reference's general case (BASELINE configs 1, 3, 5 shapes):
  * B independent instances, each the graph one Localization object holds when it calls solve()
  * (localization.cpp:164-170): moving VertexSE3 poses (robot.cpp:75-110), fixed anchors, EdgeSE3Range factors
- * with an antenna lever arm on endpoint 0 (localization.cpp:331-340, types_edge_se3range.cpp:105-114),
+ * with an antenna lever arm on endpoint 0 (localization.cpp:331-340, types_edge_se3range.cpp:105-114; endpoint 1's through
+ * loc_window_set_endpoint1_offsets),
  * EdgeSE3Prior with diagonal information (IMU / lidar, localization.cpp:476-486, 513-525) and EdgeSE3
  * (pose / twist, localization.cpp:263-281, 588-602).  Range and SE3 edges carry RobustKernelCauchy(1) as in the
  * reference (range always; SE3 per the `robust` flag); priors do not.  Range Jacobians: g2o's central differences by default
@@ -199,6 +200,12 @@ int loc_window_solve_host(loc_window* w, int64_t n_instances, const int32_t* cou
                           const int32_t* s_idx, const double* s_val, double* result);
 /* kernel time of the last loc_window_solve_host launch (HIP events on its stream), milliseconds */
 int loc_window_last_kernel_ms(loc_window* w, double* ms);
+/* EdgeSE3Range carries a lever arm per ENDPOINT (Isometry3d offset[2], types_edge_se3range.h:73; setVertexOffset(int, ...),
+ * types_edge_se3range.cpp:99-103; both used in the residual, :108-112).  r_val holds endpoint 0's — the only one the reference
+ * ever sets (localization.cpp:334).  This call supplies endpoint 1's for the instances of every LATER solve / upload: off1 =
+ * [n_instances][nr_max][3] (xyz per range edge; for a fixed endpoint 1 — identity rotation — the point is the anchor + o1), or
+ * NULL to go back to none.  Batches with endpoint-1 lever arms are solved by the general kernel (LOC_WINDOW_KERNEL_GENERAL). */
+int loc_window_set_endpoint1_offsets(loc_window* w, int64_t n_instances, const double* off1_xyz);
 /* LOC_JAC_NUMERIC_G2O (default: the reference's configuration) or LOC_JAC_ANALYTIC (opt-in fast mode) for the EdgeSE3Range
  * factors of every later solve */
 int loc_window_set_jacobian(loc_window* w, int32_t jacobian);

@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = [
     "loc_snapshot_solve_host_kmb", "loc_host_alloc", "loc_host_free",
     "loc_snapshot_timing_begin", "loc_snapshot_timing_end",
     "loc_window_create", "loc_window_destroy", "loc_window_set_anchors", "loc_window_lds_bytes", "loc_window_solve_host",
-    "loc_window_last_kernel_ms", "loc_window_set_jacobian", "loc_window_set_ordering", "loc_window_set_chain_threshold", "loc_window_last_kernel_kind", "loc_window_upload",
+    "loc_window_last_kernel_ms", "loc_window_set_endpoint1_offsets", "loc_window_set_jacobian", "loc_window_set_ordering", "loc_window_set_chain_threshold", "loc_window_last_kernel_kind", "loc_window_upload",
     "loc_window_solve_resident", "loc_window_download", "loc_window_poses_device", "loc_window_result_device",
     "loc_window_timing_begin", "loc_window_timing_end",
     "loc_node_default_config", "loc_node_create", "loc_node_destroy", "loc_node_add_range", "loc_node_add_imu",
@@ -95,6 +95,7 @@ def lib():
     L.loc_window_solve_host.argtypes = [vp, C.c_int64, ip, dp, ip, dp, ip, dp, ip, dp, dp]
     L.loc_window_last_kernel_ms.argtypes = [vp, dp]
     L.loc_window_set_jacobian.argtypes = [vp, C.c_int32]
+    L.loc_window_set_endpoint1_offsets.argtypes = [vp, C.c_int64, dp]
     L.loc_window_set_ordering.argtypes = [vp, C.c_int32]
     L.loc_window_set_chain_threshold.argtypes = [vp, C.c_int64]
     L.loc_window_last_kernel_kind.argtypes = [vp, ip]

@@ -34,6 +34,8 @@ struct loc_window {
     double* d_poses_in = nullptr;   // resident mode: the uploaded initial estimates (every resident solve starts from them)
     double* d_chain_ws = nullptr;   // chain windows (one lane per window, window_kernel.hip: chain_lm_kernel): its workspace
     double* d_chain3_ws = nullptr;  // translation-only chain windows (chain3_kernel.hip)
+    double* d_roff1 = nullptr;      // optional lever arms of endpoint 1 (loc_window_set_endpoint1_offsets), [B][nr_max][3]
+    bool has_off1 = false;
     // translation-only chain + dense border windows (arrow3_kernel.hip): per-pose edge lists built on the host, its workspace
     int32_t *d_ahdr = nullptr, *d_arslot = nullptr;
     double *d_arec = nullptr, *d_aprec = nullptr, *d_arrow_ws = nullptr;
@@ -81,7 +83,7 @@ int loc_window_destroy(loc_window* w) {
     if (!w) return LOC_OK;
     (void)hipSetDevice(w->device);
     void* ptrs[] = {w->d_anchors, w->d_counts, w->d_ridx, w->d_pidx, w->d_sidx, w->d_poses, w->d_rval, w->d_pval, w->d_sval, w->d_result, w->d_workspace, w->d_poses_in,
-                    w->d_chain_ws, w->d_chain3_ws, w->d_ahdr, w->d_arslot, w->d_arec, w->d_aprec, w->d_arrow_ws};
+                    w->d_chain_ws, w->d_chain3_ws, w->d_roff1, w->d_ahdr, w->d_arslot, w->d_arec, w->d_aprec, w->d_arrow_ws};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : w->ev) (void)hipEventDestroy(e);
     if (w->h_stage) (void)hipHostFree(w->h_stage);
@@ -421,6 +423,7 @@ static int batch_topology(loc_window* w, int64_t n, const int32_t* counts, const
 // the kernel a batch of n windows with that structure takes NOW (threshold, ordering override, LOCAMD_CHAIN3=0 for A/B runs)
 static int pick_kernel(const loc_window* w, int64_t n, int topology) {
     const long long mn = w->chain_min >= 0 ? w->chain_min : chain_min_batch();
+    if (w->has_off1) return LOC_WINDOW_KERNEL_GENERAL;   // (lever arms on endpoint 1: only the general kernel evaluates them)
     if (topology == LOC_WINDOW_KERNEL_ARROW3) return w->natural_order ? LOC_WINDOW_KERNEL_GENERAL : LOC_WINDOW_KERNEL_ARROW3;   // (one wave per window: any batch size)
     if (topology == LOC_WINDOW_KERNEL_GENERAL || mn <= 0 || n < mn || w->natural_order) return LOC_WINDOW_KERNEL_GENERAL;
     if (topology == LOC_WINDOW_KERNEL_CHAIN3) {   // LOCAMD_CHAIN3=0: the 6-DoF kernel on a translation-only batch (A/B runs, tests; read per call)
@@ -461,6 +464,21 @@ int loc_window_last_kernel_kind(const loc_window* w, int32_t* kind) {
 int loc_window_set_chain_threshold(loc_window* w, int64_t min_batch) {
     if (!w) return locamd_fail(LOC_ERR_INVALID, "null");
     w->chain_min = min_batch;
+    return LOC_OK;
+}
+
+int loc_window_set_endpoint1_offsets(loc_window* w, int64_t n, const double* off1) {
+    if (!w || (off1 && (n <= 0 || n > w->B))) return locamd_fail(LOC_ERR_INVALID, "set_endpoint1_offsets");
+    if (!off1) { w->has_off1 = false; return LOC_OK; }
+    if (w->caps.nr_max <= 0) return locamd_fail(LOC_ERR_INVALID, "set_endpoint1_offsets: no range edges in this solver");
+    LOC_HIP(hipSetDevice(w->device));
+    if (w->last_stream) LOC_HIP(hipStreamSynchronize(w->last_stream));
+    if (!w->d_roff1) {
+        LOC_HIP(hipMalloc((void**)&w->d_roff1, (size_t)w->B * w->caps.nr_max * 3 * sizeof(double)));
+        LOC_HIP(hipMemset(w->d_roff1, 0, (size_t)w->B * w->caps.nr_max * 3 * sizeof(double)));
+    }
+    LOC_HIP(hipMemcpy(w->d_roff1, off1, (size_t)n * w->caps.nr_max * 3 * sizeof(double), hipMemcpyHostToDevice));
+    w->has_off1 = true;
     return LOC_OK;
 }
 
@@ -510,6 +528,7 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
             locamd::WindowArgs a;
             a.poses = (double*)(d + off[0]); a.poses_in = a.poses; a.jacobian = w->jacobian; a.natural_order = w->natural_order; a.result = (double*)(d + off[1]); a.counts = (const int32_t*)(d + off[2]);
             a.r_val = (const double*)(d + off[3]); a.p_val = (const double*)(d + off[4]); a.s_val = (const double*)(d + off[5]);
+            a.r_off1 = w->has_off1 ? w->d_roff1 : nullptr;
             a.r_idx = (const int32_t*)(d + off[6]); a.p_idx = (const int32_t*)(d + off[7]); a.s_idx = (const int32_t*)(d + off[8]);
             a.anchors = w->d_anchors; a.workspace = w->d_workspace;
             a.n_anchors = w->n_anchors; a.B = (int)n; a.iterations = w->iterations; a.caps = c;
@@ -545,6 +564,7 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
     }
     locamd::WindowArgs a;
     a.counts = w->d_counts; a.poses = w->d_poses; a.poses_in = a.poses; a.jacobian = w->jacobian; a.natural_order = w->natural_order; a.r_idx = w->d_ridx; a.r_val = w->d_rval; a.p_idx = w->d_pidx;
+    a.r_off1 = w->has_off1 ? w->d_roff1 : nullptr;
     a.p_val = w->d_pval; a.s_idx = w->d_sidx; a.s_val = w->d_sval; a.anchors = w->d_anchors; a.result = w->d_result;
     a.workspace = w->d_workspace;
     a.n_anchors = w->n_anchors; a.B = (int)n; a.iterations = w->iterations; a.caps = c;
@@ -613,6 +633,7 @@ int loc_window_solve_resident(loc_window* w, void* hip_stream) {
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : w->stream;
     locamd::WindowArgs a;
     a.counts = w->d_counts; a.poses_in = w->d_poses_in; a.poses = w->d_poses; a.r_idx = w->d_ridx; a.r_val = w->d_rval; a.p_idx = w->d_pidx;
+    a.r_off1 = w->has_off1 ? w->d_roff1 : nullptr;
     a.p_val = w->d_pval; a.s_idx = w->d_sidx; a.s_val = w->d_sval; a.anchors = w->d_anchors; a.result = w->d_result;
     a.workspace = w->d_workspace;
     a.n_anchors = w->n_anchors; a.B = (int)w->n_resident; a.iterations = w->iterations; a.jacobian = w->jacobian;

@@ -235,17 +235,29 @@ int pack(const loc_node* n, Packed& P) {
         std::memcpy(&P.poses[(size_t)kv.second * 12 + 9], v.est.t, sizeof(double) * 3);
     }
     for (auto& kv : anchor_ix) std::memcpy(&P.anchors[(size_t)kv.second * 3], n->vertices.at(kv.first).est.t, sizeof(double) * 3);
-    int nr = 0, np = 0, ns = 0;
+    int nr = 0, np = 0, ns = 0, n_derived = 0;
     for (const auto& e : n->ranges) {
         if (!active2(e.v0, e.v1)) continue;
         int a = e.v0, b = e.v1;
         double off[3] = {e.off[0], e.off[1], e.off[2]};
+        int derived_anchor = -1;
         if (n->vertices.at(a).fixed) {  // the kernel wants endpoint 0 moving; the residual is symmetric
-            if (off[0] != 0 || off[1] != 0 || off[2] != 0) return locamd_fail(LOC_ERR_UNSUPPORTED, "lever arm on a fixed endpoint");
+            if (off[0] != 0 || off[1] != 0 || off[2] != 0) {
+                // a lever arm on a FIXED endpoint 0 (setVertexOffset(0, ...) on a static requester, localization.cpp:334): its point
+                // (X O).t = R o + t never moves — it enters as one more entry of the fixed-vertex table
+                const Vertex& fv = n->vertices.at(a);
+                double pt[3];
+                for (int i = 0; i < 3; ++i) pt[i] = fv.est.R[3 * i] * off[0] + fv.est.R[3 * i + 1] * off[1] + fv.est.R[3 * i + 2] * off[2] + fv.est.t[i];
+                if (anchor_ix.empty() && n_derived == 0) P.anchors.clear();   // (the one-entry placeholder of an anchor-less window)
+                ++n_derived;
+                derived_anchor = (int)(P.anchors.size() / 3);
+                P.anchors.insert(P.anchors.end(), pt, pt + 3);
+                off[0] = off[1] = off[2] = 0.0;
+            }
             std::swap(a, b);
         }
         P.r_idx[(size_t)nr * 2] = slot.at(a);
-        P.r_idx[(size_t)nr * 2 + 1] = n->vertices.at(b).fixed ? -1 - anchor_ix.at(b) : slot.at(b);
+        P.r_idx[(size_t)nr * 2 + 1] = derived_anchor >= 0 ? -1 - derived_anchor : (n->vertices.at(b).fixed ? -1 - anchor_ix.at(b) : slot.at(b));
         if (!n->vertices.at(b).fixed) P.band = std::max(P.band, std::abs(slot.at(a) - slot.at(b)));
         double* v = &P.r_val[(size_t)nr * 5];
         v[0] = e.meas; v[1] = e.info; v[2] = off[0]; v[3] = off[1]; v[4] = off[2];

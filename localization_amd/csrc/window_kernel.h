@@ -31,6 +31,7 @@ struct WindowArgs {
     const double* poses_in;  // initial estimates (may alias `poses`: every instance reads its poses before it writes them)
     double* poses;           // optimised estimates
     const int32_t* r_idx; const double* r_val;
+    const double* r_off1;   // optional [B][nr_max][3]: lever arm of endpoint 1 (types_edge_se3range.h:73 offset[1]); nullptr = none (general kernel only)
     const int32_t* p_idx; const double* p_val;
     const int32_t* s_idx; const double* s_val;
     const double* anchors;  // [n_anchors][3] fixed vertices (identity rotation), shared by all instances

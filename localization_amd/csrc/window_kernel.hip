@@ -305,7 +305,8 @@ struct Lds {
 #pragma clang fp contract(off)
 // one column of the numeric Jacobian of endpoint `which` (0: the pose carrying the lever arm, 1: the other pose)
 template <int D>
-__device__ __forceinline__ double range_jac_numeric(const double* X0, const double* off, const double* X1, const double* q1, int which, double meas) {
+__device__ __forceinline__ double range_jac_numeric(const double* X0, const double* off, const double* X1, const double* q1, int which, double meas,
+                                                    const double* off1 = nullptr) {
     constexpr double delta = 1e-9;
     constexpr double scalar = 1.0 / (2 * delta);
     double Rp[9], tp[3], Rm[9], tm[3];
@@ -315,6 +316,11 @@ __device__ __forceinline__ double range_jac_numeric(const double* X0, const doub
         oplus_axis_plain<D>(X0, X0 + 9, -delta, Rm, tm);
         ep = range_error_plain(Rp, tp, off, q1, meas);
         em = range_error_plain(Rm, tm, off, q1, meas);
+    } else if (off1) {   // endpoint 1 carries a lever arm too: its point is (X1 * fromVectorMQT(+-delta e_D)) * o1
+        perturbed_point_plain<D>(X1, X1 + 9, off1, delta, tp);
+        perturbed_point_plain<D>(X1, X1 + 9, off1, -delta, tm);
+        ep = range_error_plain(X0, X0 + 9, off, tp, meas);
+        em = range_error_plain(X0, X0 + 9, off, tm, meas);
     } else {
         oplus_axis_plain<D>(X1, X1 + 9, delta, Rp, tp);   // endpoint 1 has no lever arm: its point is its translation
         oplus_axis_plain<D>(X1, X1 + 9, -delta, Rm, tm);
@@ -352,6 +358,16 @@ __device__ __forceinline__ void evaluate_edges(const WindowArgs& a, const Lds& L
         p0[0] += X0[9]; p0[1] += X0[10]; p0[2] += X0[11];
         if (v1 >= 0) { p1[0] = L.pose[v1 * 12 + 9]; p1[1] = L.pose[v1 * 12 + 10]; p1[2] = L.pose[v1 * 12 + 11]; }
         else { const double* an = a.anchors + (size_t)(-1 - v1) * 3; p1[0] = an[0]; p1[1] = an[1]; p1[2] = an[2]; }
+        // optional lever arm on endpoint 1 (EdgeSE3Range::offset[1], types_edge_se3range.h:73, .cpp:99-103, 111): (X1 * O1).t; a fixed
+        // vertex has the identity rotation (localization.cpp:100-106), so its point is the anchor + o1
+        double off1[3] = {0.0, 0.0, 0.0};
+        const bool has1 = a.r_off1 != nullptr;
+        if (has1) {
+            const double* o1 = a.r_off1 + ((size_t)inst * a.caps.nr_max + e) * 3;
+            off1[0] = o1[0]; off1[1] = o1[1]; off1[2] = o1[2];
+            if (v1 >= 0) perturbed_point_plain<0>(L.pose + v1 * 12, L.pose + v1 * 12 + 9, off1, 0.0, p1);   // X1 * o1, a plain CPU build's operation order
+            else { p1[0] = off1[0] + p1[0]; p1[1] = off1[1] + p1[1]; p1[2] = off1[2] + p1[2]; }
+        }
         double u[3] = {p0[0] - p1[0], p0[1] - p1[1], p0[2] - p1[2]};
         const double n = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
         const double err = JAC == 0 ? meas - n : range_error_plain(X0, X0 + 9, off, p1, meas);
@@ -375,7 +391,11 @@ __device__ __forceinline__ void evaluate_edges(const WindowArgs& a, const Lds& L
                     double uR1[3];
                     mat_tvec(L.pose + v1 * 12, u, uR1);
                     rec[6] = uR1[0]; rec[7] = uR1[1]; rec[8] = uR1[2];
-                } else { rec[6] = 0; rec[7] = 0; rec[8] = 0; }
+                    // dp1/dv = -2 R1 [o1]x  =>  de/dv1 = -2 (uR1 x o1)
+                    rec[9] = -2.0 * (uR1[1] * off1[2] - uR1[2] * off1[1]);
+                    rec[10] = -2.0 * (uR1[2] * off1[0] - uR1[0] * off1[2]);
+                    rec[11] = -2.0 * (uR1[0] * off1[1] - uR1[1] * off1[0]);
+                } else { rec[6] = 0; rec[7] = 0; rec[8] = 0; rec[9] = 0; rec[10] = 0; rec[11] = 0; }
             } else {
                 const double* X1 = v1 >= 0 ? L.pose + v1 * 12 : X0;
                 rec[0] = range_jac_numeric<0>(X0, off, X1, p1, 0, meas);
@@ -384,13 +404,18 @@ __device__ __forceinline__ void evaluate_edges(const WindowArgs& a, const Lds& L
                 rec[3] = range_jac_numeric<3>(X0, off, X1, p1, 0, meas);
                 rec[4] = range_jac_numeric<4>(X0, off, X1, p1, 0, meas);
                 rec[5] = range_jac_numeric<5>(X0, off, X1, p1, 0, meas);
-                if (v1 >= 0) {  // (rotating endpoint 1 does not move its point: those three columns are exactly 0)
-                    rec[6] = range_jac_numeric<0>(X0, off, X1, p1, 1, meas);
-                    rec[7] = range_jac_numeric<1>(X0, off, X1, p1, 1, meas);
-                    rec[8] = range_jac_numeric<2>(X0, off, X1, p1, 1, meas);
-                } else { rec[6] = 0; rec[7] = 0; rec[8] = 0; }
+                const double* o1 = (has1 && v1 >= 0) ? off1 : nullptr;
+                if (v1 >= 0) {  // (without a lever arm, rotating endpoint 1 does not move its point: those three columns are exactly 0)
+                    rec[6] = range_jac_numeric<0>(X0, off, X1, p1, 1, meas, o1);
+                    rec[7] = range_jac_numeric<1>(X0, off, X1, p1, 1, meas, o1);
+                    rec[8] = range_jac_numeric<2>(X0, off, X1, p1, 1, meas, o1);
+                    if (o1) {
+                        rec[9] = range_jac_numeric<3>(X0, off, X1, p1, 1, meas, o1);
+                        rec[10] = range_jac_numeric<4>(X0, off, X1, p1, 1, meas, o1);
+                        rec[11] = range_jac_numeric<5>(X0, off, X1, p1, 1, meas, o1);
+                    } else { rec[9] = 0; rec[10] = 0; rec[11] = 0; }
+                } else { rec[6] = 0; rec[7] = 0; rec[8] = 0; rec[9] = 0; rec[10] = 0; rec[11] = 0; }
             }
-            rec[9] = 0; rec[10] = 0; rec[11] = 0;
             const double wr = info / aux;  // rho' * Omega
             rec[12] = wr;
             rec[13] = -wr * err;           // omega_r

@@ -32,6 +32,7 @@ class WindowBatch:
         self.s_idx = np.zeros((self.B, max(ns_max, 1), 4), dtype=np.int32)
         self.s_val = np.zeros((self.B, max(ns_max, 1), 48))
         self.result = np.zeros((self.B, 8))
+        self.r_off1 = None   # optional lever arms of endpoint 1, [B][nr_max][3] (loc_window_set_endpoint1_offsets); created by add_range(off1=...)
 
     def add_pose(self, i, t, R=None):
         v = int(self.counts[i, 0])
@@ -41,11 +42,15 @@ class WindowBatch:
         self.counts[i, 0] = v + 1
         return v
 
-    def add_range(self, i, v0, v1, meas, info, off=(0.0, 0.0, 0.0), anchor=False):
+    def add_range(self, i, v0, v1, meas, info, off=(0.0, 0.0, 0.0), anchor=False, off1=None):
         e = int(self.counts[i, 1])
         assert e < self.caps[1]
         self.r_idx[i, e] = (v0, -1 - v1 if anchor else v1)
         self.r_val[i, e] = (meas, info, off[0], off[1], off[2])
+        if off1 is not None:
+            if self.r_off1 is None:
+                self.r_off1 = np.zeros((self.B, max(self.caps[1], 1), 3))
+            self.r_off1[i, e] = off1
         self.counts[i, 1] = e + 1
 
     def add_prior(self, i, v, t, R, info_diag):
@@ -99,8 +104,14 @@ class WindowSolver:
         except Exception:
             pass
 
+    def _endpoint1(self, wb):
+        dp = C.POINTER(C.c_double)
+        off1 = getattr(wb, "r_off1", None)
+        check(self.L.loc_window_set_endpoint1_offsets(self.h, wb.B, None if off1 is None else np.ascontiguousarray(off1).ctypes.data_as(dp)))
+
     def solve(self, wb: WindowBatch):
         assert wb.caps == self.caps and wb.B <= self.B
+        self._endpoint1(wb)
         ip, dp = C.POINTER(C.c_int32), C.POINTER(C.c_double)
         for a in (wb.counts, wb.poses, wb.r_idx, wb.r_val, wb.p_idx, wb.p_val, wb.s_idx, wb.s_val, wb.result):
             assert a.flags["C_CONTIGUOUS"]
@@ -114,6 +125,7 @@ class WindowSolver:
     # ---- device-resident operation: upload once, solve any number of times from the uploaded estimates, download
     def upload(self, wb: WindowBatch):
         assert wb.caps == self.caps and wb.B <= self.B
+        self._endpoint1(wb)
         ip, dp = C.POINTER(C.c_int32), C.POINTER(C.c_double)
         check(self.L.loc_window_upload(self.h, wb.B, wb.counts.ctypes.data_as(ip), wb.poses.ctypes.data_as(dp),
                                        wb.r_idx.ctypes.data_as(ip), wb.r_val.ctypes.data_as(dp),

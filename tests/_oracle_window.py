@@ -18,7 +18,8 @@ def oracle_solve_instance(wb, i, anchors, iterations=10, jac_mode=None):
     for e in range(nr):
         v0, v1 = int(wb.r_idx[i, e, 0]), int(wb.r_idx[i, e, 1])
         meas, info = wb.r_val[i, e, 0], wb.r_val[i, e, 1]
-        G.add_range_edge(base + v0, (-1 - v1) if v1 < 0 else base + v1, meas, info, off0=wb.r_val[i, e, 2:5].copy())
+        o1 = None if getattr(wb, "r_off1", None) is None else wb.r_off1[i, e].copy()
+        G.add_range_edge(base + v0, (-1 - v1) if v1 < 0 else base + v1, meas, info, off0=wb.r_val[i, e, 2:5].copy(), off1=o1)
     for e in range(np_):
         Ri = wb.p_val[i, e, :9].reshape(3, 3); ti = wb.p_val[i, e, 9:12]
         G.add_prior_edge(base + int(wb.p_idx[i, e]), -Ri.T @ ti, Ri.T, np.diag(wb.p_val[i, e, 12:18]))

@@ -576,3 +576,26 @@ def test_one_command_bag_replay_tool(gpu, bag, tmp_path):
     tail = node.path(200)[5:10]
     assert np.abs(opt[-5:, 0] - tail[:, 0]).max() < 1e-6 and np.abs(opt[-5:, 1:4] - tail[:, 1:4]).max() < 1e-5
     assert np.abs(opt[-5, 1:4] - opt[-6, 1:4]).max() < 1e-5    # (path[T/2] was already logged by the last publish)
+
+
+@pytest.mark.parametrize("jac", ["analytic", "numeric"])
+def test_lever_arm_on_a_fixed_requester(gpu, bag, jac):
+    """A range whose REQUESTER is a static node with an antenna offset: addRangeEdge sets offset[0] on the requester's vertex
+    (localization.cpp:331-334) — here a fixed anchor, whose point (X O).t = anchor + o never moves.  The node enters it as one
+    more fixed point; the oracle evaluates (X O).t on the fixed vertex itself."""
+    antenna = np.array([[0.1, 0.0, -0.05], [0.0, 0.2, 0.1], [-0.15, 0.05, 0.0]])
+    cfg = dict(trajectory_length=8, maximum_velocity=5.0, distance_outlier=10.0, maximum_iteration=10, minimum_optimize_error=1e9, publish_range=True)
+    node, ora = _pair(bag, cfg, antenna=antenna, jac=jac)
+    worst, solves = 0.0, 0
+    for i in range(80):
+        anchor, stamp = int(bag["uwb_responder"][i]), float(bag["uwb_stamp"][i])
+        d, err = float(bag["uwb_distance"][i]), float(bag["uwb_distance_err"][i])
+        # every third message is the anchor ranging the tag (requester = the static node, antenna 2 or 3), the others as recorded
+        args = (anchor, 200, stamp, d, err, 2 + i % 2, "uwb") if i % 3 == 1 else (200, anchor, stamp, d, err, 1, "uwb")
+        outs = [obj.add_range(*args) for obj in (node, ora)]
+        assert outs[0]["solved"] == outs[1]["solved"]
+        if outs[0]["solved"]:
+            solves += 1
+            worst = max(worst, np.abs(outs[0]["realtime"][1:] - outs[1]["realtime"][1:]).max())
+    assert solves >= 50 and worst < (1e-7 if jac == "analytic" else 1e-4), (solves, worst)
+    node.close()

@@ -525,11 +525,10 @@ def test_chain_kernel_matches_oracle(gpu, T, with_imu, lever, jac, twist):
     assert np.array_equal(wb2.result, res)
 
 
-def test_skyline_window_matches_chain_kernel_600_poses(gpu):
-    """Windows of 513 .. 1024 poses take the envelope (skyline) factorisation in the caller's order; the oracle's dense solve of
-    3600 unknowns is out of reach for a unit test, so the check is against the other independent implementation of the same
-    problem: the one-lane-per-window block-tridiagonal kernel (forced by the threshold), whose own parity with the oracle is
-    held by test_chain_kernel_matches_oracle.  Same LM trajectory, same poses."""
+def test_skyline_window_matches_oracle_and_chain_kernel_600_poses(gpu):
+    """Windows of 513 .. 1024 poses take the envelope (skyline) factorisation in the caller's order: against the oracle (3600
+    unknowns per window) and against the other independent implementation of the same problem, the one-lane-per-window
+    block-tridiagonal kernel (forced by the threshold).  Same LM trajectory, same poses."""
     import localization_amd as la
     T, B = 600, 2
     rng = np.random.default_rng(600)
@@ -548,6 +547,7 @@ def test_skyline_window_matches_chain_kernel_600_poses(gpu):
                     if kk == k: wb.add_range(i, k, a, d, info, off, anchor=True)
                 for (k0, k1, d, info) in smooth:
                     if k1 == k: wb.add_range(i, k0, k1, d, info)
+    before = wbs[0].poses.copy()
     sky = la.WindowSolver(ANCH, B, T, nr_max, 0, 0, bw_max=1, chain_threshold=0, jacobian="analytic")
     res_sky = sky.solve(wbs[0]).copy()
     sky.close()
@@ -560,6 +560,17 @@ def test_skyline_window_matches_chain_kernel_600_poses(gpu):
     assert np.array_equal(res_sky[:, 3:6], res_chain[:, 3:6])                                # iterations, trials, terminated
     assert np.abs(res_sky[:, 0] - res_chain[:, 0]).max() <= 1e-6 * np.abs(res_sky[:, 0]).max()
     assert (res_sky[:, 1] < 0.5 * 1e9).all() and (res_sky[:, 4] >= 10).all()
+    # ... and against the oracle itself (its envelope Cholesky takes ~0.2 s per 600-pose solve): the 513 .. 1024-pose path has its own
+    # oracle check, not only the comparison with another kernel
+    from _oracle_window import oracle_solve_instance
+    fresh = la.WindowBatch(B, T, nr_max, 0, 0)
+    for name in ("counts", "r_idx", "r_val", "p_idx", "p_val", "s_idx", "s_val"):
+        getattr(fresh, name)[:] = getattr(wbs[0], name)
+    fresh.poses[:] = before
+    for i in range(B):
+        poses, chi, st = oracle_solve_instance(fresh, i, ANCH)
+        assert np.abs(wbs[0].poses[i] - poses).max() < 1e-7, (i, np.abs(wbs[0].poses[i] - poses).max())
+        assert abs(res_sky[i, 0] - chi) <= 1e-6 * max(1.0, abs(chi)) and res_sky[i, 4] == st.lm_trials
 
 
 def test_chain_kernel_failed_cholesky_like_g2o(gpu):
@@ -590,3 +601,56 @@ def test_chain_kernel_failed_cholesky_like_g2o(gpu):
     assert want[2][2].terminated == 1 and want[2][2].lm_trials == 10
     for i in (0, 1, 3, 4):
         assert np.abs(wb.poses[i] - want[i][0]).max() < 1e-7
+
+
+@pytest.mark.parametrize("T,jac", [(8, "analytic"), (8, "numeric"), (24, "analytic"), (70, "numeric")])
+def test_range_lever_arm_on_endpoint1_and_on_fixed_endpoints(gpu, T, jac):
+    """EdgeSE3Range carries a lever arm per endpoint (Isometry3d offset[2], types_edge_se3range.h:73; setVertexOffset(int, ...),
+    types_edge_se3range.cpp:99-103; both in the residual, :108-112).  The reference only ever sets endpoint 0's; endpoint 1's goes
+    through loc_window_set_endpoint1_offsets: peer ranges between poses with antennas on BOTH ends, ranges to anchors whose own
+    antenna sits off the surveyed point, in LDS (T = 8), workspace (24) and eight-wave (70) windows."""
+    import localization_amd as la
+    from oracle import oracle as O
+    from _oracle_window import oracle_solve_instance
+    B = 5
+    rng = np.random.default_rng(900 + T + len(jac))
+    wb = la.WindowBatch(B, T, 3 * T + 4, T, 0)
+    for i in range(B):
+        est_t, est_R, off, ranges, smooth, priors, _ = _random_window(rng, T, True, False, True)
+        for k in range(T): wb.add_pose(i, est_t[k], est_R[k])
+        for k in range(T):
+            for (kk, a, d, info) in ranges:
+                if kk == k: wb.add_range(i, k, a, d, info, off, anchor=True, off1=(0.05, -0.02, 0.1) if k % 2 else None)   # the anchor's own antenna
+            for (k0, k1, d, info) in smooth:
+                if k1 == k: wb.add_range(i, k0, k1, d, info)
+            if k >= 3 and k % 3 == 0:    # a peer range between two poses of the window, antennas on both ends (either storage order)
+                a, b = (k, k - 3) if k % 2 else (k - 3, k)
+                wb.add_range(i, a, b, float(np.linalg.norm(est_t[a] - est_t[b]) + rng.normal(0, 0.03)), 1 / 0.055 ** 2, (0.1, 0.0, -0.05), off1=(-0.08, 0.03, 0.02))
+        for (k, t, R, dg) in priors: wb.add_prior(i, k, t, R, dg)
+    wb._initial = wb.poses.copy()
+    mode = O.JAC_ANALYTIC if jac == "analytic" else O.JAC_NUMERIC_G2O
+    want = [oracle_solve_instance(wb, i, ANCH, jac_mode=mode) for i in range(B)]
+    zero = [oracle_solve_instance(_without_off1(la, wb), i, ANCH, jac_mode=mode)[0] for i in range(1)]
+    s = la.WindowSolver(ANCH, B, *wb.caps, jacobian=jac, bw_max=3, chain_threshold=1)
+    res = s.solve(wb).copy()
+    assert s.last_kernel_kind() == "window_lm_kernel"
+    tol = 1e-7 if jac == "analytic" else 1e-5
+    for i in range(B):
+        poses, chi, st = want[i]
+        d = np.abs(wb.poses[i] - poses).max()
+        assert d < tol, (i, d)
+        assert abs(res[i, 0] - chi) <= (1e-6 if jac == "analytic" else 1e-4) * max(1.0, abs(chi))
+    assert np.abs(want[0][0] - zero[0]).max() > 1e-3      # (the lever arms matter: without them the oracle lands elsewhere)
+    # clearing them again: the next solve is the plain one
+    plain = _without_off1(la, wb)
+    s.solve(plain)
+    assert np.abs(plain.poses[0] - zero[0]).max() < tol
+    s.close()
+
+
+def _without_off1(la, wb):
+    out = la.WindowBatch(wb.B, *wb.caps)
+    for name in ("counts", "r_idx", "r_val", "p_idx", "p_val", "s_idx", "s_val"):
+        getattr(out, name)[:] = getattr(wb, name)
+    out.poses[:] = wb._initial if hasattr(wb, "_initial") else wb.poses
+    return out
