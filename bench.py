@@ -47,7 +47,7 @@ def kernel_source_hash(names):
 
 
 SNAPSHOT_KERNEL_SOURCES = ("snapshot_kernel.hip", "snapshot_kernel.h", "device_math.h")
-WINDOW_KERNEL_SOURCES = ("window_kernel.hip", "window_kernel.h", "device_math.h", "numeric_jacobian.h")
+WINDOW_KERNEL_SOURCES = ("window_kernel.hip", "chain3_kernel.hip", "arrow3_kernel.hip", "window_kernel.h", "device_math.h", "numeric_jacobian.h")
 
 
 def window_traffic(leg, world):
@@ -361,6 +361,7 @@ def _window_leg(D, args, wb, anchors, bw_max, name, workload, metric, unit, algo
         res["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
         res["roofline"]["traffic_unit"] = "bytes per launch"
         res["roofline"]["traffic_source"] = tr["source"]
+        res["roofline"]["traffic_calibration"] = tr.get("calibration")
         res["roofline"]["traffic_rate"] = {"achieved": tr["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                            "frac": tr["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                            "note": "PMC-measured HBM-side bytes of the same launch shape / live kernel time: what the memory system "
