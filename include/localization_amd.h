@@ -234,9 +234,15 @@ int loc_window_set_chain_threshold(loc_window* w, int64_t min_batch);
  *            self-calibration, BASELINE config 4; "every node moves", localization.cpp:94-98): the chain cut into four segments
  *            (one wave each), block-tridiagonal sweeps + the border's Schur complement on the f64 matrix cores; taken by
  *            windows of more than 64 poses (any batch size)
+ *   TREE     tree_wave_kernel: batches (>= 256 windows) in which EVERY window has the same structure (same counts and index
+ *            tables: one graph replayed with different measurements) and that structure is a forest of up to 64 poses (BASELINE
+ *            config 5: the key-frame star of addPoseEdge, localization.cpp:254-290, + one anchor range per pose).  The fill-free
+ *            elimination schedule is computed once on the host; one wave per window with LANE = POSE and a pose's whole solver
+ *            state in that lane's registers (no workspace in memory), elimination by height.  (Nodes with several EdgeSE3 to
+ *            their parent: tree_lm_kernel, one lane per window on the same schedule.)
  * All of them run the same LM and agree to the tolerances of DESIGN.md §3; result[6] / result[7] keep their meaning (the
  * lane-per-window kernels eliminate in pose order: result[7] = nv * 65536 + 2 nv - 1). */
-enum { LOC_WINDOW_KERNEL_NONE = -1, LOC_WINDOW_KERNEL_GENERAL = 0, LOC_WINDOW_KERNEL_CHAIN = 1, LOC_WINDOW_KERNEL_CHAIN3 = 2, LOC_WINDOW_KERNEL_ARROW3 = 3 };
+enum { LOC_WINDOW_KERNEL_NONE = -1, LOC_WINDOW_KERNEL_GENERAL = 0, LOC_WINDOW_KERNEL_CHAIN = 1, LOC_WINDOW_KERNEL_CHAIN3 = 2, LOC_WINDOW_KERNEL_ARROW3 = 3, LOC_WINDOW_KERNEL_TREE = 4 };
 int loc_window_last_kernel_kind(const loc_window* w, int32_t* kind);
 /* Device-resident operation: upload n instances once (same host layouts as loc_window_solve_host), then run
  * loc_window_solve_resident any number of times — each launch starts from the uploaded estimates, is asynchronous on

@@ -6,8 +6,10 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <algorithm>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "window_kernel.h"
@@ -34,6 +36,12 @@ struct loc_window {
     double* d_poses_in = nullptr;   // resident mode: the uploaded initial estimates (every resident solve starts from them)
     double* d_chain_ws = nullptr;   // chain windows (one lane per window, window_kernel.hip: chain_lm_kernel): its workspace
     double* d_chain3_ws = nullptr;  // translation-only chain windows (chain3_kernel.hip)
+    // forest windows of one shared topology (window_kernel.hip: tree_lm_kernel): the schedule (one int table on the device), its workspace
+    int32_t* d_tsched = nullptr;
+    size_t tsched_cap = 0;
+    std::vector<int32_t> h_tsched;
+    locamd::TreeSched tsched{};
+    double* d_tree_ws = nullptr;
     double* d_roff1 = nullptr;      // optional lever arms of endpoint 1 (loc_window_set_endpoint1_offsets), [B][nr_max][3]
     bool has_off1 = false;
     // translation-only chain + dense border windows (arrow3_kernel.hip): per-pose edge lists built on the host, its workspace
@@ -83,7 +91,7 @@ int loc_window_destroy(loc_window* w) {
     if (!w) return LOC_OK;
     (void)hipSetDevice(w->device);
     void* ptrs[] = {w->d_anchors, w->d_counts, w->d_ridx, w->d_pidx, w->d_sidx, w->d_poses, w->d_rval, w->d_pval, w->d_sval, w->d_result, w->d_workspace, w->d_poses_in,
-                    w->d_chain_ws, w->d_chain3_ws, w->d_roff1, w->d_ahdr, w->d_arslot, w->d_arec, w->d_aprec, w->d_arrow_ws};
+                    w->d_chain_ws, w->d_chain3_ws, w->d_roff1, w->d_tsched, w->d_tree_ws, w->d_ahdr, w->d_arslot, w->d_arec, w->d_aprec, w->d_arrow_ws};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : w->ev) (void)hipEventDestroy(e);
     if (w->h_stage) (void)hipHostFree(w->h_stage);
@@ -380,7 +388,150 @@ static hipError_t upload_arrow_aux(loc_window* w, int64_t n, hipStream_t st) {
     return hipStreamSynchronize(st);   // (the host vectors may be rebuilt by the next call)
 }
 
-// what the batch qualifies for BY ITS STRUCTURE: LOC_WINDOW_KERNEL_GENERAL, _CHAIN (block-tridiagonal, 6-DoF), _CHAIN3 or _ARROW3
+// FOREST windows of ONE shared topology (BASELINE config 5: the key-frame star of addPoseEdge, localization.cpp:254-290, replayed
+// with different measurements in every instance): every instance has the same counts and index tables, and the pose-to-pose
+// edges form a forest.  Builds the elimination schedule tree_lm_kernel walks: nodes in post-order (children before their parent,
+// a node's children heavy subtree first so that the leaves of one parent are consecutive), per node its parent and its edges.
+// Layout of the int table: node[nv] par[nv] r_off[nv+1] r_list[nr] p_off[nv+1] p_list[np] s_off[nv+1] s_list[ns] r_idx[2 nr] s_idx[4 ns].
+static bool build_tree_sched(loc_window* w, int64_t n, const int32_t* counts, const int32_t* r_idx, const int32_t* p_idx, const int32_t* s_idx) {
+    const locamd::WindowCaps& c = w->caps;
+    const int nv = counts[0], nr = counts[1], np = counts[2], ns = counts[3];
+    if (nv < 2 || nv > 64 || w->has_off1) return false;
+    for (int64_t i = 1; i < n; ++i) {   // one topology
+        if (std::memcmp(counts + i * 4, counts, 4 * sizeof(int32_t)) != 0) return false;
+        if (nr && std::memcmp(r_idx + (size_t)i * c.nr_max * 2, r_idx, (size_t)nr * 2 * sizeof(int32_t)) != 0) return false;
+        if (np && std::memcmp(p_idx + (size_t)i * c.np_max, p_idx, (size_t)np * sizeof(int32_t)) != 0) return false;
+        if (ns && std::memcmp(s_idx + (size_t)i * c.ns_max * 4, s_idx, (size_t)ns * 4 * sizeof(int32_t)) != 0) return false;
+    }
+    // adjacency (pairs joined by at least one edge); a forest has no cycle: union-find on the distinct pairs
+    std::vector<int> uf((size_t)nv);
+    for (int v = 0; v < nv; ++v) uf[(size_t)v] = v;
+    auto find = [&](int v) { while (uf[(size_t)v] != v) { uf[(size_t)v] = uf[(size_t)uf[(size_t)v]]; v = uf[(size_t)v]; } return v; };
+    std::vector<std::vector<int>> adj((size_t)nv);
+    auto join = [&](int a, int b) -> bool {
+        for (int x : adj[(size_t)a]) if (x == b) return true;   // a second edge on the same pair
+        const int ra = find(a), rb = find(b);
+        if (ra == rb) return false;                             // a cycle
+        uf[(size_t)ra] = rb;
+        adj[(size_t)a].push_back(b); adj[(size_t)b].push_back(a);
+        return true;
+    };
+    for (int e = 0; e < nr; ++e) if (r_idx[2 * e + 1] >= 0 && !join(r_idx[2 * e], r_idx[2 * e + 1])) return false;
+    for (int e = 0; e < ns; ++e) if (!join(s_idx[4 * e], s_idx[4 * e + 1])) return false;
+    // roots = the lowest slot of every component; parents towards the root; subtree sizes; post-order, heavy child first
+    std::vector<int> parent((size_t)nv, -2), size((size_t)nv, 1), order, stack, depth((size_t)nv, 0);
+    int nroots = 0, maxdepth = 0;
+    std::vector<int> bfs;
+    for (int root = 0; root < nv; ++root) {
+        if (parent[(size_t)root] != -2) continue;
+        parent[(size_t)root] = -1; ++nroots;
+        const size_t b0 = bfs.size();
+        bfs.push_back(root);
+        for (size_t h = b0; h < bfs.size(); ++h) {
+            const int v = bfs[h];
+            for (int x : adj[(size_t)v]) if (parent[(size_t)x] == -2) { parent[(size_t)x] = v; depth[(size_t)x] = depth[(size_t)v] + 1; if (depth[(size_t)x] > maxdepth) maxdepth = depth[(size_t)x]; bfs.push_back(x); }
+        }
+        for (size_t h = bfs.size(); h-- > b0 + 1;) size[(size_t)parent[(size_t)bfs[h]]] += size[(size_t)bfs[h]];
+    }
+    std::vector<std::vector<int>> kids((size_t)nv);
+    for (int v = 0; v < nv; ++v) if (parent[(size_t)v] >= 0) kids[(size_t)parent[(size_t)v]].push_back(v);
+    for (auto& k : kids) std::stable_sort(k.begin(), k.end(), [&](int a2, int b2) { return size[(size_t)a2] > size[(size_t)b2]; });
+    // iterative post-order
+    for (int root = 0; root < nv; ++root) {
+        if (parent[(size_t)root] != -1) continue;
+        std::vector<std::pair<int, size_t>> st;
+        st.push_back({root, 0});
+        while (!st.empty()) {
+            auto& top = st.back();
+            if (top.second < kids[(size_t)top.first].size()) { const int ch = kids[(size_t)top.first][top.second++]; st.push_back({ch, 0}); }
+            else { order.push_back(top.first); st.pop_back(); }
+        }
+    }
+    if ((int)order.size() != nv) return false;
+    std::vector<int> pos((size_t)nv);
+    for (int k = 0; k < nv; ++k) pos[(size_t)order[(size_t)k]] = k;
+    // edges by node: a unary edge belongs to its pose; an edge between a node and its parent to the node (the child)
+    std::vector<std::vector<int>> re((size_t)nv), pe((size_t)nv), se((size_t)nv);
+    for (int e = 0; e < nr; ++e) {
+        const int v0 = r_idx[2 * e], v1 = r_idx[2 * e + 1];
+        if (v1 < 0) re[(size_t)pos[(size_t)v0]].push_back(e);
+        else re[(size_t)pos[(size_t)(parent[(size_t)v0] == v1 ? v0 : v1)]].push_back(e);
+    }
+    for (int e = 0; e < np; ++e) pe[(size_t)pos[(size_t)p_idx[e]]].push_back(e);
+    for (int e = 0; e < ns; ++e) {
+        const int vi = s_idx[4 * e], vj = s_idx[4 * e + 1];
+        se[(size_t)pos[(size_t)(parent[(size_t)vi] == vj ? vi : vj)]].push_back(e);
+    }
+    std::vector<int32_t>& t = w->h_tsched;
+    t.clear();
+    for (int k = 0; k < nv; ++k) t.push_back(order[(size_t)k]);
+    for (int k = 0; k < nv; ++k) { const int p = parent[(size_t)order[(size_t)k]]; t.push_back(p < 0 ? -1 : pos[(size_t)p]); }
+    auto lists = [&](const std::vector<std::vector<int>>& L) {
+        int acc = 0;
+        for (int k = 0; k < nv; ++k) { t.push_back(acc); acc += (int)L[(size_t)k].size(); }
+        t.push_back(acc);
+        for (int k = 0; k < nv; ++k) for (int e : L[(size_t)k]) t.push_back(e);
+    };
+    lists(re); lists(pe); lists(se);
+    for (int i = 0; i < 2 * nr; ++i) t.push_back(r_idx[i]);
+    for (int i = 0; i < 4 * ns; ++i) t.push_back(s_idx[i]);
+    // by pose slot (tree_wave_kernel): parent, height, children, edges
+    std::vector<int> height((size_t)nv, 0);
+    int hmax = 0;
+    for (int k = 0; k < nv; ++k) {   // (post-order: children before their parent)
+        const int v = order[(size_t)k], p = parent[(size_t)v];
+        if (p >= 0 && height[(size_t)p] < height[(size_t)v] + 1) height[(size_t)p] = height[(size_t)v] + 1;
+        if (height[(size_t)v] > hmax) hmax = height[(size_t)v];
+    }
+    for (int v = 0; v < nv; ++v) t.push_back(parent[(size_t)v]);
+    for (int v = 0; v < nv; ++v) t.push_back(height[(size_t)v]);
+    auto by_slot = [&](const std::vector<std::vector<int>>& L, bool positions) {   // L indexed by slot, or by schedule position
+        int acc = 0;
+        for (int v = 0; v < nv; ++v) { t.push_back(acc); acc += (int)L[(size_t)(positions ? pos[(size_t)v] : v)].size(); }
+        t.push_back(acc);
+        for (int v = 0; v < nv; ++v) for (int e : L[(size_t)(positions ? pos[(size_t)v] : v)]) t.push_back(e);
+    };
+    by_slot(kids, false); by_slot(re, true); by_slot(pe, true); by_slot(se, true);
+    w->tsched.nlev = hmax + 1;
+    w->tsched.max_se3_per_node = 0;
+    for (int k = 0; k < nv; ++k) if ((int)se[(size_t)k].size() > w->tsched.max_se3_per_node) w->tsched.max_se3_per_node = (int)se[(size_t)k].size();
+    w->tsched.nv = nv; w->tsched.nr = nr; w->tsched.np = np; w->tsched.ns = ns; w->tsched.depth = maxdepth + 1; w->tsched.nroots = nroots;
+    return true;
+}
+static hipError_t upload_tree_sched(loc_window* w, hipStream_t st) {
+    hipError_t e;
+    if (w->tsched_cap < w->h_tsched.size()) {
+        if (w->d_tsched) (void)hipFree(w->d_tsched);
+        w->d_tsched = nullptr; w->tsched_cap = 0;
+        if ((e = hipMalloc((void**)&w->d_tsched, w->h_tsched.size() * sizeof(int32_t))) != hipSuccess) return e;
+        w->tsched_cap = w->h_tsched.size();
+    }
+    if (!w->d_tree_ws && (e = hipMalloc((void**)&w->d_tree_ws, locamd::window_tree_workspace_doubles(w->caps, w->B) * sizeof(double))) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(w->d_tsched, w->h_tsched.data(), w->h_tsched.size() * sizeof(int32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    locamd::TreeSched& ts = w->tsched;
+    const int nv = ts.nv, nr = ts.nr, np = ts.np, ns = ts.ns;
+    const int32_t* p = w->d_tsched;
+    ts.node = p; p += nv; ts.par = p; p += nv;
+    ts.r_off = p; p += nv + 1; ts.r_list = p; p += nr;
+    ts.p_off = p; p += nv + 1; ts.p_list = p; p += np;
+    ts.s_off = p; p += nv + 1; ts.s_list = p; p += ns;
+    ts.r_idx = p; p += 2 * nr; ts.s_idx = p; p += 4 * ns;
+    ts.w_par = p; p += nv; ts.w_height = p; p += nv;
+    ts.w_koff = p; p += nv + 1; ts.w_klist = p; p += nv - ts.nroots;
+    ts.w_roff = p; p += nv + 1; ts.w_rlist = p; p += nr;
+    ts.w_poff = p; p += nv + 1; ts.w_plist = p; p += np;
+    ts.w_soff = p; p += nv + 1; ts.w_slist = p;
+    return hipSuccess;
+}
+
+static long long tree_min_batch(const loc_window* w) {
+    const long long mn = w->chain_min >= 0 ? w->chain_min : chain_min_batch();
+    if (mn <= 0) return 1ll << 62;     // (threshold 0 = "never a batch kernel")
+    return mn < 256 ? mn : 256;
+}
+
+// what the batch qualifies for BY ITS STRUCTURE: LOC_WINDOW_KERNEL_GENERAL, _CHAIN (block-tridiagonal, 6-DoF), _CHAIN3, _ARROW3 or _TREE
 // (for _ARROW3 the edge lists are left in w->h_a*)
 static int batch_topology(loc_window* w, int64_t n, const int32_t* counts, const double* poses, const int32_t* r_idx, const double* r_val,
                           const int32_t* p_idx, const double* p_val, const int32_t* s_idx) {
@@ -418,6 +569,12 @@ static int batch_topology(loc_window* w, int64_t n, const int32_t* counts, const
         const bool want = v ? v[0] == '1' : c.nv_max > 64;
         if (want && translation_only(w, n, counts, poses, r_val, p_val) && build_arrow_aux(w, n, counts, r_idx, r_val, p_idx, p_val)) return LOC_WINDOW_KERNEL_ARROW3;
     }
+    {
+        // (LOCAMD_TREE=0: never.  One wave per window, so any batch gains; the host-side comparison of the index tables is only worth
+        //  it from a few hundred windows on — or from the chain threshold when that was lowered, as the tests do)
+        const char* v = getenv("LOCAMD_TREE");
+        if (!(v && v[0] == '0') && n >= tree_min_batch(w) && build_tree_sched(w, n, counts, r_idx, p_idx, s_idx)) return LOC_WINDOW_KERNEL_TREE;
+    }
     return LOC_WINDOW_KERNEL_GENERAL;
 }
 // the kernel a batch of n windows with that structure takes NOW (threshold, ordering override, LOCAMD_CHAIN3=0 for A/B runs)
@@ -425,6 +582,7 @@ static int pick_kernel(const loc_window* w, int64_t n, int topology) {
     const long long mn = w->chain_min >= 0 ? w->chain_min : chain_min_batch();
     if (w->has_off1) return LOC_WINDOW_KERNEL_GENERAL;   // (lever arms on endpoint 1: only the general kernel evaluates them)
     if (topology == LOC_WINDOW_KERNEL_ARROW3) return w->natural_order ? LOC_WINDOW_KERNEL_GENERAL : LOC_WINDOW_KERNEL_ARROW3;   // (one wave per window: any batch size)
+    if (topology == LOC_WINDOW_KERNEL_TREE) return (w->natural_order || n < tree_min_batch(w)) ? LOC_WINDOW_KERNEL_GENERAL : LOC_WINDOW_KERNEL_TREE;
     if (topology == LOC_WINDOW_KERNEL_GENERAL || mn <= 0 || n < mn || w->natural_order) return LOC_WINDOW_KERNEL_GENERAL;
     if (topology == LOC_WINDOW_KERNEL_CHAIN3) {   // LOCAMD_CHAIN3=0: the 6-DoF kernel on a translation-only batch (A/B runs, tests; read per call)
         const char* v = getenv("LOCAMD_CHAIN3");
@@ -439,6 +597,11 @@ static hipError_t launch_any(loc_window* w, const locamd::WindowArgs& a, hipStre
         x.hdr = w->d_ahdr; x.rslot = w->d_arslot; x.rec = w->d_arec; x.prec = w->d_aprec;
         x.ws = w->d_arrow_ws; x.nb_max = w->arrow_nb_max; x.jmax = w->arrow_jmax; x.jpmax = w->arrow_jpmax; x.nchunk = (w->caps.nv_max + 63) / 64;
         return locamd::launch_window_arrow3(a, x, st);
+    }
+    if (kind == LOC_WINDOW_KERNEL_TREE) {   // (LOCAMD_TREE=lane: the one-lane-per-window variant, for A/B runs)
+        const char* v = getenv("LOCAMD_TREE");
+        if ((v && v[0] == 'l') || w->tsched.max_se3_per_node > 1) return locamd::launch_window_tree(a, w->tsched, w->d_tree_ws, st);   // (tree_wave_kernel: one EdgeSE3 per node)
+        return locamd::launch_window_tree_wave(a, w->tsched, st);
     }
     if (kind == LOC_WINDOW_KERNEL_CHAIN3) {
         if (!w->d_chain3_ws) {
@@ -535,6 +698,7 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
             LOC_HIP(hipEventRecord(w->ev0, st));
             const int kind = pick_kernel(w, n, batch_topology(w, n, counts, poses, r_idx, r_val, p_idx, p_val, s_idx));
             if (kind == LOC_WINDOW_KERNEL_ARROW3) LOC_HIP(upload_arrow_aux(w, n, st));
+            if (kind == LOC_WINDOW_KERNEL_TREE) LOC_HIP(upload_tree_sched(w, st));
             hipError_t e = launch_any(w, a, st, kind);
             if (e != hipSuccess) return locamd_fail_hip(e, "launch_window");
             LOC_HIP(hipEventRecord(w->ev1, st));
@@ -570,6 +734,7 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
     a.n_anchors = w->n_anchors; a.B = (int)n; a.iterations = w->iterations; a.caps = c;
     const int kind = pick_kernel(w, n, batch_topology(w, n, counts, poses, r_idx, r_val, p_idx, p_val, s_idx));
     if (kind == LOC_WINDOW_KERNEL_ARROW3) LOC_HIP(upload_arrow_aux(w, n, st));
+    if (kind == LOC_WINDOW_KERNEL_TREE) LOC_HIP(upload_tree_sched(w, st));
     LOC_HIP(hipEventRecord(w->ev0, st));
     hipError_t e = launch_any(w, a, st, kind);
     if (e != hipSuccess) return locamd_fail_hip(e, "launch_window");
@@ -617,6 +782,7 @@ int loc_window_upload(loc_window* w, int64_t n, const int32_t* counts, const dou
     w->resident_solved = false;
     w->resident_topology = batch_topology(w, n, counts, poses, r_idx, r_val, p_idx, p_val, s_idx);
     if (w->resident_topology == LOC_WINDOW_KERNEL_ARROW3) LOC_HIP(upload_arrow_aux(w, n, w->stream));
+    if (w->resident_topology == LOC_WINDOW_KERNEL_TREE) LOC_HIP(upload_tree_sched(w, w->stream));
     int max_anchor = 0;   // anchors referenced: v1 = -1 - anchor
     for (int64_t i = 0; i < n; ++i)
         for (int e = 0; e < counts[i * 4 + 1]; ++e) {

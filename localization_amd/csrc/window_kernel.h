@@ -73,4 +73,24 @@ size_t window_arrow3_workspace_doubles(const WindowCaps& c, int nb_max);
 size_t window_arrow3_lds_bytes(const WindowCaps& c, int nb_max);
 hipError_t launch_window_arrow3(const WindowArgs& a, const ArrowAux& x, hipStream_t stream);
 
+// forest windows of ONE shared topology, one lane per window (window_kernel.hip: tree_lm_kernel): the elimination schedule the
+// host builds once per upload (capi_window.cpp: build_tree_sched); all pointers are device arrays shared by the whole batch
+struct TreeSched {
+    const int32_t* node;    // [nv]   pose slot of the k-th node in elimination order (children before their parent)
+    const int32_t* par;     // [nv]   position (in that order) of the node's parent, -1 for a root
+    const int32_t* r_off;   // [nv+1] the node's range edges (to anchors, or to its parent) = r_list[r_off[k] .. r_off[k+1])
+    const int32_t* r_list;  // [nr]   edge numbers in schedule order (the kernel copies the values into its workspace in this order)
+    const int32_t* p_off; const int32_t* p_list;   // priors of the node
+    const int32_t* s_off; const int32_t* s_list;   // EdgeSE3 factors between the node and its parent
+    const int32_t* r_idx;   // [nr][2], [ns][4]: the index tables of instance 0 (= of every instance)
+    const int32_t* s_idx;
+    // the same structure by POSE SLOT, for tree_wave_kernel (one wave per window, lane = pose): parent slot (-1: root), height above
+    // the leaves, children (w_klist[w_koff[v] .. w_koff[v+1])), and the edges of the pose (unary ones, and those to its parent)
+    const int32_t *w_par, *w_height, *w_koff, *w_klist, *w_roff, *w_rlist, *w_poff, *w_plist, *w_soff, *w_slist;
+    int nv, nr, np, ns, depth, nroots, nlev, max_se3_per_node;
+};
+size_t window_tree_workspace_doubles(const WindowCaps& c, long long B);
+hipError_t launch_window_tree(const WindowArgs& a, const TreeSched& ts, double* ws, hipStream_t stream);
+hipError_t launch_window_tree_wave(const WindowArgs& a, const TreeSched& ts, hipStream_t stream);
+
 }  // namespace locamd

@@ -1,0 +1,127 @@
+"""GPU parity of tree_lm_kernel (window_kernel.hip) — large batches of forest windows that all share ONE topology (BASELINE config 5:
+the key-frame star of addPoseEdge + one anchor range per pose), one lane per window on a host-built elimination schedule — against
+the oracle, against the wave-per-window kernel on the same batch, and the selection rules.
+
+Tolerances: analytic vs analytic 1e-7 m / rad on every pose, numeric vs numeric 1e-5."""
+import os
+
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation
+
+pytestmark = pytest.mark.gpu
+
+ANCH = np.array([[3, -3, 0.58], [3, 3, 1.97], [-3, 3, 0.54], [-3, -3, 1.76]], dtype=float)
+
+
+def _copy_batch(la, wb):
+    out = la.WindowBatch(wb.B, *wb.caps)
+    for name in ("counts", "poses", "r_idx", "r_val", "p_idx", "p_val", "s_idx", "s_val"):
+        getattr(out, name)[:] = getattr(wb, name)
+    return out
+
+
+def _forest_batch(la, rng, B, T, every, rich):
+    """Key-frame stars as addPoseEdge builds them (a new key every `every` poses; the pose before a new key IS that key), one anchor range
+    per pose.  rich: two trees (one link missing), a smoothness range next to the EdgeSE3 of some pairs, IMU-style priors on some poses,
+    lever arms, EdgeSE3 stored in either direction, a non-robust EdgeSE3."""
+    wb = la.WindowBatch(B, T, 2 * T + 2, T, T)
+    key = np.where(np.arange(T) < every, 0, (np.arange(T) // every) * every - 1)
+    for i in range(B):
+        tt = np.cumsum(rng.normal(0, 0.05, (T, 3)), axis=0) + np.array([rng.uniform(-1.5, 1.5), rng.uniform(-1.5, 1.5), 1.1])
+        tR = Rotation.from_rotvec(np.cumsum(rng.normal(0, 0.03, (T, 3)), axis=0) + rng.normal(0, 0.3, 3))
+        et = tt + rng.normal(0, 0.05, (T, 3))
+        eR = (tR * Rotation.from_rotvec(rng.normal(0, 0.02, (T, 3)))).as_matrix()
+        off = np.array([0.1, 0.0, -0.05]) if rich else np.zeros(3)
+        for k in range(T): wb.add_pose(i, et[k], eR[k])
+        for k in range(T):
+            a = k % 4
+            wb.add_range(i, k, a, float(np.float32(np.linalg.norm(tt[k] + tR[k].apply(off) - ANCH[a]) + rng.normal(0, 0.03))), 1 / 0.055 ** 2, off, anchor=True)
+            if k == 0 or (rich and k == T // 2):
+                continue                                                     # (rich: pose T/2 starts a second tree)
+            kk = int(key[k])
+            Zt = tR[kk].inv().apply(tt[k] - tt[kk]) + rng.normal(0, 0.01, 3)
+            ZR = (tR[kk].inv() * tR[k] * Rotation.from_rotvec(rng.normal(0, 0.01, 3))).as_matrix()
+            A = rng.normal(size=(6, 6)); info = A @ A.T + 6 * np.eye(6); info *= 6e4 / np.trace(info)
+            if rich and k % 3 == 0:                                           # stored child -> key: the inverse measurement
+                wb.add_se3(i, k, kk, -ZR.T @ Zt, ZR.T, info, True)
+            else:
+                wb.add_se3(i, kk, k, Zt, ZR, info, not (rich and k % 5 == 0))
+            if rich and kk == k - 1:
+                wb.add_range(i, k - 1, k, 0.0, 1 / (5.0 / 32 / 3) ** 2)       # the smoothness edge lands on the same pair as the EdgeSE3
+            if rich and k % 4 == 1:
+                wb.add_prior(i, k, et[k], (tR[k] * Rotation.from_rotvec(rng.normal(0, 2e-3, 3))).as_matrix(), np.array([0, 0, 0, 1, 1, 1.0]) / 4.592449e-06)
+    return wb
+
+
+@pytest.mark.parametrize("T,every,rich,jac", [
+    (64, 8, False, "analytic"),    # BASELINE config 5's shape
+    (64, 8, False, "numeric"),
+    (24, 4, True, "analytic"),     # two trees, doubled pairs, priors, lever arms
+    (24, 4, True, "numeric"),
+    (10, 1, True, "analytic"),     # every pose a key: a chain of EdgeSE3 + smoothness edges with a gap
+])
+def test_tree_kernel_matches_oracle_and_general_kernel(gpu, T, every, rich, jac):
+    import localization_amd as la
+    from oracle import oracle as O
+    from _oracle_window import oracle_solve_instance
+    B = 70 if T < 64 else 66
+    rng = np.random.default_rng(7000 + T + every + len(jac))
+    wb = _forest_batch(la, rng, B, T, every, rich)
+    before = wb.poses.copy()
+    ref = _copy_batch(la, wb)
+    mode = O.JAC_ANALYTIC if jac == "analytic" else O.JAC_NUMERIC_G2O
+    n_or = B if T < 64 else 12
+    want = [oracle_solve_instance(wb, i, ANCH, jac_mode=mode) for i in range(n_or)]
+    g = la.WindowSolver(ANCH, B, *wb.caps, jacobian=jac, bw_max=T - 1, chain_threshold=0)
+    res_g = g.solve(ref).copy()
+    assert g.last_kernel_kind() == "window_lm_kernel"
+    g.close()
+    s = la.WindowSolver(ANCH, B, *wb.caps, jacobian=jac, bw_max=T - 1, chain_threshold=1)
+    res = s.solve(wb).copy()
+    kind = s.last_kernel_kind()
+    assert kind in ("tree_lm_kernel", "chain_lm_kernel") and (kind == "tree_lm_kernel" or every == 1)
+    tol = 1e-7 if jac == "analytic" else 1e-5
+    n_same_it = 0
+    for i in range(n_or):
+        poses, chi, st = want[i]
+        d = np.abs(wb.poses[i] - poses).max()
+        assert d < tol, (i, d)
+        assert abs(res[i, 0] - chi) <= (1e-6 if jac == "analytic" else 1e-4) * max(1.0, abs(chi)), (i, res[i, 0], chi)
+        n_same_it += res[i, 3] == st.outer_iterations
+    assert n_same_it >= 0.9 * n_or     # (g2o's Terminate — ten rejected trials or a gain ratio of exactly 0 — is a rounding-edge event at convergence)
+    assert np.abs(wb.poses - ref.poses).max() < tol
+    assert np.array_equal(res[:, 6], res_g[:, 6])          # pose-to-pose edges that share their pair with another edge
+    assert (res[:, 4] != res_g[:, 4]).mean() < (0.05 if T > 10 else 0.3)   # (ten-pose windows converge: their last accept / reject decisions are rounding-level ties)
+    # resident API: the same bits
+    wb2 = _copy_batch(la, wb); wb2.poses[:] = before
+    s.upload(wb2); s.solve_resident(); s.download(wb2)
+    assert s.last_kernel_kind() == kind and np.array_equal(wb2.poses, wb.poses) and np.array_equal(wb2.result, res)
+    s.close()
+
+
+def test_tree_kernel_needs_one_shared_forest_topology(gpu):
+    import localization_amd as la
+    rng = np.random.default_rng(3)
+    B, T = 64, 12
+    base = _forest_batch(la, rng, B, T, 4, False)
+    s = la.WindowSolver(ANCH, B, *base.caps, jacobian="analytic", bw_max=T - 1, chain_threshold=1)
+
+    def kind(mut):
+        wb = _copy_batch(la, base)
+        mut(wb)
+        s.solve(wb)
+        return s.last_kernel_kind()
+
+    assert kind(lambda wb: None) == "tree_lm_kernel"
+    def other_anchor(wb): wb.r_idx[17, 3, 1] = -1 - 2                        # one window ranges another anchor: not ONE topology
+    def shorter(wb): wb.counts[5] = (T - 1, T - 1, 0, T - 2)                  # one window is shorter
+    def cycle(wb):                                                            # every window gets a loop closure: not a forest
+        for i in range(B): wb.add_range(i, 2, 9, 1.0, 10.0)
+    for mut in (other_anchor, shorter, cycle):
+        assert kind(mut) == "window_lm_kernel", mut.__name__
+    s.close()
+    small = la.WindowSolver(ANCH, B, *base.caps, jacobian="analytic", bw_max=T - 1)   # default threshold: 64 windows are a small batch
+    small.solve(_copy_batch(la, base))
+    assert small.last_kernel_kind() == "window_lm_kernel"
+    small.close()
