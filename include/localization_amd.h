@@ -322,6 +322,9 @@ int loc_node_add_rl_range(loc_node* n, int32_t requester_id, int32_t responder_i
 int loc_node_solve(loc_node* n, loc_node_output* out);
 int loc_node_get_path(loc_node* n, int32_t node_id, double* out_T_by_8, int32_t capacity_poses);
 int32_t loc_node_number_measurements(const loc_node* n);
+/* Where the last solve's time went, milliseconds: [0] packing the window on the host, [1] the window solve call (copy in, launch, copy
+ * out, synchronise), [2] of which the kernel (HIP events) — the reference prints the same figure per solve (CPPTimer, localization.cpp:166,191) */
+int loc_node_last_timing(const loc_node* n, double* pack_solve_kernel_ms);
 /* Fleet mode: with deferred on, add_* only mark the node "solve pending"; loc_nodes_solve_batch then solves every
  * pending node of the array in ONE launch per parameter group (returns how many were solved). */
 int loc_node_set_deferred(loc_node* n, int32_t on);

@@ -44,7 +44,7 @@ EXPORTED_SYMBOLS = [
     "loc_window_timing_begin", "loc_window_timing_end",
     "loc_node_default_config", "loc_node_create", "loc_node_destroy", "loc_node_add_range", "loc_node_add_imu",
     "loc_node_add_pose", "loc_node_add_twist", "loc_node_add_lidar", "loc_node_add_rl_range", "loc_node_solve", "loc_node_get_path",
-    "loc_node_number_measurements", "loc_node_set_deferred", "loc_node_solve_pending", "loc_nodes_solve_batch",
+    "loc_node_number_measurements", "loc_node_last_timing", "loc_node_set_deferred", "loc_node_solve_pending", "loc_nodes_solve_batch",
     "loc_nodes_release_batch_cache",
     "loc_fusion_default_params", "loc_fusion_create", "loc_fusion_destroy", "loc_fusion_set_poses", "loc_fusion_get_poses",
     "loc_fusion_solve_device", "loc_fusion_solve_host", "loc_fusion_solve_host_kmb", "loc_fusion_last_kernel_ms",

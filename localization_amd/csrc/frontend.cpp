@@ -7,6 +7,7 @@
 #include "../../include/localization_amd.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -123,6 +124,7 @@ struct loc_node {
     loc_window_caps caps{16, 0, 0, 0, -1};     // LIMIT of what pack() accepts: nv_max = the most active poses (set in loc_node_create);
                                                // the edge counts have no limit (the reference has none): the handle grows on demand
     loc_window_caps win_caps{0, 0, 0, 0, 0};   // capacities of the cached handle: what the packed graphs needed so far
+    double t_pack_ms = 0, t_solve_ms = 0, t_kernel_ms = 0;   // the last solve: host packing, loc_window_solve_host (copies + launch + sync), its kernel
 
     RobotRing* robot(int id) { for (auto& r : robots) if (r.id == id) return &r; return nullptr; }
     void remove_vertex(int vid) {  // optimizer.removeVertex(v, false): the vertex and every edge touching it
@@ -330,6 +332,7 @@ void fill_output(loc_node* n, const double* res, loc_node_output* out) {
 // Localization::solve() + publish(): one window-kernel launch on this node's graph
 int solve_now(loc_node* n, loc_node_output* out) {
     Packed P;
+    const auto t0 = std::chrono::steady_clock::now();
     int rc = pack(n, P);
     if (rc != LOC_OK) return rc;
     double res[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -352,9 +355,14 @@ int solve_now(loc_node* n, loc_node_output* out) {
             if (rc != LOC_OK) return rc;
             n->win_anchors = P.anchors;
         }
+        const auto t1 = std::chrono::steady_clock::now();
         rc = loc_window_solve_host(n->win, 1, P.counts.data(), P.poses.data(), P.r_idx.data(), P.r_val.data(), P.p_idx.data(),
                                    P.p_val.data(), P.s_idx.data(), P.s_val.data(), res);
         if (rc != LOC_OK) return rc;
+        const auto t2 = std::chrono::steady_clock::now();
+        n->t_pack_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        n->t_solve_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
+        (void)loc_window_last_kernel_ms(n->win, &n->t_kernel_ms);
         for (size_t s = 0; s < P.slot_vid.size(); ++s) {
             Vertex& v = n->vertices.at(P.slot_vid[s]);
             std::memcpy(v.est.R, &P.poses[s * 12], sizeof(double) * 9);
@@ -449,6 +457,12 @@ int loc_node_set_deferred(loc_node* n, int32_t on) {
     return LOC_OK;
 }
 int32_t loc_node_solve_pending(const loc_node* n) { return n && n->pending ? 1 : 0; }
+int loc_node_last_timing(const loc_node* n, double* pack_solve_kernel_ms) {
+    if (!n || !pack_solve_kernel_ms) return locamd_fail(LOC_ERR_INVALID, "null");
+    pack_solve_kernel_ms[0] = n->t_pack_ms; pack_solve_kernel_ms[1] = n->t_solve_ms; pack_solve_kernel_ms[2] = n->t_kernel_ms;
+    return LOC_OK;
+}
+
 int32_t loc_node_number_measurements(const loc_node* n) { return n ? n->number_measurements : 0; }
 
 // Localization::addRangeEdge, localization.cpp:297-376

@@ -38,6 +38,7 @@ def _bind(L):
     L.loc_node_solve.argtypes = [vp, po]
     L.loc_node_get_path.argtypes = [vp, C.c_int32, dp, C.c_int32]
     L.loc_node_number_measurements.argtypes = [vp]; L.loc_node_number_measurements.restype = C.c_int32
+    L.loc_node_last_timing.argtypes = [vp, C.POINTER(C.c_double)]
     L.loc_node_set_deferred.argtypes = [vp, C.c_int32]
     L.loc_node_solve_pending.argtypes = [vp]; L.loc_node_solve_pending.restype = C.c_int32
     L.loc_nodes_solve_batch.argtypes = [C.POINTER(vp), C.c_int32, po]
@@ -150,6 +151,12 @@ class LocalizationNode:
     @property
     def solve_pending(self):
         return bool(self.L.loc_node_solve_pending(self.h))
+
+    def last_timing(self):
+        """(pack, solve call, kernel) milliseconds of the last solve (loc_node_last_timing)"""
+        t = (C.c_double * 3)()
+        check(self.L.loc_node_last_timing(self.h, t))
+        return float(t[0]), float(t[1]), float(t[2])
 
     @property
     def number_measurements(self):

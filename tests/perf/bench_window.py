@@ -182,6 +182,8 @@ def main():
     ap.add_argument("--no-latency", action="store_true", help="skip the single-window latency launches (profiling: one kernel shape only)")
     ap.add_argument("--pmc-json", default=None, help="a tests/perf/pmc_summary.py output for THIS shape and batch: its f64 instruction counts "
                     "(wave-instructions per launch, x 64 lanes; fma = 2 flop) give the f64 rate next to the HBM roofline")
+    ap.add_argument("--tile", type=int, default=0, help="build this many distinct windows and repeat them cyclically up to --batch (selfcal: building 1 024 "
+                    "hypotheses of 2 815 edges in Python takes a minute)")
     ap.add_argument("--cache", default=None, help="npz file: load the generated batch from it if it exists, else build and save "
                     "(profiling runs repeat the same command once per counter pass)")
     a = ap.parse_args()
@@ -196,7 +198,13 @@ def main():
         graphs, anchors, T = [], z["anchors"], int(z["T"])
         a.cpu_n = 0
     else:
-        wb, graphs, anchors, T = build(a.batch, a.shape)
+        if a.tile and a.tile < a.batch:
+            small, graphs, anchors, T = build(a.tile, a.shape)
+            wb = la.WindowBatch(a.batch, *small.caps)
+            for nm in names:
+                src = getattr(small, nm); getattr(wb, nm)[:] = np.resize(src, (a.batch,) + src.shape[1:])
+        else:
+            wb, graphs, anchors, T = build(a.batch, a.shape)
         if a.cache:
             np.savez(a.cache, caps=np.array(wb.caps), anchors=anchors, T=T, **{nm: getattr(wb, nm) for nm in names})
     if a.bw == "auto":
@@ -235,7 +243,7 @@ def main():
     algo_bytes = 2.0 * T * 56 + 240
     ach = algo_bytes * a.batch / (k_ms * 1e-3) / 1e9
     roof = {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
-            "algorithmic_bytes_per_window": algo_bytes, "kernel": "window_lm_kernel", "kernel_ms_avg": k_ms}   # ("kernel" is corrected below for chain batches)
+            "algorithmic_bytes_per_window": algo_bytes, "kernel": solver.last_kernel_kind(), "kernel_ms_avg": k_ms}
     if a.pmc_json and os.path.exists(a.pmc_json):
         pj = json.load(open(a.pmc_json))
         lane_flop = 64.0 * (pj.get("SQ_INSTS_VALU_ADD_F64", 0) + pj.get("SQ_INSTS_VALU_MUL_F64", 0) + 2 * pj.get("SQ_INSTS_VALU_FMA_F64", 0)
@@ -244,12 +252,10 @@ def main():
         roof["valu_f64"] = {"issued_tflops": tf, "peak_tflops": 78.6, "frac": tf / 78.6,
                             "note": "f64 VALU wave-instructions x 64 lanes (PMC; counts idle lanes too: an upper bound on useful flops)"}
         if pj.get("FETCH_SIZE") is not None and pj.get("WRITE_SIZE") is not None:
-            roof["traffic"] = (2.0 * pj["FETCH_SIZE"] + pj["WRITE_SIZE"]) * 1024.0   # KB -> B, FETCH_SIZE x2 (gfx950, MI355X_MICROARCH.md)
-            roof["traffic_note"] = "HBM-side bytes per launch from PMC (FETCH_SIZE x 2 + WRITE_SIZE); uncalibrated for this access pattern"
-    if T > 1 and a.shape in ("uwb_only", "uwb_imu") and int(wb.result[0, 7]) == T * 65536 + 2 * T - 1:
-        # (the signature of the one-lane-per-window kernel that large batches of chain windows take: pose order, T levels)
-        roof["kernel"] = "chain_lm_kernel"
-        roof["note"] = "bound by its [entry][lane] workspace traffic (~0.5 MB per window), not by the algorithmic bytes"
+            roof["traffic"] = (2.0 * pj["FETCH_SIZE"] + pj["WRITE_SIZE"]) * 1024.0   # KB -> B
+            roof["traffic_rate_gbs"] = roof["traffic"] / (k_ms * 1e-3) / 1e9
+            roof["traffic_note"] = ("HBM-side bytes per launch from PMC: FETCH_SIZE x 2 + WRITE_SIZE, the factor 2 measured for coalesced 8-B and 16-B per "
+                                    "lane streams and for scattered 8-B reads alike (profiles/r03_fetch_calibration.json: FETCH_SIZE x 2 = 128-B lines fetched)")
     print(json.dumps({
         "roofline": roof,
         "shape": a.shape, "poses_per_window": T, "unknowns": 6 * T, "batch": a.batch, "bw_max": bw, "lds_bytes_per_instance": solver.lds_bytes,

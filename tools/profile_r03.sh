@@ -1,0 +1,41 @@
+#!/bin/bash
+# Round-3 rocprofv3 evidence on the GPU box:  tools/profile_r03.sh OUTDIR   (run from the repo root; summaries land in OUTDIR, copy them to profiles/)
+#   headline snapshot kernel (analytic = `value`, numeric = the reference's configuration), fusion kernel (both modes),
+#   chain3_lm_kernel (cfg1 windows, 65 536), arrow3_lm_kernel (cfg4: 128 and 1 024 hypotheses), tree_wave_kernel (cfg5, 16 384):
+#   each --kernel-trace --stats once, then separate --pmc passes (never combined with a trace domain).
+set -eo pipefail
+OUT=$1
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+P1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY"
+P2="SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE"
+P5="SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM TCC_HIT_sum TCC_MISS_sum"
+profile() {   # profile TAG KERNEL_SUBSTRING -- command ...
+  local TAG=$1 KER=$2; shift 3
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_$TAG" -o t -- "$@" > "$OUT/${TAG}_under_rocprof.json" 2>/dev/null
+  head -6 "$(find "$OUT/trace_$TAG" -name '*kernel_stats.csv' | head -1)" > "$OUT/${TAG}_kernel_stats_head.csv"
+  local i=0
+  for P in "$P1" "$P2" "FETCH_SIZE" "WRITE_SIZE" "$P5"; do
+    i=$((i+1))
+    rocprofv3 --pmc $P --output-format csv -d "$OUT/pmc${i}_$TAG" -o p -- "$@" > /dev/null 2>&1 || echo "[profile_r03] $TAG pmc pass $i failed"
+  done
+  python3 tests/perf/pmc_summary.py "$KER" "$OUT"/pmc*_"$TAG" > "$OUT/${TAG}_pmc.json"
+  rm -rf "$OUT/trace_$TAG" "$OUT"/pmc*_"$TAG"
+  echo "[profile_r03] $TAG done: $(head -2 "$OUT/${TAG}_kernel_stats_head.csv" | tail -1 | cut -c1-160)"
+}
+SHORT="--steps 3 --warmup 1 --no-cpu-baseline --legs none --datagen numpy"
+profile cfg2_analytic snapshot_lm_kernel -- python3 bench.py $SHORT
+profile cfg2_numeric snapshot_lm_kernel -- python3 bench.py $SHORT --jacobian numeric
+FUS="tests/perf/bench_fusion.py --steps 2 --cpu-tags 64 --cpu-epochs 4"
+profile cfg3_analytic fusion_lm_kernel -- python3 $FUS
+profile cfg3_numeric fusion_lm_kernel -- python3 $FUS --jacobian numeric
+W="tests/perf/bench_window.py --reps 3 --no-latency --cpu-n 0"
+python3 $W --shape uwb_only --batch 65536 --tile 4096 --cache /tmp/wb_t10.npz --bw 1 > /dev/null
+profile cfg1_windows chain3_lm_kernel -- python3 $W --shape uwb_only --batch 65536 --cache /tmp/wb_t10.npz --bw 1
+python3 $W --shape selfcal --batch 128 --tile 32 --cache /tmp/wb_sc128.npz > /dev/null
+profile cfg4_128 arrow3_lm_kernel -- python3 $W --shape selfcal --batch 128 --cache /tmp/wb_sc128.npz
+python3 $W --shape selfcal --batch 1024 --tile 32 --cache /tmp/wb_sc1024.npz > /dev/null
+profile cfg4_1024 arrow3_lm_kernel -- python3 $W --shape selfcal --batch 1024 --cache /tmp/wb_sc1024.npz
+python3 $W --shape pose64 --batch 16384 --cache /tmp/wb_p64.npz --bw 8 > /dev/null
+profile cfg5 tree_wave_kernel -- python3 $W --shape pose64 --batch 16384 --cache /tmp/wb_p64.npz --bw 8
+ls -la "$OUT"

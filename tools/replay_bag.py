@@ -61,7 +61,7 @@ def main():
         cfg.nodes_pos = [v for i in sorted(anchors) for v in anchors[i]] + [0.0, 0.0, 1.0]
     node = la.LocalizationNode.from_config(cfg, device=a.device, jacobian=a.jacobian)
     import time
-    realtime, optimized, n_solved, lat = [], [], 0, []
+    realtime, optimized, n_solved, lat, parts = [], [], 0, [], []
     it = bag.replay(a.bag, node, range_topic, imu_topic)
     while True:   # the generator runs the node between yields: time from one solve's output to the next = feed + solve
         t0 = time.perf_counter()
@@ -69,6 +69,7 @@ def main():
         if o is None:
             break
         lat.append(time.perf_counter() - t0)
+        parts.append(node.last_timing())
         n_solved += 1
         if o["published"]:
             realtime.append(o["realtime"]); optimized.append(o["optimized"])
@@ -94,6 +95,10 @@ def main():
         l = np.array(lat[1:]) * 1e3
         rep["ms_per_solve_incl_feed"] = {"median": float(np.median(l)), "p99": float(np.percentile(l, 99)), "max": float(l.max()),
                                          "budget_ms_between_ranges": 31.0}
+        pt = np.array(parts[1:])
+        rep["ms_per_solve_parts_median"] = {"pack_host": float(np.median(pt[:, 0])), "window_solve_call": float(np.median(pt[:, 1])),
+                                            "of_which_kernel": float(np.median(pt[:, 2])),
+                                            "note": "inside the library (loc_node_last_timing); the rest of ms_per_solve_incl_feed is this Python harness (bag decoding, ctypes)"}
     if truth and realtime:
         t8 = np.array([[e["stamp"], *e["pose"]] for e in truth])
         for name, rows in (("realtime", realtime), ("optimized", optimized)):
