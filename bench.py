@@ -122,11 +122,17 @@ def cpu_baseline_all_cores(anchors, dist_tiles, err_tiles, init, tags_per_core, 
                       f"over {used} single-threaded worker processes, same oracle and settings as cpu_baseline"}
 
 
-def spawn_ranks(n, argv):
+def spawn_ranks(n, argv, backend):
     """One child process per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (what torch.distributed.run would set);
-    rank 0's stdout is this process's stdout.  Returns non-zero unless every rank exits 0."""
+    rank 0's stdout is this process's stdout.  Returns non-zero unless every rank exits 0; a rank that fails takes the others down
+    (they would wait for it in the rendezvous forever)."""
     import socket
     import subprocess
+    if backend == "nccl":
+        import torch   # (counting devices does not initialise the GPU in this process)
+        if torch.cuda.device_count() < n:
+            print(f"[bench] --gpus {n} but only {torch.cuda.device_count()} device(s) are visible: refusing to run a smaller job", file=sys.stderr)
+            return 2
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     procs = []
     for r in range(n):
@@ -134,7 +140,18 @@ def spawn_ranks(n, argv):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    rcs = [p.wait() for p in procs]
+    rcs = [None] * n
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+        if any(rc not in (None, 0) for rc in rcs):
+            for i, p in enumerate(procs):   # (exactly the processes started above)
+                if rcs[i] is None:
+                    p.kill()
+                    rcs[i] = p.wait()
+            break
+        time.sleep(0.2)
     if any(rcs):
         print(f"[bench] ranks exited with {rcs}: the {n}-GPU run FAILED", file=sys.stderr)
         return 1
@@ -487,7 +504,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # Launched bare (`python bench.py --gpus N`): start the N ranks ourselves.  This happens BEFORE anything touches the
         # GPU in this process (no torch import yet); the children are ordinary subprocesses, never an exec of this one.
-        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:], args.dist_backend))
 
     import numpy as np
     import torch

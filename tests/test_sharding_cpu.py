@@ -128,3 +128,15 @@ def test_two_rank_window_shard_equals_single_process(tmp_path, B):
         assert np.array_equal(got["poses"][i], p) and got["chi2"][i] == c
     part, lo, hi = shard_window_batch(wb, 1, 2)
     assert (lo, hi) == (-(-B // 2), B) and np.array_equal(part.s_val[: hi - lo], wb.s_val[lo:hi])
+
+
+def test_bench_refuses_to_run_a_smaller_job_than_asked():
+    """`python bench.py --gpus N` without a launcher starts the N ranks itself — and exits non-zero, before touching any GPU, when fewer
+    than N devices are visible (here: none), instead of silently benchmarking what is there."""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--legs", "none"],
+                         capture_output=True, text=True, timeout=120, env=env)
+    assert run.returncode != 0 and "refusing to run a smaller job" in run.stderr and run.stdout.strip() == ""
