@@ -418,11 +418,35 @@ static bool build_tree_sched(loc_window* w, int64_t n, const int32_t* counts, co
     };
     for (int e = 0; e < nr; ++e) if (r_idx[2 * e + 1] >= 0 && !join(r_idx[2 * e], r_idx[2 * e + 1])) return false;
     for (int e = 0; e < ns; ++e) if (!join(s_idx[4 * e], s_idx[4 * e + 1])) return false;
-    // roots = the lowest slot of every component; parents towards the root; subtree sizes; post-order, heavy child first
+    // root of every component = its CENTRE (the middle of a longest path: two breadth-first searches), so that the elimination by
+    // height takes half as many steps as from an end (config 5's chain of eight keys: 6 levels instead of 9); parents towards the
+    // root; subtree sizes; post-order, heavy child first
     std::vector<int> parent((size_t)nv, -2), size((size_t)nv, 1), order, stack, depth((size_t)nv, 0);
     int nroots = 0, maxdepth = 0;
     std::vector<int> bfs;
-    for (int root = 0; root < nv; ++root) {
+    std::vector<int> seen((size_t)nv, 0), dist((size_t)nv, 0), from((size_t)nv, -1), centre_of;
+    auto far_from = [&](int start) {   // the farthest node from `start` inside its component (dist / from filled)
+        std::vector<int> q2{start};
+        std::vector<int> mark((size_t)nv, 0);
+        mark[(size_t)start] = 1; dist[(size_t)start] = 0; from[(size_t)start] = -1;
+        int last = start;
+        for (size_t h = 0; h < q2.size(); ++h) {
+            const int v = q2[h];
+            last = v;
+            for (int x : adj[(size_t)v]) if (!mark[(size_t)x]) { mark[(size_t)x] = 1; dist[(size_t)x] = dist[(size_t)v] + 1; from[(size_t)x] = v; q2.push_back(x); }
+        }
+        for (int v : q2) seen[(size_t)v] = 1;
+        return last;
+    };
+    for (int v0 = 0; v0 < nv; ++v0) {
+        if (seen[(size_t)v0]) continue;
+        const int a1 = far_from(v0);
+        const int b1 = far_from(a1);        // a1 .. b1: a longest path of this tree
+        int c1 = b1;
+        for (int step = dist[(size_t)b1] / 2; step > 0; --step) c1 = from[(size_t)c1];
+        centre_of.push_back(c1);
+    }
+    for (int root : centre_of) {
         if (parent[(size_t)root] != -2) continue;
         parent[(size_t)root] = -1; ++nroots;
         const size_t b0 = bfs.size();
@@ -491,7 +515,15 @@ static bool build_tree_sched(loc_window* w, int64_t n, const int32_t* counts, co
         t.push_back(acc);
         for (int v = 0; v < nv; ++v) for (int e : L[(size_t)(positions ? pos[(size_t)v] : v)]) t.push_back(e);
     };
-    by_slot(kids, false); by_slot(re, true); by_slot(pe, true); by_slot(se, true);
+    // (tree_wave_kernel wants a node's LEAF children first: their sums are taken in one parallel pass right after the leaves' level)
+    std::vector<std::vector<int>> kids_lf((size_t)nv);
+    std::vector<int> nleafkids((size_t)nv, 0);
+    for (int v = 0; v < nv; ++v) {
+        for (int ch : kids[(size_t)v]) if (height[(size_t)ch] == 0) { kids_lf[(size_t)v].push_back(ch); ++nleafkids[(size_t)v]; }
+        for (int ch : kids[(size_t)v]) if (height[(size_t)ch] != 0) kids_lf[(size_t)v].push_back(ch);
+    }
+    by_slot(kids_lf, false); by_slot(re, true); by_slot(pe, true); by_slot(se, true);
+    for (int v = 0; v < nv; ++v) t.push_back(nleafkids[(size_t)v]);
     w->tsched.nlev = hmax + 1;
     w->tsched.max_se3_per_node = 0;
     for (int k = 0; k < nv; ++k) if ((int)se[(size_t)k].size() > w->tsched.max_se3_per_node) w->tsched.max_se3_per_node = (int)se[(size_t)k].size();
@@ -521,7 +553,8 @@ static hipError_t upload_tree_sched(loc_window* w, hipStream_t st) {
     ts.w_koff = p; p += nv + 1; ts.w_klist = p; p += nv - ts.nroots;
     ts.w_roff = p; p += nv + 1; ts.w_rlist = p; p += nr;
     ts.w_poff = p; p += nv + 1; ts.w_plist = p; p += np;
-    ts.w_soff = p; p += nv + 1; ts.w_slist = p;
+    ts.w_soff = p; p += nv + 1; ts.w_slist = p; p += ns;
+    ts.w_kleaf = p;
     return hipSuccess;
 }
 

@@ -87,6 +87,7 @@ struct TreeSched {
     // the same structure by POSE SLOT, for tree_wave_kernel (one wave per window, lane = pose): parent slot (-1: root), height above
     // the leaves, children (w_klist[w_koff[v] .. w_koff[v+1])), and the edges of the pose (unary ones, and those to its parent)
     const int32_t *w_par, *w_height, *w_koff, *w_klist, *w_roff, *w_rlist, *w_poff, *w_plist, *w_soff, *w_slist;
+    const int32_t* w_kleaf;   // [nv] how many of a pose's children are leaves (they come first in w_klist)
     int nv, nr, np, ns, depth, nroots, nlev, max_se3_per_node;
 };
 size_t window_tree_workspace_doubles(const WindowCaps& c, long long B);

@@ -4693,6 +4693,7 @@ __global__ void __launch_bounds__(64, 1) tree_wave_kernel(const WindowArgs a, co
         nd.q0 = ts.w_poff[lane]; nd.q1 = ts.w_poff[lane + 1];
         nd.s0 = ts.w_soff[lane]; nd.s1 = ts.w_soff[lane + 1];
     }
+    const int kleaf = node ? ts.w_kleaf[lane] : 0;
     const double* gin = a.poses_in + ((size_t)inst * c.nv_max + (node ? lane : 0)) * 12;
     double* gout = a.poses + ((size_t)inst * c.nv_max + (node ? lane : 0)) * 12;
     double Xa[12], Xb[12];   // state / trial state
@@ -4765,6 +4766,27 @@ __global__ void __launch_bounds__(64, 1) tree_wave_kernel(const WindowArgs a, co
                 // ---- (H + lambda I) x = b: leaves first, by height; a node's Schur update goes to its parent through LDS ----------------
                 bool ok = true;
                 for (int h = 0; h < ts.nlev; ++h) {
+                    if (h == 1) {
+                        // every node sums what its LEAF children handed up, all nodes at once (inside the level loop that sum would be
+                        // walked once per level by the whole wave: config 5's keys have seven leaves each); it waits in the node's own
+                        // slot of `dep`, which the node only overwrites when it hands its own update up
+                        if (node && nd.height >= 1) {
+                            double pre[27];
+#pragma unroll
+                            for (int k = 0; k < 27; ++k) pre[k] = 0.0;
+                            for (int ci = nd.k0; ci < nd.k0 + kleaf; ++ci) {
+                                const double* d = dep + ts.w_klist[ci] * 27;
+#pragma unroll
+                                for (int k = 0; k < 27; ++k) pre[k] += d[k];
+                            }
+                            wsync();
+#pragma unroll
+                            for (int k = 0; k < 27; ++k) dep[lane * 27 + k] = pre[k];
+                        } else {
+                            wsync();
+                        }
+                        wsync();
+                    }
                     if (node && nd.height == h) {
                         double A[6][6], rhs[6];
 #pragma unroll
@@ -4774,7 +4796,16 @@ __global__ void __launch_bounds__(64, 1) tree_wave_kernel(const WindowArgs a, co
                             A[r][r] += lambda;
                             rhs[r] = HB[r];
                         }
-                        for (int ci = nd.k0; ci < nd.k1; ++ci) {
+                        if (h >= 1) {
+                            const double* d = dep + lane * 27;
+#pragma unroll
+                            for (int r = 0; r < 6; ++r) {
+#pragma unroll
+                                for (int cc = 0; cc <= r; ++cc) A[r][cc] -= d[r * (r + 1) / 2 + cc];
+                                rhs[r] -= d[21 + r];
+                            }
+                        }
+                        for (int ci = nd.k0 + kleaf; ci < nd.k1; ++ci) {
                             const double* d = dep + ts.w_klist[ci] * 27;
 #pragma unroll
                             for (int r = 0; r < 6; ++r) {
