@@ -566,8 +566,10 @@ static long long tree_min_batch(const loc_window* w) {
 
 // what the batch qualifies for BY ITS STRUCTURE: LOC_WINDOW_KERNEL_GENERAL, _CHAIN (block-tridiagonal, 6-DoF), _CHAIN3, _ARROW3 or _TREE
 // (for _ARROW3 the edge lists are left in w->h_a*)
+// may_build_aux: ARROW3 / TREE keep host-built tables on the handle (edge records, the elimination schedule).  A resident batch owns
+// them from its upload on: a loc_window_solve_host call in between must not rebuild them (it takes the general kernel instead).
 static int batch_topology(loc_window* w, int64_t n, const int32_t* counts, const double* poses, const int32_t* r_idx, const double* r_val,
-                          const int32_t* p_idx, const double* p_val, const int32_t* s_idx) {
+                          const int32_t* p_idx, const double* p_val, const int32_t* s_idx, bool may_build_aux) {
     const locamd::WindowCaps& c = w->caps;
     bool chain = true;
     for (int64_t i = 0; i < n && chain; ++i) {
@@ -595,6 +597,7 @@ static int batch_topology(loc_window* w, int64_t n, const int32_t* counts, const
         }
     }
     if (chain) return translation_only(w, n, counts, poses, r_val, p_val) ? LOC_WINDOW_KERNEL_CHAIN3 : LOC_WINDOW_KERNEL_CHAIN;
+    if (!may_build_aux) return LOC_WINDOW_KERNEL_GENERAL;
     {
         // (LOCAMD_ARROW3: 0 = never, 1 = whenever the batch qualifies; default: windows of more than 64 poses — below that the
         //  wave-per-window kernel keeps everything in LDS and is the better choice)
@@ -729,7 +732,7 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
             a.anchors = w->d_anchors; a.workspace = w->d_workspace;
             a.n_anchors = w->n_anchors; a.B = (int)n; a.iterations = w->iterations; a.caps = c;
             LOC_HIP(hipEventRecord(w->ev0, st));
-            const int kind = pick_kernel(w, n, batch_topology(w, n, counts, poses, r_idx, r_val, p_idx, p_val, s_idx));
+            const int kind = pick_kernel(w, n, batch_topology(w, n, counts, poses, r_idx, r_val, p_idx, p_val, s_idx, w->n_resident == 0));
             if (kind == LOC_WINDOW_KERNEL_ARROW3) LOC_HIP(upload_arrow_aux(w, n, st));
             if (kind == LOC_WINDOW_KERNEL_TREE) LOC_HIP(upload_tree_sched(w, st));
             hipError_t e = launch_any(w, a, st, kind);
@@ -765,7 +768,7 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
     a.p_val = w->d_pval; a.s_idx = w->d_sidx; a.s_val = w->d_sval; a.anchors = w->d_anchors; a.result = w->d_result;
     a.workspace = w->d_workspace;
     a.n_anchors = w->n_anchors; a.B = (int)n; a.iterations = w->iterations; a.caps = c;
-    const int kind = pick_kernel(w, n, batch_topology(w, n, counts, poses, r_idx, r_val, p_idx, p_val, s_idx));
+    const int kind = pick_kernel(w, n, batch_topology(w, n, counts, poses, r_idx, r_val, p_idx, p_val, s_idx, w->n_resident == 0));
     if (kind == LOC_WINDOW_KERNEL_ARROW3) LOC_HIP(upload_arrow_aux(w, n, st));
     if (kind == LOC_WINDOW_KERNEL_TREE) LOC_HIP(upload_tree_sched(w, st));
     LOC_HIP(hipEventRecord(w->ev0, st));
@@ -813,7 +816,7 @@ int loc_window_upload(loc_window* w, int64_t n, const int32_t* counts, const dou
     }
     w->n_resident = n;
     w->resident_solved = false;
-    w->resident_topology = batch_topology(w, n, counts, poses, r_idx, r_val, p_idx, p_val, s_idx);
+    w->resident_topology = batch_topology(w, n, counts, poses, r_idx, r_val, p_idx, p_val, s_idx, true);
     if (w->resident_topology == LOC_WINDOW_KERNEL_ARROW3) LOC_HIP(upload_arrow_aux(w, n, w->stream));
     if (w->resident_topology == LOC_WINDOW_KERNEL_TREE) LOC_HIP(upload_tree_sched(w, w->stream));
     int max_anchor = 0;   // anchors referenced: v1 = -1 - anchor

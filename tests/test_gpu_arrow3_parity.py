@@ -153,3 +153,42 @@ def test_arrow3_is_taken_by_large_translation_only_arrowheads_only(gpu):
     s.solve(small)
     assert s.last_kernel_kind() == "window_lm_kernel"
     s.close()
+
+
+def test_cfg4_full_batch_properties(gpu):
+    """BASELINE config 4 at its full size on ONE GPU (1 024 hypotheses of 256 + 10 poses, tiled from 32 distinct ones): determinism,
+    repeated hypotheses in other workgroups give the same bits, permutation equivariance over the hypotheses, resident path = host path,
+    and an oracle spot check on two hypotheses."""
+    import sys
+    import localization_amd as la
+    from oracle import oracle as O
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "perf"))
+    import bench_window as bw
+    B, nd = 1024, 32
+    small, graphs, anchors, nv = bw.build_selfcal(nd, np.random.default_rng(21))
+    wb = la.WindowBatch(B, *small.caps)
+    for name in ("counts", "poses", "r_idx", "r_val", "p_idx", "p_val", "s_idx", "s_val"):
+        src = getattr(small, name); getattr(wb, name)[:] = np.resize(src, (B,) + src.shape[1:])
+    poses0 = wb.poses.copy()
+    s = la.WindowSolver(anchors, B, *wb.caps, maximum_iteration=10, bw_max=nv - 1, jacobian="analytic")
+    res = s.solve(wb).copy()
+    assert s.last_kernel_kind() == "arrow3_lm_kernel"
+    first = wb.poses.copy()
+    assert np.isfinite(first).all()
+    for k in range(1, B // nd):                                      # the same hypothesis in another workgroup: the same bits
+        assert np.array_equal(first[k * nd:(k + 1) * nd], first[:nd]) and np.array_equal(res[k * nd:(k + 1) * nd], res[:nd])
+    wb.poses[:] = poses0
+    assert np.array_equal(s.solve(wb), res) and np.array_equal(wb.poses, first)          # determinism
+    perm = np.random.default_rng(0).permutation(B)
+    pw = la.WindowBatch(B, *wb.caps)
+    for name in ("counts", "r_idx", "r_val", "p_idx", "p_val", "s_idx", "s_val"):
+        getattr(pw, name)[:] = getattr(wb, name)[perm]
+    pw.poses[:] = poses0[perm]
+    assert np.array_equal(s.solve(pw), res[perm]) and np.array_equal(pw.poses, first[perm])   # permutation equivariance
+    wb.poses[:] = poses0
+    s.upload(wb); s.solve_resident(); s.download(wb)
+    assert np.array_equal(wb.poses, first) and np.array_equal(wb.result, res)                  # resident path
+    s.close()
+    for i in (0, 17):
+        want = bw.oracle_selfcal(graphs[i], 256, 10)    # numeric oracle; the kernel ran analytic: the cross-mode bound of this shape
+        assert np.abs(first[i, :, 9:] - want).max() < 1e-4, (i, np.abs(first[i, :, 9:] - want).max())
