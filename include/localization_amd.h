@@ -225,7 +225,7 @@ int loc_window_set_chain_threshold(loc_window* w, int64_t min_batch);
 /* Which kernel the last solve of this handle ran (the choice depends on the batch: its size and structure).
  *   GENERAL  window_lm_kernel: one wave (65 ... 512 poses: eight waves) per window, sparse block Cholesky in a minimum-degree order
  *   CHAIN    chain_lm_kernel: one lane per window, block-tridiagonal 6x6 (batches >= the chain threshold of chain windows)
- *   CHAIN3   chain3_lm_kernel: the same for TRANSLATION-ONLY batches — no EdgeSE3, every lever arm zero, every rotation the
+ *   CHAIN3   chain3_lm_kernel: the same (from 4 096 windows on, unless a threshold was set) for TRANSLATION-ONLY batches — no EdgeSE3, every lever arm zero, every rotation the
  *            identity (what Robot::init, robot.cpp:47, and the default identity antenna offsets, localization.h:170, give:
  *            cfg/uwb_only.yaml on the example bag), priors without rotation information: the 6-DoF problem then reduces EXACTLY
  *            to 3x3 blocks (types_edge_se3range.cpp:105-114 does not see the rotation; SURVEY.md §8(a) note)

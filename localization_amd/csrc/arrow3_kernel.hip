@@ -127,7 +127,7 @@ __device__ __forceinline__ double pivot_rsqrtA(double d) {   // window_kernel.hi
 }
 
 #pragma clang fp contract(off)
-__device__ __forceinline__ double norm3_plainA(double dx, double dy, double dz) { return sqrt(dx * dx + dy * dy + dz * dz); }
+__device__ __forceinline__ double norm3_plainA(double dx, double dy, double dz) { return sqrt_ieee_unscaled(dx * dx + dy * dy + dz * dz); }
 // g2o's central difference along axis D of endpoint `which` (chain3_kernel.hip: range_jac_numeric3)
 template <int D>
 __device__ __forceinline__ double range_jac_numericA(const double* p0, const double* p1, int which, double meas) {

@@ -619,6 +619,12 @@ static int pick_kernel(const loc_window* w, int64_t n, int topology) {
     if (w->has_off1) return LOC_WINDOW_KERNEL_GENERAL;   // (lever arms on endpoint 1: only the general kernel evaluates them)
     if (topology == LOC_WINDOW_KERNEL_ARROW3) return w->natural_order ? LOC_WINDOW_KERNEL_GENERAL : LOC_WINDOW_KERNEL_ARROW3;   // (one wave per window: any batch size)
     if (topology == LOC_WINDOW_KERNEL_TREE) return (w->natural_order || n < tree_min_batch(w)) ? LOC_WINDOW_KERNEL_GENERAL : LOC_WINDOW_KERNEL_TREE;
+    if (topology == LOC_WINDOW_KERNEL_CHAIN3 && mn > 0 && !w->natural_order && w->chain_min < 0 && !getenv("LOCAMD_CHAIN_MIN_BATCH") && n >= 4096 && n < mn) {
+        // the translation-only kernel is worth it from ~4 096 windows on (it takes ~1 ms for any batch up to 16 384, the wave-per-window
+        // kernel 4.3e6 windows/s): e.g. one GPU's 8 192-window share of a 65 536-window job split over eight
+        const char* v = getenv("LOCAMD_CHAIN3");
+        if (!(v && v[0] == '0')) return LOC_WINDOW_KERNEL_CHAIN3;
+    }
     if (topology == LOC_WINDOW_KERNEL_GENERAL || mn <= 0 || n < mn || w->natural_order) return LOC_WINDOW_KERNEL_GENERAL;
     if (topology == LOC_WINDOW_KERNEL_CHAIN3) {   // LOCAMD_CHAIN3=0: the 6-DoF kernel on a translation-only batch (A/B runs, tests; read per call)
         const char* v = getenv("LOCAMD_CHAIN3");

@@ -71,7 +71,7 @@ __device__ __forceinline__ double pivot_rsqrt3(double d) {   // window_kernel.hi
 
 #pragma clang fp contract(off)
 // ||d|| the way a plain CPU build of computeError evaluates it (numeric_jacobian.h: range_error_plain with a zero lever arm)
-__device__ __forceinline__ double norm3_plain(double dx, double dy, double dz) { return sqrt(dx * dx + dy * dy + dz * dz); }
+__device__ __forceinline__ double norm3_plain(double dx, double dy, double dz) { return sqrt_ieee_unscaled(dx * dx + dy * dy + dz * dz); }
 // g2o's central difference of e = meas - ||p0 - p1|| along axis D of endpoint `which`'s translation (numeric_jacobian.h /
 // window_kernel.hip: range_jac_numeric with R = I and a zero lever arm: X * fromVectorMQT(+-delta e_D) = (I, t +- delta e_D))
 template <int D>

@@ -38,6 +38,25 @@ __device__ __forceinline__ void sqrt_and_rsqrt(double x, double& n, double& inv)
     inv = h + h;
 }
 
+// The IEEE square root of the numeric-Jacobian paths (g2o's central differences need the CPU's roundings): the compiler's own f64
+// expansion (AMDGPU lowerFSQRTF64: v_rsq_f64 seed, one coupled Goldschmidt step, two residual corrections, +-0 / +inf passed through)
+// WITHOUT its 2^+-256 argument scaling, which only matters below 2^-767 — squared distances never are, short of exactly 0 — so the
+// result is bit-identical to sqrt() for every argument these kernels produce (tools/sqrt_probe.hip, profiles/r03_sqrt_probe.txt) at 13
+// instructions instead of 18; a numeric-mode edge takes seven of them per LM pass.
+__device__ __forceinline__ double sqrt_ieee_unscaled(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double s = x * y;
+    double h = y * 0.5;
+    const double r = __builtin_fma(-h, s, 0.5);
+    s = __builtin_fma(s, r, s);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-s, s, x);
+    s = __builtin_fma(d, h, s);
+    d = __builtin_fma(-s, s, x);
+    s = __builtin_fma(d, h, s);
+    return (x == 0.0 || x == __builtin_inf()) ? x : s;
+}
+
 // n = sqrt(x) to 4.1e-15 relative (the Goldschmidt step without the residual correction; profiles/r01_math_probe.txt) and
 // inv = 1/sqrt(x) to 4.2e-15:
 // the range norm of the analytic kernels, where 1e-14 m is five orders below anything the estimate resolves; two

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 
+#include "device_math.h"
+
 namespace locamd {
 namespace {
 
@@ -18,7 +20,7 @@ __device__ __forceinline__ double range_error_plain(const double* R, const doubl
     const double py = R[3] * off[0] + R[4] * off[1] + R[5] * off[2];
     const double pz = R[6] * off[0] + R[7] * off[1] + R[8] * off[2];
     const double dx = (px + t[0]) - q1[0], dy = (py + t[1]) - q1[1], dz = (pz + t[2]) - q1[2];
-    return meas - sqrt(dx * dx + dy * dy + dz * dz);
+    return meas - sqrt_ieee_unscaled(dx * dx + dy * dy + dz * dz);
 }
 // X * fromVectorMQT(dl e_D): (R Rinc, R tinc + t)
 template <int D>
@@ -53,7 +55,7 @@ __device__ __forceinline__ void perturbed_point_plain(const double* R, const dou
 }
 __device__ __forceinline__ double norm_to_plain(const double* P, double ax, double ay, double az) {
     const double dx = P[0] - ax, dy = P[1] - ay, dz = P[2] - az;
-    return sqrt(dx * dx + dy * dy + dz * dz);
+    return sqrt_ieee_unscaled(dx * dx + dy * dy + dz * dz);
 }
 // J = ((meas - n+) - (meas - n-)) / (2 delta), g2o's operation order
 __device__ __forceinline__ double central_difference_plain(double meas, double np, double nm) {

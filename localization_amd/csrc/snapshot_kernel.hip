@@ -82,7 +82,7 @@ struct System {
 // on the IEEE sqrt so the difference quotient sees (nearly) the same roundings as a CPU build.
 #pragma clang fp contract(off)
 __device__ __forceinline__ double range_norm_plain(double dx, double dy, double dz) {
-    return sqrt(dx * dx + dy * dy + dz * dz);
+    return sqrt_ieee_unscaled(dx * dx + dy * dy + dz * dz);
 }
 #pragma clang fp contract(fast)
 
