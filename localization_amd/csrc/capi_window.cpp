@@ -36,22 +36,26 @@ struct loc_window {
     double* d_poses_in = nullptr;   // resident mode: the uploaded initial estimates (every resident solve starts from them)
     double* d_chain_ws = nullptr;   // chain windows (one lane per window, window_kernel.hip: chain_lm_kernel): its workspace
     double* d_chain3_ws = nullptr;  // translation-only chain windows (chain3_kernel.hip)
-    // forest windows of one shared topology (window_kernel.hip: tree_lm_kernel): the schedule (one int table on the device), its workspace
-    int32_t* d_tsched = nullptr;
-    size_t tsched_cap = 0;
-    std::vector<int32_t> h_tsched;
-    locamd::TreeSched tsched{};
-    double* d_tree_ws = nullptr;
+    // Host-built tables of the kernels that need them (tree_wave / tree_lm: the elimination schedule; arrow3: row order + packed edge
+    // records).  Two sets: [0] for loc_window_solve_host calls, [1] owned by the resident batch from its upload on — a host-path solve in
+    // between must not disturb what the next loc_window_solve_resident walks.
+    struct WinAux {
+        int32_t* d_tsched = nullptr;
+        size_t tsched_cap = 0;
+        std::vector<int32_t> h_tsched;
+        locamd::TreeSched tsched{};
+        int32_t *d_ahdr = nullptr, *d_arslot = nullptr;
+        double *d_arec = nullptr, *d_aprec = nullptr;
+        size_t arec_cap = 0, aprec_cap = 0;   // doubles allocated
+        int arrow_nb_max = 0, arrow_jmax = 0, arrow_jpmax = 0;
+        std::vector<int32_t> h_ahdr, h_arslot;
+        std::vector<double> h_arec, h_aprec;
+    } aux[2];
+    double* d_tree_ws = nullptr;    // workspaces (used only while a launch runs)
+    double* d_arrow_ws = nullptr;
+    int arrow_ws_nb = 0;            // border size d_arrow_ws was allocated for
     double* d_roff1 = nullptr;      // optional lever arms of endpoint 1 (loc_window_set_endpoint1_offsets), [B][nr_max][3]
     bool has_off1 = false;
-    // translation-only chain + dense border windows (arrow3_kernel.hip): per-pose edge lists built on the host, its workspace
-    int32_t *d_ahdr = nullptr, *d_arslot = nullptr;
-    double *d_arec = nullptr, *d_aprec = nullptr, *d_arrow_ws = nullptr;
-    size_t arec_cap = 0, aprec_cap = 0;   // doubles allocated
-    int arrow_ws_nb = 0;            // border size d_arrow_ws was allocated for
-    int arrow_nb_max = 0, arrow_jmax = 0, arrow_jpmax = 0;   // of the batch whose records are on the device
-    std::vector<int32_t> h_ahdr, h_arslot;
-    std::vector<double> h_arec, h_aprec;
     int resident_topology = 0;      // LOC_WINDOW_KERNEL_* the uploaded batch qualifies for by its structure (the batch-size threshold is applied per solve)
     long long chain_min = -1;       // smallest batch that takes a lane-per-window kernel (-1: the default / LOCAMD_CHAIN_MIN_BATCH)
     long long n_resident = 0;
@@ -91,7 +95,9 @@ int loc_window_destroy(loc_window* w) {
     if (!w) return LOC_OK;
     (void)hipSetDevice(w->device);
     void* ptrs[] = {w->d_anchors, w->d_counts, w->d_ridx, w->d_pidx, w->d_sidx, w->d_poses, w->d_rval, w->d_pval, w->d_sval, w->d_result, w->d_workspace, w->d_poses_in,
-                    w->d_chain_ws, w->d_chain3_ws, w->d_roff1, w->d_tsched, w->d_tree_ws, w->d_ahdr, w->d_arslot, w->d_arec, w->d_aprec, w->d_arrow_ws};
+                    w->d_chain_ws, w->d_chain3_ws, w->d_roff1, w->d_tree_ws, w->d_arrow_ws,
+                    w->aux[0].d_tsched, w->aux[0].d_ahdr, w->aux[0].d_arslot, w->aux[0].d_arec, w->aux[0].d_aprec,
+                    w->aux[1].d_tsched, w->aux[1].d_ahdr, w->aux[1].d_arslot, w->aux[1].d_arec, w->aux[1].d_aprec};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : w->ev) (void)hipEventDestroy(e);
     if (w->h_stage) (void)hipHostFree(w->h_stage);
@@ -240,13 +246,14 @@ static bool translation_only(const loc_window* w, int64_t n, const int32_t* coun
 // rows (separators first, then the original border in slot order).  A chain row owns its edges to anchors, to border poses and
 // to the previous chain row; a border row those to lower-index border poses and to anchors.  Every row's edges (creation order)
 // and priors are packed as records [chunk of 64 rows][slot][lane].
-static bool build_arrow_aux(loc_window* w, int64_t n, const int32_t* counts, const int32_t* r_idx, const double* r_val, const int32_t* p_idx,
+static bool build_arrow_aux(loc_window* w, int which, int64_t n, const int32_t* counts, const int32_t* r_idx, const double* r_val, const int32_t* p_idx,
                             const double* p_val) {
+    loc_window::WinAux& A = w->aux[which];
     const locamd::WindowCaps& c = w->caps;
     const int NW = 4;
     const int nchunk = (c.nv_max + 63) / 64;
-    w->h_ahdr.assign((size_t)n * 8, 0);
-    w->h_arslot.assign((size_t)n * c.nv_max, 0);
+    A.h_ahdr.assign((size_t)n * 8, 0);
+    A.h_arslot.assign((size_t)n * c.nv_max, 0);
     std::vector<int32_t> cls, nedge, nprior, pairs;
     std::vector<int> seps;
     // pass 1: structure, record counts
@@ -271,8 +278,8 @@ static bool build_arrow_aux(loc_window* w, int64_t n, const int32_t* counts, con
         cls.assign((size_t)nv, 0);
         seps.clear();
         for (int k = 1; k < nseg; ++k) seps.push_back((int)((long long)k * n0 / nseg));
-        int32_t* hdr = w->h_ahdr.data() + (size_t)i * 8;
-        int32_t* rslot = w->h_arslot.data() + (size_t)i * c.nv_max;
+        int32_t* hdr = A.h_ahdr.data() + (size_t)i * 8;
+        int32_t* rslot = A.h_arslot.data() + (size_t)i * c.nv_max;
         hdr[0] = nb; hdr[1] = nseg; hdr[2] = nc; hdr[3] = 0;
         int q = 0, si = 0;
         for (int v = 0; v < n0; ++v) {
@@ -310,20 +317,20 @@ static bool build_arrow_aux(loc_window* w, int64_t n, const int32_t* counts, con
     if (locamd::window_arrow3_lds_bytes(c, nb_max) > 160 * 1024 - 512) return false;
     // pass 2: the records
     const size_t rec_per = (size_t)nchunk * jmax * 64 * 3, prec_per = (size_t)nchunk * jpmax * 64 * 7;
-    w->h_arec.assign((size_t)n * rec_per, -1.0);
-    w->h_aprec.assign((size_t)n * prec_per, 0.0);
+    A.h_arec.assign((size_t)n * rec_per, -1.0);
+    A.h_aprec.assign((size_t)n * prec_per, 0.0);
     for (int64_t i = 0; i < n; ++i) {
         const int32_t* cn = counts + i * 4;
         const int nv = cn[0], nr = cn[1], np = cn[2];
         const int32_t* ri = r_idx + (size_t)i * c.nr_max * 2;
         const double* rv = r_val + (size_t)i * c.nr_max * 5;
-        const int32_t* hdr = w->h_ahdr.data() + (size_t)i * 8;
-        const int32_t* rslot = w->h_arslot.data() + (size_t)i * c.nv_max;
+        const int32_t* hdr = A.h_ahdr.data() + (size_t)i * 8;
+        const int32_t* rslot = A.h_arslot.data() + (size_t)i * c.nv_max;
         const int nb = hdr[0], nc = hdr[2];
         cls.assign((size_t)nv, 0);
         for (int r = 0; r < nc + nb; ++r) cls[rslot[r]] = r < nc ? r : -1 - (r - nc);
         nedge.assign((size_t)nv, 0); nprior.assign((size_t)nv, 0);
-        double* rec = w->h_arec.data() + (size_t)i * rec_per;
+        double* rec = A.h_arec.data() + (size_t)i * rec_per;
         for (int e = 0; e < nr; ++e) {
             const int v0 = ri[2 * e], v1 = ri[2 * e + 1];
             int row, kind, idx, own0;
@@ -344,7 +351,7 @@ static bool build_arrow_aux(loc_window* w, int64_t n, const int32_t* counts, con
         }
         const int32_t* pi = p_idx + (size_t)i * c.np_max;
         const double* pv = p_val + (size_t)i * c.np_max * 18;
-        double* prec = w->h_aprec.data() + (size_t)i * prec_per;
+        double* prec = A.h_aprec.data() + (size_t)i * prec_per;
         for (int e = 0; e < np; ++e) {
             const int cv = cls[pi[e]], row = cv >= 0 ? cv : nc + (-1 - cv);
             double* q = prec + (((size_t)(row / 64) * jpmax + nprior[row]++) * 64 + row % 64) * 7;
@@ -352,39 +359,40 @@ static bool build_arrow_aux(loc_window* w, int64_t n, const int32_t* counts, con
             for (int k = 0; k < 3; ++k) { q[1 + k] = pv[18 * e + 9 + k]; q[4 + k] = pv[18 * e + 12 + k]; }
         }
     }
-    w->arrow_nb_max = nb_max; w->arrow_jmax = jmax; w->arrow_jpmax = jpmax;
+    A.arrow_nb_max = nb_max; A.arrow_jmax = jmax; A.arrow_jpmax = jpmax;
     return true;
 }
-static hipError_t upload_arrow_aux(loc_window* w, int64_t n, hipStream_t st) {
+static hipError_t upload_arrow_aux(loc_window* w, int which, int64_t n, hipStream_t st) {
+    loc_window::WinAux& A = w->aux[which];
     const locamd::WindowCaps& c = w->caps;
     const size_t B = (size_t)w->B, N = (size_t)n;
     hipError_t e;
-    if (!w->d_ahdr) {
-        if ((e = hipMalloc((void**)&w->d_ahdr, B * 8 * sizeof(int32_t))) != hipSuccess ||
-            (e = hipMalloc((void**)&w->d_arslot, B * c.nv_max * sizeof(int32_t))) != hipSuccess) return e;
+    if (!A.d_ahdr) {
+        if ((e = hipMalloc((void**)&A.d_ahdr, B * 8 * sizeof(int32_t))) != hipSuccess ||
+            (e = hipMalloc((void**)&A.d_arslot, B * c.nv_max * sizeof(int32_t))) != hipSuccess) return e;
     }
-    if (w->arec_cap < w->h_arec.size()) {
-        if (w->d_arec) (void)hipFree(w->d_arec);
-        w->d_arec = nullptr; w->arec_cap = 0;
-        if ((e = hipMalloc((void**)&w->d_arec, w->h_arec.size() / N * B * sizeof(double))) != hipSuccess) return e;
-        w->arec_cap = w->h_arec.size() / N * B;
+    if (A.arec_cap < A.h_arec.size()) {
+        if (A.d_arec) (void)hipFree(A.d_arec);
+        A.d_arec = nullptr; A.arec_cap = 0;
+        if ((e = hipMalloc((void**)&A.d_arec, A.h_arec.size() / N * B * sizeof(double))) != hipSuccess) return e;
+        A.arec_cap = A.h_arec.size() / N * B;
     }
-    if (w->aprec_cap < w->h_aprec.size()) {
-        if (w->d_aprec) (void)hipFree(w->d_aprec);
-        w->d_aprec = nullptr; w->aprec_cap = 0;
-        if ((e = hipMalloc((void**)&w->d_aprec, w->h_aprec.size() / N * B * sizeof(double))) != hipSuccess) return e;
-        w->aprec_cap = w->h_aprec.size() / N * B;
+    if (A.aprec_cap < A.h_aprec.size()) {
+        if (A.d_aprec) (void)hipFree(A.d_aprec);
+        A.d_aprec = nullptr; A.aprec_cap = 0;
+        if ((e = hipMalloc((void**)&A.d_aprec, A.h_aprec.size() / N * B * sizeof(double))) != hipSuccess) return e;
+        A.aprec_cap = A.h_aprec.size() / N * B;
     }
-    if (!w->d_arrow_ws || w->arrow_ws_nb < w->arrow_nb_max) {
+    if (!w->d_arrow_ws || w->arrow_ws_nb < A.arrow_nb_max) {
         if (w->d_arrow_ws) (void)hipFree(w->d_arrow_ws);
         w->d_arrow_ws = nullptr;
-        if ((e = hipMalloc((void**)&w->d_arrow_ws, B * locamd::window_arrow3_workspace_doubles(c, w->arrow_nb_max) * sizeof(double))) != hipSuccess) return e;
-        w->arrow_ws_nb = w->arrow_nb_max;
+        if ((e = hipMalloc((void**)&w->d_arrow_ws, B * locamd::window_arrow3_workspace_doubles(c, A.arrow_nb_max) * sizeof(double))) != hipSuccess) return e;
+        w->arrow_ws_nb = A.arrow_nb_max;
     }
-    if ((e = hipMemcpyAsync(w->d_ahdr, w->h_ahdr.data(), N * 8 * sizeof(int32_t), hipMemcpyHostToDevice, st)) != hipSuccess ||
-        (e = hipMemcpyAsync(w->d_arslot, w->h_arslot.data(), N * c.nv_max * sizeof(int32_t), hipMemcpyHostToDevice, st)) != hipSuccess ||
-        (e = hipMemcpyAsync(w->d_arec, w->h_arec.data(), w->h_arec.size() * sizeof(double), hipMemcpyHostToDevice, st)) != hipSuccess ||
-        (e = hipMemcpyAsync(w->d_aprec, w->h_aprec.data(), w->h_aprec.size() * sizeof(double), hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(A.d_ahdr, A.h_ahdr.data(), N * 8 * sizeof(int32_t), hipMemcpyHostToDevice, st)) != hipSuccess ||
+        (e = hipMemcpyAsync(A.d_arslot, A.h_arslot.data(), N * c.nv_max * sizeof(int32_t), hipMemcpyHostToDevice, st)) != hipSuccess ||
+        (e = hipMemcpyAsync(A.d_arec, A.h_arec.data(), A.h_arec.size() * sizeof(double), hipMemcpyHostToDevice, st)) != hipSuccess ||
+        (e = hipMemcpyAsync(A.d_aprec, A.h_aprec.data(), A.h_aprec.size() * sizeof(double), hipMemcpyHostToDevice, st)) != hipSuccess) return e;
     return hipStreamSynchronize(st);   // (the host vectors may be rebuilt by the next call)
 }
 
@@ -393,7 +401,8 @@ static hipError_t upload_arrow_aux(loc_window* w, int64_t n, hipStream_t st) {
 // edges form a forest.  Builds the elimination schedule tree_lm_kernel walks: nodes in post-order (children before their parent,
 // a node's children heavy subtree first so that the leaves of one parent are consecutive), per node its parent and its edges.
 // Layout of the int table: node[nv] par[nv] r_off[nv+1] r_list[nr] p_off[nv+1] p_list[np] s_off[nv+1] s_list[ns] r_idx[2 nr] s_idx[4 ns].
-static bool build_tree_sched(loc_window* w, int64_t n, const int32_t* counts, const int32_t* r_idx, const int32_t* p_idx, const int32_t* s_idx) {
+static bool build_tree_sched(loc_window* w, int which, int64_t n, const int32_t* counts, const int32_t* r_idx, const int32_t* p_idx, const int32_t* s_idx) {
+    loc_window::WinAux& A = w->aux[which];
     const locamd::WindowCaps& c = w->caps;
     const int nv = counts[0], nr = counts[1], np = counts[2], ns = counts[3];
     if (nv < 2 || nv > 64 || w->has_off1) return false;
@@ -486,7 +495,7 @@ static bool build_tree_sched(loc_window* w, int64_t n, const int32_t* counts, co
         const int vi = s_idx[4 * e], vj = s_idx[4 * e + 1];
         se[(size_t)pos[(size_t)(parent[(size_t)vi] == vj ? vi : vj)]].push_back(e);
     }
-    std::vector<int32_t>& t = w->h_tsched;
+    std::vector<int32_t>& t = A.h_tsched;
     t.clear();
     for (int k = 0; k < nv; ++k) t.push_back(order[(size_t)k]);
     for (int k = 0; k < nv; ++k) { const int p = parent[(size_t)order[(size_t)k]]; t.push_back(p < 0 ? -1 : pos[(size_t)p]); }
@@ -524,26 +533,27 @@ static bool build_tree_sched(loc_window* w, int64_t n, const int32_t* counts, co
     }
     by_slot(kids_lf, false); by_slot(re, true); by_slot(pe, true); by_slot(se, true);
     for (int v = 0; v < nv; ++v) t.push_back(nleafkids[(size_t)v]);
-    w->tsched.nlev = hmax + 1;
-    w->tsched.max_se3_per_node = 0;
-    for (int k = 0; k < nv; ++k) if ((int)se[(size_t)k].size() > w->tsched.max_se3_per_node) w->tsched.max_se3_per_node = (int)se[(size_t)k].size();
-    w->tsched.nv = nv; w->tsched.nr = nr; w->tsched.np = np; w->tsched.ns = ns; w->tsched.depth = maxdepth + 1; w->tsched.nroots = nroots;
+    A.tsched.nlev = hmax + 1;
+    A.tsched.max_se3_per_node = 0;
+    for (int k = 0; k < nv; ++k) if ((int)se[(size_t)k].size() > A.tsched.max_se3_per_node) A.tsched.max_se3_per_node = (int)se[(size_t)k].size();
+    A.tsched.nv = nv; A.tsched.nr = nr; A.tsched.np = np; A.tsched.ns = ns; A.tsched.depth = maxdepth + 1; A.tsched.nroots = nroots;
     return true;
 }
-static hipError_t upload_tree_sched(loc_window* w, hipStream_t st) {
+static hipError_t upload_tree_sched(loc_window* w, int which, hipStream_t st) {
+    loc_window::WinAux& A = w->aux[which];
     hipError_t e;
-    if (w->tsched_cap < w->h_tsched.size()) {
-        if (w->d_tsched) (void)hipFree(w->d_tsched);
-        w->d_tsched = nullptr; w->tsched_cap = 0;
-        if ((e = hipMalloc((void**)&w->d_tsched, w->h_tsched.size() * sizeof(int32_t))) != hipSuccess) return e;
-        w->tsched_cap = w->h_tsched.size();
+    if (A.tsched_cap < A.h_tsched.size()) {
+        if (A.d_tsched) (void)hipFree(A.d_tsched);
+        A.d_tsched = nullptr; A.tsched_cap = 0;
+        if ((e = hipMalloc((void**)&A.d_tsched, A.h_tsched.size() * sizeof(int32_t))) != hipSuccess) return e;
+        A.tsched_cap = A.h_tsched.size();
     }
     if (!w->d_tree_ws && (e = hipMalloc((void**)&w->d_tree_ws, locamd::window_tree_workspace_doubles(w->caps, w->B) * sizeof(double))) != hipSuccess) return e;
-    if ((e = hipMemcpyAsync(w->d_tsched, w->h_tsched.data(), w->h_tsched.size() * sizeof(int32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(A.d_tsched, A.h_tsched.data(), A.h_tsched.size() * sizeof(int32_t), hipMemcpyHostToDevice, st)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
-    locamd::TreeSched& ts = w->tsched;
+    locamd::TreeSched& ts = A.tsched;
     const int nv = ts.nv, nr = ts.nr, np = ts.np, ns = ts.ns;
-    const int32_t* p = w->d_tsched;
+    const int32_t* p = A.d_tsched;
     ts.node = p; p += nv; ts.par = p; p += nv;
     ts.r_off = p; p += nv + 1; ts.r_list = p; p += nr;
     ts.p_off = p; p += nv + 1; ts.p_list = p; p += np;
@@ -566,10 +576,9 @@ static long long tree_min_batch(const loc_window* w) {
 
 // what the batch qualifies for BY ITS STRUCTURE: LOC_WINDOW_KERNEL_GENERAL, _CHAIN (block-tridiagonal, 6-DoF), _CHAIN3, _ARROW3 or _TREE
 // (for _ARROW3 the edge lists are left in w->h_a*)
-// may_build_aux: ARROW3 / TREE keep host-built tables on the handle (edge records, the elimination schedule).  A resident batch owns
-// them from its upload on: a loc_window_solve_host call in between must not rebuild them (it takes the general kernel instead).
-static int batch_topology(loc_window* w, int64_t n, const int32_t* counts, const double* poses, const int32_t* r_idx, const double* r_val,
-                          const int32_t* p_idx, const double* p_val, const int32_t* s_idx, bool may_build_aux) {
+// which: the set of host-built tables ARROW3 / TREE fill (0: a loc_window_solve_host call, 1: the resident batch)
+static int batch_topology(loc_window* w, int which, int64_t n, const int32_t* counts, const double* poses, const int32_t* r_idx, const double* r_val,
+                          const int32_t* p_idx, const double* p_val, const int32_t* s_idx) {
     const locamd::WindowCaps& c = w->caps;
     bool chain = true;
     for (int64_t i = 0; i < n && chain; ++i) {
@@ -597,19 +606,18 @@ static int batch_topology(loc_window* w, int64_t n, const int32_t* counts, const
         }
     }
     if (chain) return translation_only(w, n, counts, poses, r_val, p_val) ? LOC_WINDOW_KERNEL_CHAIN3 : LOC_WINDOW_KERNEL_CHAIN;
-    if (!may_build_aux) return LOC_WINDOW_KERNEL_GENERAL;
     {
         // (LOCAMD_ARROW3: 0 = never, 1 = whenever the batch qualifies; default: windows of more than 64 poses — below that the
         //  wave-per-window kernel keeps everything in LDS and is the better choice)
         const char* v = getenv("LOCAMD_ARROW3");
         const bool want = v ? v[0] == '1' : c.nv_max > 64;
-        if (want && translation_only(w, n, counts, poses, r_val, p_val) && build_arrow_aux(w, n, counts, r_idx, r_val, p_idx, p_val)) return LOC_WINDOW_KERNEL_ARROW3;
+        if (want && translation_only(w, n, counts, poses, r_val, p_val) && build_arrow_aux(w, which, n, counts, r_idx, r_val, p_idx, p_val)) return LOC_WINDOW_KERNEL_ARROW3;
     }
     {
         // (LOCAMD_TREE=0: never.  One wave per window, so any batch gains; the host-side comparison of the index tables is only worth
         //  it from a few hundred windows on — or from the chain threshold when that was lowered, as the tests do)
         const char* v = getenv("LOCAMD_TREE");
-        if (!(v && v[0] == '0') && n >= tree_min_batch(w) && build_tree_sched(w, n, counts, r_idx, p_idx, s_idx)) return LOC_WINDOW_KERNEL_TREE;
+        if (!(v && v[0] == '0') && n >= tree_min_batch(w) && build_tree_sched(w, which, n, counts, r_idx, p_idx, s_idx)) return LOC_WINDOW_KERNEL_TREE;
     }
     return LOC_WINDOW_KERNEL_GENERAL;
 }
@@ -632,18 +640,19 @@ static int pick_kernel(const loc_window* w, int64_t n, int topology) {
     }
     return topology;
 }
-static hipError_t launch_any(loc_window* w, const locamd::WindowArgs& a, hipStream_t st, int kind) {
+static hipError_t launch_any(loc_window* w, int which, const locamd::WindowArgs& a, hipStream_t st, int kind) {
+    loc_window::WinAux& A = w->aux[which];
     w->last_kind = kind;
     if (kind == LOC_WINDOW_KERNEL_ARROW3) {
         locamd::ArrowAux x;
-        x.hdr = w->d_ahdr; x.rslot = w->d_arslot; x.rec = w->d_arec; x.prec = w->d_aprec;
-        x.ws = w->d_arrow_ws; x.nb_max = w->arrow_nb_max; x.jmax = w->arrow_jmax; x.jpmax = w->arrow_jpmax; x.nchunk = (w->caps.nv_max + 63) / 64;
+        x.hdr = A.d_ahdr; x.rslot = A.d_arslot; x.rec = A.d_arec; x.prec = A.d_aprec;
+        x.ws = w->d_arrow_ws; x.nb_max = A.arrow_nb_max; x.jmax = A.arrow_jmax; x.jpmax = A.arrow_jpmax; x.nchunk = (w->caps.nv_max + 63) / 64;
         return locamd::launch_window_arrow3(a, x, st);
     }
     if (kind == LOC_WINDOW_KERNEL_TREE) {   // (LOCAMD_TREE=lane: the one-lane-per-window variant, for A/B runs)
         const char* v = getenv("LOCAMD_TREE");
-        if ((v && v[0] == 'l') || w->tsched.max_se3_per_node > 1) return locamd::launch_window_tree(a, w->tsched, w->d_tree_ws, st);   // (tree_wave_kernel: one EdgeSE3 per node)
-        return locamd::launch_window_tree_wave(a, w->tsched, st);
+        if ((v && v[0] == 'l') || A.tsched.max_se3_per_node > 1) return locamd::launch_window_tree(a, A.tsched, w->d_tree_ws, st);   // (tree_wave_kernel: one EdgeSE3 per node)
+        return locamd::launch_window_tree_wave(a, A.tsched, st);
     }
     if (kind == LOC_WINDOW_KERNEL_CHAIN3) {
         if (!w->d_chain3_ws) {
@@ -738,10 +747,10 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
             a.anchors = w->d_anchors; a.workspace = w->d_workspace;
             a.n_anchors = w->n_anchors; a.B = (int)n; a.iterations = w->iterations; a.caps = c;
             LOC_HIP(hipEventRecord(w->ev0, st));
-            const int kind = pick_kernel(w, n, batch_topology(w, n, counts, poses, r_idx, r_val, p_idx, p_val, s_idx, w->n_resident == 0));
-            if (kind == LOC_WINDOW_KERNEL_ARROW3) LOC_HIP(upload_arrow_aux(w, n, st));
-            if (kind == LOC_WINDOW_KERNEL_TREE) LOC_HIP(upload_tree_sched(w, st));
-            hipError_t e = launch_any(w, a, st, kind);
+            const int kind = pick_kernel(w, n, batch_topology(w, 0, n, counts, poses, r_idx, r_val, p_idx, p_val, s_idx));
+            if (kind == LOC_WINDOW_KERNEL_ARROW3) LOC_HIP(upload_arrow_aux(w, 0, n, st));
+            if (kind == LOC_WINDOW_KERNEL_TREE) LOC_HIP(upload_tree_sched(w, 0, st));
+            hipError_t e = launch_any(w, 0, a, st, kind);
             if (e != hipSuccess) return locamd_fail_hip(e, "launch_window");
             LOC_HIP(hipEventRecord(w->ev1, st));
             LOC_HIP(hipMemcpyAsync(h, d, off[2], hipMemcpyDeviceToHost, st));  // [poses | result]
@@ -774,11 +783,11 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
     a.p_val = w->d_pval; a.s_idx = w->d_sidx; a.s_val = w->d_sval; a.anchors = w->d_anchors; a.result = w->d_result;
     a.workspace = w->d_workspace;
     a.n_anchors = w->n_anchors; a.B = (int)n; a.iterations = w->iterations; a.caps = c;
-    const int kind = pick_kernel(w, n, batch_topology(w, n, counts, poses, r_idx, r_val, p_idx, p_val, s_idx, w->n_resident == 0));
-    if (kind == LOC_WINDOW_KERNEL_ARROW3) LOC_HIP(upload_arrow_aux(w, n, st));
-    if (kind == LOC_WINDOW_KERNEL_TREE) LOC_HIP(upload_tree_sched(w, st));
+    const int kind = pick_kernel(w, n, batch_topology(w, 0, n, counts, poses, r_idx, r_val, p_idx, p_val, s_idx));
+    if (kind == LOC_WINDOW_KERNEL_ARROW3) LOC_HIP(upload_arrow_aux(w, 0, n, st));
+    if (kind == LOC_WINDOW_KERNEL_TREE) LOC_HIP(upload_tree_sched(w, 0, st));
     LOC_HIP(hipEventRecord(w->ev0, st));
-    hipError_t e = launch_any(w, a, st, kind);
+    hipError_t e = launch_any(w, 0, a, st, kind);
     if (e != hipSuccess) return locamd_fail_hip(e, "launch_window");
     LOC_HIP(hipEventRecord(w->ev1, st));
     LOC_HIP(hipMemcpyAsync(poses, w->d_poses, N * c.nv_max * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -822,9 +831,9 @@ int loc_window_upload(loc_window* w, int64_t n, const int32_t* counts, const dou
     }
     w->n_resident = n;
     w->resident_solved = false;
-    w->resident_topology = batch_topology(w, n, counts, poses, r_idx, r_val, p_idx, p_val, s_idx, true);
-    if (w->resident_topology == LOC_WINDOW_KERNEL_ARROW3) LOC_HIP(upload_arrow_aux(w, n, w->stream));
-    if (w->resident_topology == LOC_WINDOW_KERNEL_TREE) LOC_HIP(upload_tree_sched(w, w->stream));
+    w->resident_topology = batch_topology(w, 1, n, counts, poses, r_idx, r_val, p_idx, p_val, s_idx);
+    if (w->resident_topology == LOC_WINDOW_KERNEL_ARROW3) LOC_HIP(upload_arrow_aux(w, 1, n, w->stream));
+    if (w->resident_topology == LOC_WINDOW_KERNEL_TREE) LOC_HIP(upload_tree_sched(w, 1, w->stream));
     int max_anchor = 0;   // anchors referenced: v1 = -1 - anchor
     for (int64_t i = 0; i < n; ++i)
         for (int e = 0; e < counts[i * 4 + 1]; ++e) {
@@ -850,7 +859,7 @@ int loc_window_solve_resident(loc_window* w, void* hip_stream) {
     if (timed) LOC_HIP(hipEventRecord(w->ev[w->ev_used], st));
     // (the batch-size threshold and the ordering override are looked at per solve: loc_window_set_chain_threshold /
     //  loc_window_set_ordering after the upload take effect)
-    hipError_t e = launch_any(w, a, st, pick_kernel(w, w->n_resident, w->resident_topology));
+    hipError_t e = launch_any(w, 1, a, st, pick_kernel(w, w->n_resident, w->resident_topology));
     if (e != hipSuccess) return locamd_fail_hip(e, "launch_window");
     if (timed) { LOC_HIP(hipEventRecord(w->ev[w->ev_used + 1], st)); w->ev_used += 2; }
     w->last_stream = st;

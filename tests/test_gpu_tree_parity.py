@@ -97,10 +97,10 @@ def test_tree_kernel_matches_oracle_and_general_kernel(gpu, T, every, rich, jac)
     wb2 = _copy_batch(la, wb); wb2.poses[:] = before
     s.upload(wb2); s.solve_resident(); s.download(wb2)
     assert s.last_kernel_kind() == kind and np.array_equal(wb2.poses, wb.poses) and np.array_equal(wb2.result, res)
-    # a host-path solve of ANOTHER batch while this one is resident must not disturb the resident batch's schedule (it takes the general kernel)
+    # a host-path solve of ANOTHER batch (another topology, another schedule) while this one is resident must not disturb the resident
+    # batch's schedule: the handle keeps one set of host-built tables per path
     other = _forest_batch(la, np.random.default_rng(1), B, T, max(every, 2) if T >= 12 else every, False)
     s.solve(other)
-    assert s.last_kernel_kind() in ("window_lm_kernel", "chain_lm_kernel")
     s.solve_resident(); s.download(wb2)
     assert s.last_kernel_kind() == kind and np.array_equal(wb2.poses, wb.poses) and np.array_equal(wb2.result, res)
     s.close()
