@@ -106,6 +106,48 @@ def test_tree_kernel_matches_oracle_and_general_kernel(gpu, T, every, rich, jac)
     s.close()
 
 
+@pytest.mark.parametrize("jac", ["analytic", "numeric"])
+def test_lane_per_window_tree_kernel_on_the_same_schedule(gpu, jac):
+    """tree_lm_kernel — one lane per window walking the host's schedule, the state in an [entry][lane] workspace — serves batches whose
+    nodes have several EdgeSE3 to their parent; LOCAMD_TREE=lane selects it for any forest batch: the same answers as tree_wave_kernel
+    and the oracle, on a batch with two trees, doubled pairs, priors and lever arms."""
+    import localization_amd as la
+    from oracle import oracle as O
+    from _oracle_window import oracle_solve_instance
+    B, T = 70, 24
+    rng = np.random.default_rng(31 + len(jac))
+    wb = _forest_batch(la, rng, B, T, 4, True)
+    # a second EdgeSE3 on one child-parent pair of every window: tree_wave_kernel does not take such batches
+    for i in range(B):
+        wb.add_se3(i, 3, 5, *_rel(wb, i, 3, 5), np.eye(6) * 2e3, True)
+    mode = O.JAC_ANALYTIC if jac == "analytic" else O.JAC_NUMERIC_G2O
+    want = [oracle_solve_instance(wb, i, ANCH, jac_mode=mode) for i in range(12)]
+    s = la.WindowSolver(ANCH, B, *wb.caps, jacobian=jac, bw_max=T - 1, chain_threshold=1)
+    res = s.solve(wb).copy()
+    assert s.last_kernel_kind() == "tree_lm_kernel" and (res[:, 7] % 65536 == 2 * T - 2).all()   # (two trees: 2 nv - 2 blocks)
+    tol = 1e-7 if jac == "analytic" else 1e-5
+    for i in range(12):
+        assert np.abs(wb.poses[i] - want[i][0]).max() < tol, (i, np.abs(wb.poses[i] - want[i][0]).max())
+    # without the doubled EdgeSE3 both variants apply: lane-per-window (forced) against lane-per-pose
+    plain_lane = _forest_batch(la, np.random.default_rng(5), B, T, 4, True)
+    plain_wave = _copy_batch(la, plain_lane)
+    os.environ["LOCAMD_TREE"] = "lane"
+    try:
+        s.solve(plain_lane)
+    finally:
+        del os.environ["LOCAMD_TREE"]
+    s.solve(plain_wave)
+    assert np.abs(plain_lane.poses - plain_wave.poses).max() < tol
+    s.close()
+
+
+def _rel(wb, i, a, b):
+    """relative pose a -> b of window i's current estimates (a measurement the estimates satisfy), as (t, R)"""
+    Ra, ta = wb.poses[i, a, :9].reshape(3, 3), wb.poses[i, a, 9:]
+    Rb, tb = wb.poses[i, b, :9].reshape(3, 3), wb.poses[i, b, 9:]
+    return Ra.T @ (tb - ta), Ra.T @ Rb
+
+
 def test_tree_kernel_needs_one_shared_forest_topology(gpu):
     import localization_amd as la
     rng = np.random.default_rng(3)
