@@ -242,7 +242,8 @@ int loc_window_set_chain_threshold(loc_window* w, int64_t min_batch);
  *            their parent: tree_lm_kernel, one lane per window on the same schedule.)
  * All of them run the same LM and agree to the tolerances of DESIGN.md §3; result[6] / result[7] keep their meaning (the
  * lane-per-window kernels eliminate in pose order: result[7] = nv * 65536 + 2 nv - 1). */
-enum { LOC_WINDOW_KERNEL_NONE = -1, LOC_WINDOW_KERNEL_GENERAL = 0, LOC_WINDOW_KERNEL_CHAIN = 1, LOC_WINDOW_KERNEL_CHAIN3 = 2, LOC_WINDOW_KERNEL_ARROW3 = 3, LOC_WINDOW_KERNEL_TREE = 4 };
+enum { LOC_WINDOW_KERNEL_NONE = -1, LOC_WINDOW_KERNEL_GENERAL = 0, LOC_WINDOW_KERNEL_CHAIN = 1, LOC_WINDOW_KERNEL_CHAIN3 = 2, LOC_WINDOW_KERNEL_ARROW3 = 3, LOC_WINDOW_KERNEL_TREE = 4,
+       LOC_WINDOW_KERNEL_TREE_LANE = 5 /* reported only: the lane-per-window variant of TREE ran */ };
 int loc_window_last_kernel_kind(const loc_window* w, int32_t* kind);
 /* Device-resident operation: upload n instances once (same host layouts as loc_window_solve_host), then run
  * loc_window_solve_resident any number of times — each launch starts from the uploaded estimates, is asynchronous on

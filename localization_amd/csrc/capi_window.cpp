@@ -651,7 +651,10 @@ static hipError_t launch_any(loc_window* w, int which, const locamd::WindowArgs&
     }
     if (kind == LOC_WINDOW_KERNEL_TREE) {   // (LOCAMD_TREE=lane: the one-lane-per-window variant, for A/B runs)
         const char* v = getenv("LOCAMD_TREE");
-        if ((v && v[0] == 'l') || A.tsched.max_se3_per_node > 1) return locamd::launch_window_tree(a, A.tsched, w->d_tree_ws, st);   // (tree_wave_kernel: one EdgeSE3 per node)
+        if ((v && v[0] == 'l') || A.tsched.max_se3_per_node > 1) {   // (tree_wave_kernel: one EdgeSE3 per node)
+            w->last_kind = LOC_WINDOW_KERNEL_TREE_LANE;
+            return locamd::launch_window_tree(a, A.tsched, w->d_tree_ws, st);
+        }
         return locamd::launch_window_tree_wave(a, A.tsched, st);
     }
     if (kind == LOC_WINDOW_KERNEL_CHAIN3) {

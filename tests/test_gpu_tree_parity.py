@@ -80,7 +80,7 @@ def test_tree_kernel_matches_oracle_and_general_kernel(gpu, T, every, rich, jac)
     s = la.WindowSolver(ANCH, B, *wb.caps, jacobian=jac, bw_max=T - 1, chain_threshold=1)
     res = s.solve(wb).copy()
     kind = s.last_kernel_kind()
-    assert kind in ("tree_lm_kernel", "chain_lm_kernel") and (kind == "tree_lm_kernel" or every == 1)
+    assert kind in ("tree_wave_kernel", "chain_lm_kernel") and (kind == "tree_wave_kernel" or every == 1)
     tol = 1e-7 if jac == "analytic" else 1e-5
     n_same_it = 0
     for i in range(n_or):
@@ -161,7 +161,7 @@ def test_tree_kernel_needs_one_shared_forest_topology(gpu):
         s.solve(wb)
         return s.last_kernel_kind()
 
-    assert kind(lambda wb: None) == "tree_lm_kernel"
+    assert kind(lambda wb: None) == "tree_wave_kernel"
     def other_anchor(wb): wb.r_idx[17, 3, 1] = -1 - 2                        # one window ranges another anchor: not ONE topology
     def shorter(wb): wb.counts[5] = (T - 1, T - 1, 0, T - 2)                  # one window is shorter
     def cycle(wb):                                                            # every window gets a loop closure: not a forest
