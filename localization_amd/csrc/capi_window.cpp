@@ -627,6 +627,13 @@ static int pick_kernel(const loc_window* w, int64_t n, int topology) {
     if (w->has_off1) return LOC_WINDOW_KERNEL_GENERAL;   // (lever arms on endpoint 1: only the general kernel evaluates them)
     if (topology == LOC_WINDOW_KERNEL_ARROW3) return w->natural_order ? LOC_WINDOW_KERNEL_GENERAL : LOC_WINDOW_KERNEL_ARROW3;   // (one wave per window: any batch size)
     if (topology == LOC_WINDOW_KERNEL_TREE) return (w->natural_order || n < tree_min_batch(w)) ? LOC_WINDOW_KERNEL_GENERAL : LOC_WINDOW_KERNEL_TREE;
+    if (topology == LOC_WINDOW_KERNEL_CHAIN3 && mn > 0 && !w->natural_order && w->caps.nv_max <= 64 && locamd::window_wave3_lds_bytes(w->caps) <= 64 * 1024) {
+        // translation-only chains below the lane-per-window batch sizes (the node's single window first of all): one wave per window
+        // with 3x3 blocks (LOCAMD_WAVE3=0: the general kernel, for A/B runs)
+        const bool default_rule = w->chain_min < 0 && !getenv("LOCAMD_CHAIN_MIN_BATCH");
+        const char* v = getenv("LOCAMD_WAVE3");
+        if (n < (default_rule && mn > 4096 ? 4096 : mn) && !(v && v[0] == '0')) return LOC_WINDOW_KERNEL_WAVE3;
+    }
     if (topology == LOC_WINDOW_KERNEL_CHAIN3 && mn > 0 && !w->natural_order && w->chain_min < 0 && !getenv("LOCAMD_CHAIN_MIN_BATCH") && n >= 4096 && n < mn) {
         // the translation-only kernel is worth it from ~4 096 windows on (it takes ~1 ms for any batch up to 16 384, the wave-per-window
         // kernel 4.3e6 windows/s): e.g. one GPU's 8 192-window share of a 65 536-window job split over eight
@@ -664,6 +671,7 @@ static hipError_t launch_any(loc_window* w, int which, const locamd::WindowArgs&
         }
         return locamd::launch_window_chain3(a, w->d_chain3_ws, st);
     }
+    if (kind == LOC_WINDOW_KERNEL_WAVE3) return locamd::launch_window_wave3(a, st);
     if (kind == LOC_WINDOW_KERNEL_GENERAL) return locamd::launch_window(a, st);
     if (!w->d_chain_ws) {
         hipError_t e = hipMalloc((void**)&w->d_chain_ws, locamd::window_chain_workspace_doubles(w->caps, w->B) * sizeof(double));

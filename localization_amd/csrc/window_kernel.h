@@ -57,6 +57,10 @@ size_t window_chain3_workspace_doubles(const WindowCaps& c, long long B);
 int window_chain3_lds_mode(const WindowCaps& c, long long B, int n_cus);   // bit 0: (G, y) in LDS, bit 1: the translations in LDS
 hipError_t launch_window_chain3(const WindowArgs& a, double* ws, hipStream_t stream);
 
+// translation-only chain windows of <= 64 poses, one wave per window (wave3_kernel.hip): the node's own solve, small batches
+size_t window_wave3_lds_bytes(const WindowCaps& c);
+hipError_t launch_window_wave3(const WindowArgs& a, hipStream_t stream);
+
 // translation-only chain + dense border windows (arrow3_kernel.hip): four waves per window.  The host cuts the chain into up to
 // four segments at separator poses (which join the border), orders the rows (chain rows by segment, then border rows) and packs
 // every row's edges and priors as records [chunk of 64 rows][slot][lane] once per upload (capi_window.cpp: build_arrow_aux).

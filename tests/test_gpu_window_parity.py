@@ -173,7 +173,7 @@ def test_elimination_order_is_transparent(gpu):
     assert (blocks == 64 + 63).all() and (lev == 6).all(), (lev, blocks)
     assert (out[True][1][:, 7] % 65536 > 300).all()          # the caller's (time) order fills the 8-pose band
     wb2, _, anch2, T2 = bw.build(4, "uwb_only")
-    s2 = la.WindowSolver(anch2, 4, *wb2.caps, maximum_iteration=10, bw_max=1, jacobian="analytic")
+    s2 = la.WindowSolver(anch2, 4, *wb2.caps, maximum_iteration=10, bw_max=1, jacobian="analytic", chain_threshold=0)   # (the general kernel: small translation-only chains take wave3_lm_kernel otherwise)
     r2 = s2.solve(wb2)
     s2.close()
     assert (r2[:, 7] % 65536 == 19).all() and (r2[:, 7] // 65536 == 6).all(), r2[:, 7]
