@@ -628,11 +628,15 @@ static int pick_kernel(const loc_window* w, int64_t n, int topology) {
     if (topology == LOC_WINDOW_KERNEL_ARROW3) return w->natural_order ? LOC_WINDOW_KERNEL_GENERAL : LOC_WINDOW_KERNEL_ARROW3;   // (one wave per window: any batch size)
     if (topology == LOC_WINDOW_KERNEL_TREE) return (w->natural_order || n < tree_min_batch(w)) ? LOC_WINDOW_KERNEL_GENERAL : LOC_WINDOW_KERNEL_TREE;
     if (topology == LOC_WINDOW_KERNEL_CHAIN3 && mn > 0 && !w->natural_order && w->caps.nv_max <= 64 && locamd::window_wave3_lds_bytes(w->caps) <= 64 * 1024) {
-        // translation-only chains below the lane-per-window batch sizes (the node's single window first of all): one wave per window
-        // with 3x3 blocks (LOCAMD_WAVE3=0: the general kernel, for A/B runs)
+        // translation-only chains of <= 64 poses below the lane-per-window batch sizes (the node's single window first of all): one
+        // wave per window with 3x3 blocks.  Measured on ten-pose windows: 1.9e7 windows/s from ~4 096 windows on, against chain3's
+        // ~1.1 ms for any batch up to 16 384 — the lane-per-window kernel takes over at ~20 000 windows (an explicit threshold moves
+        // that point).  LOCAMD_WAVE3=0 / LOCAMD_CHAIN3=0: no such kernel (A/B runs, tests).
         const bool default_rule = w->chain_min < 0 && !getenv("LOCAMD_CHAIN_MIN_BATCH");
         const char* v = getenv("LOCAMD_WAVE3");
-        if (n < (default_rule && mn > 4096 ? 4096 : mn) && !(v && v[0] == '0')) return LOC_WINDOW_KERNEL_WAVE3;
+        const char* v3 = getenv("LOCAMD_CHAIN3");
+        if (n < (default_rule ? 20480 : mn) && !(v && v[0] == '0') && !(v3 && v3[0] == '0')) return LOC_WINDOW_KERNEL_WAVE3;
+        if (default_rule && n >= 20480 && !(v3 && v3[0] == '0')) return LOC_WINDOW_KERNEL_CHAIN3;
     }
     if (topology == LOC_WINDOW_KERNEL_CHAIN3 && mn > 0 && !w->natural_order && w->chain_min < 0 && !getenv("LOCAMD_CHAIN_MIN_BATCH") && n >= 4096 && n < mn) {
         // the translation-only kernel is worth it from ~4 096 windows on (it takes ~1 ms for any batch up to 16 384, the wave-per-window
@@ -749,7 +753,13 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
             if (c.nr_max) { std::memcpy(h + off[3], r_val, N * c.nr_max * 5 * sizeof(double)); std::memcpy(h + off[6], r_idx, N * c.nr_max * 2 * sizeof(int32_t)); }
             if (c.np_max) { std::memcpy(h + off[4], p_val, N * c.np_max * 18 * sizeof(double)); std::memcpy(h + off[7], p_idx, N * c.np_max * sizeof(int32_t)); }
             if (c.ns_max) { std::memcpy(h + off[5], s_val, N * c.ns_max * 48 * sizeof(double)); std::memcpy(h + off[8], s_idx, N * c.ns_max * 4 * sizeof(int32_t)); }
-            LOC_HIP(hipMemcpyAsync(d, h, off[9], hipMemcpyHostToDevice, st));
+            const int kind = pick_kernel(w, n, batch_topology(w, 0, n, counts, poses, r_idx, r_val, p_idx, p_val, s_idx));
+            // A handful of small windows on wave3_lm_kernel (the node's own solve): the kernel reads its few KB of input once and
+            // writes 1 KB of results — it does so straight from / to the page-locked staging block (host-coherent memory, mapped
+            // into the device's address space), which saves the two DMA operations around a ~75 us kernel.
+            const bool zero_copy = kind == LOC_WINDOW_KERNEL_WAVE3 && n <= 4 && !getenv("LOCAMD_NO_ZERO_COPY");
+            if (zero_copy) d = h;
+            else LOC_HIP(hipMemcpyAsync(d, h, off[9], hipMemcpyHostToDevice, st));
             locamd::WindowArgs a;
             a.poses = (double*)(d + off[0]); a.poses_in = a.poses; a.jacobian = w->jacobian; a.natural_order = w->natural_order; a.result = (double*)(d + off[1]); a.counts = (const int32_t*)(d + off[2]);
             a.r_val = (const double*)(d + off[3]); a.p_val = (const double*)(d + off[4]); a.s_val = (const double*)(d + off[5]);
@@ -758,13 +768,12 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
             a.anchors = w->d_anchors; a.workspace = w->d_workspace;
             a.n_anchors = w->n_anchors; a.B = (int)n; a.iterations = w->iterations; a.caps = c;
             LOC_HIP(hipEventRecord(w->ev0, st));
-            const int kind = pick_kernel(w, n, batch_topology(w, 0, n, counts, poses, r_idx, r_val, p_idx, p_val, s_idx));
             if (kind == LOC_WINDOW_KERNEL_ARROW3) LOC_HIP(upload_arrow_aux(w, 0, n, st));
             if (kind == LOC_WINDOW_KERNEL_TREE) LOC_HIP(upload_tree_sched(w, 0, st));
             hipError_t e = launch_any(w, 0, a, st, kind);
             if (e != hipSuccess) return locamd_fail_hip(e, "launch_window");
             LOC_HIP(hipEventRecord(w->ev1, st));
-            LOC_HIP(hipMemcpyAsync(h, d, off[2], hipMemcpyDeviceToHost, st));  // [poses | result]
+            if (!zero_copy) LOC_HIP(hipMemcpyAsync(h, d, off[2], hipMemcpyDeviceToHost, st));  // [poses | result]
             LOC_HIP(hipStreamSynchronize(st));
             std::memcpy(poses, h + off[0], N * c.nv_max * 12 * sizeof(double));
             std::memcpy(result, h + off[1], N * 8 * sizeof(double));

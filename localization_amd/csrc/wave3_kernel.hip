@@ -32,10 +32,19 @@ namespace {
 
 extern __shared__ double w3lds[];
 
+// -DLOCAMD_WAVE3_TIMING: cycle stamps per phase, reported INSTEAD of result[0 .. 7] (tools/dev/probe_wave3.py; never benchmarked)
+#ifdef LOCAMD_WAVE3_TIMING
+#define W3_T0() unsigned long long w3_tc = __builtin_readcyclecounter(), w3_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long w3_start = w3_tc
+#define W3_T(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); w3_ph[k] += n_ - w3_tc; w3_tc = n_; } while (0)
+#else
+#define W3_T0() do {} while (0)
+#define W3_T(k) do {} while (0)
+#endif
+
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double w3_dpp(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, CTRL == 0x138 || CTRL == 0x130);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, CTRL == 0x138 || CTRL == 0x130);
     return __hiloint2double(hi, lo);
 }
 // value of lane l (wave-uniform l) in every lane — through SGPRs
@@ -43,6 +52,9 @@ __device__ __forceinline__ double w3_bcast(double v, int l) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
     return __hiloint2double(hi, lo);
 }
+// the value of lane - 1 / lane + 1 (wave_shr:1 / wave_shl:1 cross the 16-lane rows on gfx9; no neighbour: 0)
+__device__ __forceinline__ double w3_from_prev(double v) { return w3_dpp<0x138, 0xF>(v); }
+__device__ __forceinline__ double w3_from_next(double v) { return w3_dpp<0x130, 0xF>(v); }
 __device__ __forceinline__ double w3_sum(double v) {   // DPP row shifts + row broadcasts: one fixed order, every lane gets the same bits
     v += w3_dpp<0x111, 0xF>(v);
     v += w3_dpp<0x112, 0xF>(v);
@@ -98,79 +110,107 @@ __device__ __forceinline__ double w3_jac_numeric(const double* p0, const double*
 
 // LDS of one window (doubles first, then ints)
 struct W3Lds {
-    double* T;      // [2][nv_max][3] translations: state / trial state
-    double* rec;    // [nr_max][8]    w, -w e, J0 (3), J1 (3) of the last linearisation
+    double* T;      // [5][nv_max][3] translations: the state and up to four trial states
+    double* rec;    // [2 nr_max][8]  the last linearisation, one record per (edge, moving endpoint), grouped by pose: w, -w e, the
+                    //                pose's own J (3), the other endpoint's J (3) when that is the previous pose (else 0)
     double* ev;     // [nr_max][2]    measurement, information
     double* fix;    // [nr_max][3]    the fixed endpoint of an anchor edge
     double* pv;     // [np_max][6]    priors: Z^-1 t (3), information diagonal (3)
     int* eidx;      // [nr_max][2]
+    int* epos;      // [nr_max][2]    where the edge's two records go (endpoint 1 of an anchor edge: -1)
     int* pidx;      // [np_max]
-    int* list;      // [2 nr_max]     the poses' incident edges, pose by pose (each pose keeps its range in registers):
-                    //                (edge << 2) | (other endpoint is the previous pose) << 1 | (this pose is endpoint 1)
 };
 __device__ __forceinline__ W3Lds w3_carve(const WindowCaps& c) {
     W3Lds l;
     double* p = w3lds;
-    l.T = p; p += 2 * c.nv_max * 3;
-    l.rec = p; p += (size_t)c.nr_max * 8;
+    l.T = p; p += 5 * c.nv_max * 3;
+    l.rec = p; p += (size_t)c.nr_max * 16;
     l.ev = p; p += (size_t)c.nr_max * 2;
     l.fix = p; p += (size_t)c.nr_max * 3;
     l.pv = p; p += (size_t)c.np_max * 6;
     int* q = reinterpret_cast<int*>(p);
     l.eidx = q; q += (size_t)c.nr_max * 2;
-    l.pidx = q; q += c.np_max;
-    l.list = q;
+    l.epos = q; q += (size_t)c.nr_max * 2;
+    l.pidx = q;
     return l;
+}
+
+// one range edge as its lane holds it (the first 64 edges of a window stay in registers for the whole solve)
+struct W3Edge {
+    int v0, v1, s0, s1;
+    double meas, info, fx, fy, fz;
+};
+__device__ __forceinline__ W3Edge w3_load_edge(const W3Lds& l, int e) {
+    W3Edge E;
+    E.v0 = l.eidx[2 * e]; E.v1 = l.eidx[2 * e + 1];
+    E.s0 = l.epos[2 * e]; E.s1 = l.epos[2 * e + 1];
+    E.meas = l.ev[2 * e]; E.info = l.ev[2 * e + 1];
+    E.fx = l.fix[3 * e]; E.fy = l.fix[3 * e + 1]; E.fz = l.fix[3 * e + 2];
+    return E;
+}
+
+// one edge at the translations T: its robust / plain chi2; FULL: its linearisation records as well
+template <bool FULL, int JAC>
+__device__ __forceinline__ void w3_edge(const W3Lds& l, const double* T, const W3Edge& E, double& rsum, double& csum) {
+    const int v0 = E.v0, v1 = E.v1;
+    const double meas = E.meas, info = E.info;
+    const double* s0 = T + v0 * 3;
+    const double* s1 = T + (v1 >= 0 ? v1 : 0) * 3;
+    const double p0[3] = {s0[0], s0[1], s0[2]};
+    const double m1[3] = {s1[0], s1[1], s1[2]};
+    const double p1[3] = {v1 >= 0 ? m1[0] : E.fx, v1 >= 0 ? m1[1] : E.fy, v1 >= 0 ? m1[2] : E.fz};
+    double u[3] = {p0[0] - p1[0], p0[1] - p1[1], p0[2] - p1[2]};
+    double err, inv = 0.0;
+    if (JAC == 0) {
+        const double x = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
+        double n;
+        sqrt_and_rsqrt(x, n, inv);
+        if (!(x > 0.0)) { n = 0.0; inv = 0.0; }   // coincident endpoints: J = 0, what the central difference gives
+        err = meas - n;
+    } else {
+        err = meas - w3_norm_plain(u[0], u[1], u[2]);
+    }
+    const double chi = err * (info * err);
+    const double aux = 1.0 + chi;
+    rsum += fast_log_ge1(aux);
+    csum += chi;
+    if (FULL) {
+        double J0[3], J1[3];
+        if (JAC == 0) {
+            u[0] *= inv; u[1] *= inv; u[2] *= inv;
+            J0[0] = -u[0]; J0[1] = -u[1]; J0[2] = -u[2];
+            J1[0] = u[0]; J1[1] = u[1]; J1[2] = u[2];
+        } else {
+            J0[0] = w3_jac_numeric<0>(p0, p1, 0, meas);
+            J0[1] = w3_jac_numeric<1>(p0, p1, 0, meas);
+            J0[2] = w3_jac_numeric<2>(p0, p1, 0, meas);
+            J1[0] = w3_jac_numeric<0>(p0, p1, 1, meas);
+            J1[1] = w3_jac_numeric<1>(p0, p1, 1, meas);
+            J1[2] = w3_jac_numeric<2>(p0, p1, 1, meas);
+        }
+        const double wr = info * fast_rcp(aux), wre = -wr * err;
+        const bool c0 = v1 >= 0 && v1 == v0 - 1, c1 = v0 == v1 - 1;   // the endpoint that is the later pose of a consecutive pair keeps the coupling block
+        double* r = l.rec + (size_t)E.s0 * 8;
+        r[0] = wr; r[1] = wre;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { r[2 + k] = J0[k]; r[5 + k] = c0 ? J1[k] : 0.0; }
+        if (v1 >= 0) {
+            double* r1 = l.rec + (size_t)E.s1 * 8;
+            r1[0] = wr; r1[1] = wre;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { r1[2 + k] = J1[k]; r1[5 + k] = c1 ? J0[k] : 0.0; }
+        }
+    }
 }
 
 // every edge and prior of the window at the translations of buffer `buf`: the robust and plain chi2 sums; FULL: the edges'
 // linearisation records as well
 template <bool FULL, int JAC>
-__device__ __forceinline__ void w3_edges(const W3Lds& l, int nvm, int nr, int np, int buf, int lane, double& robust_chi, double& plain_chi) {
+__device__ __forceinline__ void w3_edges(const W3Lds& l, const W3Edge& E0, int nvm, int nr, int np, int buf, int lane, double& robust_chi, double& plain_chi) {
     double rsum = 0.0, csum = 0.0;
     const double* T = l.T + (size_t)buf * nvm * 3;
-    for (int e = lane; e < nr; e += 64) {
-        const int v0 = l.eidx[2 * e], v1 = l.eidx[2 * e + 1];
-        const double meas = l.ev[2 * e], info = l.ev[2 * e + 1];
-        const double* s0 = T + v0 * 3;
-        const double* s1 = v1 >= 0 ? T + v1 * 3 : l.fix + (size_t)e * 3;
-        const double p0[3] = {s0[0], s0[1], s0[2]}, p1[3] = {s1[0], s1[1], s1[2]};
-        double u[3] = {p0[0] - p1[0], p0[1] - p1[1], p0[2] - p1[2]};
-        double err, inv = 0.0;
-        if (JAC == 0) {
-            const double x = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
-            double n;
-            sqrt_and_rsqrt(x, n, inv);
-            if (!(x > 0.0)) { n = 0.0; inv = 0.0; }   // coincident endpoints: J = 0, what the central difference gives
-            err = meas - n;
-        } else {
-            err = meas - w3_norm_plain(u[0], u[1], u[2]);
-        }
-        const double chi = err * (info * err);
-        const double aux = 1.0 + chi;
-        rsum += fast_log_ge1(aux);
-        csum += chi;
-        if (FULL) {
-            double J0[3], J1[3];
-            if (JAC == 0) {
-                u[0] *= inv; u[1] *= inv; u[2] *= inv;
-                J0[0] = -u[0]; J0[1] = -u[1]; J0[2] = -u[2];
-                J1[0] = u[0]; J1[1] = u[1]; J1[2] = u[2];
-            } else {
-                J0[0] = w3_jac_numeric<0>(p0, p1, 0, meas);
-                J0[1] = w3_jac_numeric<1>(p0, p1, 0, meas);
-                J0[2] = w3_jac_numeric<2>(p0, p1, 0, meas);
-                J1[0] = w3_jac_numeric<0>(p0, p1, 1, meas);
-                J1[1] = w3_jac_numeric<1>(p0, p1, 1, meas);
-                J1[2] = w3_jac_numeric<2>(p0, p1, 1, meas);
-            }
-            const double wr = info * fast_rcp(aux), wre = -wr * err;
-            double* r = l.rec + (size_t)e * 8;
-            r[0] = wr; r[1] = wre;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { r[2 + k] = J0[k]; r[5 + k] = v1 >= 0 ? J1[k] : 0.0; }
-        }
-    }
+    if (lane < nr) w3_edge<FULL, JAC>(l, T, E0, rsum, csum);
+    for (int e = lane + 64; e < nr; e += 64) w3_edge<FULL, JAC>(l, T, w3_load_edge(l, e), rsum, csum);
     // unary priors: e = t + Z^-1.t (identity rotations), diagonal information on the translation, no robust kernel
     for (int q = lane; q < np; q += 64) {
         const double* s = T + l.pidx[q] * 3;
@@ -192,30 +232,50 @@ __global__ void __launch_bounds__(64) wave3_lm_kernel(const WindowArgs a) {
     const WindowCaps& cp = a.caps;
     const W3Lds l = w3_carve(cp);
     const int nvm = cp.nv_max;
-    const int nv = a.counts[inst * 4 + 0], nr = a.counts[inst * 4 + 1], np = a.counts[inst * 4 + 2];
     const double* gin = a.poses_in + (size_t)inst * nvm * 12;
     double* gout = a.poses + (size_t)inst * nvm * 12;
+    const int32_t* ridx = a.r_idx + (size_t)inst * cp.nr_max * 2;
+    const double* rval = a.r_val + (size_t)inst * cp.nr_max * 5;
+    // the first 64 poses and edges are requested before the counts have arrived (inside the instance's slices whatever the counts
+    // say): the node's window comes straight from page-locked host memory, a round trip of microseconds per dependent level
+    double pin[12];
+    int pv0 = 0, pv1 = 0;
+    double pmeas = 0.0, pinfo = 0.0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) pin[k] = 0.0;
+    if (lane < nvm) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) pin[k] = gin[lane * 12 + k];
+    }
+    if (lane < cp.nr_max) { pv0 = ridx[2 * lane]; pv1 = ridx[2 * lane + 1]; pmeas = rval[5 * lane]; pinfo = rval[5 * lane + 1]; }
+    const int nv = a.counts[inst * 4 + 0], nr = a.counts[inst * 4 + 1], np = a.counts[inst * 4 + 2];
+    // speculation: G groups of W lanes solve the SAME normal equations with the lambdas of this and the next G - 1 trials (what LM
+    // would try next if it rejects); a group keeps one idle lane after its last pose (the hand-over between lanes reads zeros there)
+    const int W = nv <= 15 ? 16 : (nv <= 31 ? 32 : 64);
+    const int G = 64 / W;
+    const int grp = lane / W, pp = lane & (W - 1);
+    const bool pose = pp < nv;
+    const unsigned long long group_mask = W == 64 ? ~0ull : ((1ull << W) - 1ull);
+    W3_T0();
     // ---- set-up: translations, edges (with their fixed endpoints), priors into LDS; the poses' incidence lists ---------------
     double rot[9];   // this lane's pose keeps its rotation (it never moves)
 #pragma unroll
     for (int k = 0; k < 9; ++k) rot[k] = 0.0;
     if (lane < nv) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) rot[k] = gin[lane * 12 + k];
+        for (int k = 0; k < 9; ++k) rot[k] = pin[k];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) l.T[lane * 3 + k] = gin[lane * 12 + 9 + k];
+        for (int k = 0; k < 3; ++k) l.T[lane * 3 + k] = pin[9 + k];
     }
     {
-        const int32_t* ridx = a.r_idx + (size_t)inst * cp.nr_max * 2;
-        const double* rval = a.r_val + (size_t)inst * cp.nr_max * 5;
         for (int e = lane; e < nr; e += 64) {
-            const int v0 = ridx[2 * e], v1 = ridx[2 * e + 1];
+            const bool first = e == lane;
+            const int v0 = first ? pv0 : ridx[2 * e], v1 = first ? pv1 : ridx[2 * e + 1];
             l.eidx[2 * e] = v0; l.eidx[2 * e + 1] = v1;
-            l.ev[2 * e] = rval[5 * e]; l.ev[2 * e + 1] = rval[5 * e + 1];
-            if (v1 < 0) {
-                const double* an = a.anchors + (size_t)(-1 - v1) * 3;
-                l.fix[3 * e] = an[0]; l.fix[3 * e + 1] = an[1]; l.fix[3 * e + 2] = an[2];
-            }
+            l.ev[2 * e] = first ? pmeas : rval[5 * e]; l.ev[2 * e + 1] = first ? pinfo : rval[5 * e + 1];
+            l.epos[2 * e + 1] = -1;
+            const double* an = a.anchors + (size_t)(v1 < 0 ? -1 - v1 : 0) * 3;
+            l.fix[3 * e] = an[0]; l.fix[3 * e + 1] = an[1]; l.fix[3 * e + 2] = an[2];
         }
         const int32_t* pidx = a.p_idx + (size_t)inst * cp.np_max;
         const double* pval = a.p_val + (size_t)inst * cp.np_max * 18;
@@ -226,13 +286,14 @@ __global__ void __launch_bounds__(64) wave3_lm_kernel(const WindowArgs a) {
         }
     }
     w3_sync();
-    int deg = 0, nbin = 0;
+    int deg = 0, nbin = 0;   // (lanes 0 .. nv-1: pose = lane)
     for (int e = 0; e < nr; ++e) {
         const int v0 = l.eidx[2 * e], v1 = l.eidx[2 * e + 1];
         deg += (v0 == lane) + (v1 == lane);
         nbin += (v1 >= 0 && (v0 > v1 ? v0 : v1) == lane);
     }
     int lst = 0;   // first entry of this pose's list: exclusive prefix sum of deg over the lanes
+    int kc = -1;   // the record of the (last) edge to the previous pose
     {
         int incl = deg;
 #pragma unroll
@@ -241,26 +302,36 @@ __global__ void __launch_bounds__(64) wave3_lm_kernel(const WindowArgs a) {
             if (lane >= d) incl += o;
         }
         lst = incl - deg;
-    }
-    {
         int k = lst;
         for (int e = 0; e < nr; ++e) {
             const int v0 = l.eidx[2 * e], v1 = l.eidx[2 * e + 1];
-            if (v0 == lane) l.list[k++] = (e << 2) | ((v1 == lane - 1 && v1 >= 0) ? 2 : 0);
-            if (v1 == lane) l.list[k++] = (e << 2) | (v0 == lane - 1 ? 2 : 0) | 1;
+            if (v0 == lane) { if (v1 >= 0 && v1 == lane - 1) kc = k; l.epos[2 * e] = k++; }
+            if (v1 == lane) { if (v0 == lane - 1) kc = k; l.epos[2 * e + 1] = k++; }
         }
     }
     const int shared_edges = (int)w3_sum(lane < nv && nbin >= 2 ? (double)nbin : 0.0);
+    // no pair of consecutive poses with more than one edge (the reference's own window: one smoothness edge per pair): every
+    // coupling block is a rank-1 product (w J_p) J_{p-1}^T, and the sweeps below hand two numbers from pose to pose instead of nine
+    const bool rank1 = __ballot(lane < nv && nbin >= 2) == 0ull;
+    deg = __shfl(deg, pp, 64);   // every group's lane of pose pp
+    lst = __shfl(lst, pp, 64);
+    kc = __shfl(kc, pp, 64);
     w3_sync();
+    W3Edge E0;
+    E0.v0 = 0; E0.v1 = -1; E0.s0 = 0; E0.s1 = -1; E0.meas = 0.0; E0.info = 0.0; E0.fx = 0.0; E0.fy = 0.0; E0.fz = 0.0;
+    if (lane < nr) E0 = w3_load_edge(l, lane);
+    W3_T(0);
 
     // ---- Levenberg-Marquardt (g2o: OptimizationAlgorithmLevenberg::solve), wave-uniform control flow ---------------
     constexpr double tau = 1e-5, good_lo = 1.0 / 3.0, good_hi = 2.0 / 3.0;
     constexpr int max_trials = 10;
+    constexpr int NSLOT = 5;   // translation buffers in LDS: the state + up to four trial states
     double lambda = 0.0, ni = 2.0, cur_chi = 0.0, last_plain = 0.0;
-    int it = 0, q = 0, trials = 0, terminated = 0, buf = 0;
+    int it = 0, q = 0, trials = 0, terminated = 0, cur = 0, jlast = 0;
     bool need_lin = true;
     bool done = nv <= 0 || nr + np <= 0 || a.iterations <= 0;
-    double D[6], b[3], O[9], X[3] = {0.0, 0.0, 0.0};   // this pose's H_pp, b_p, H_p,p-1 (entry (r, c) at 3 c + r), x_p
+    double D[6], b[3], O[9], X[3] = {0.0, 0.0, 0.0};   // this pose's H_pp, b_p, H_p,p-1 (entry (r, c) at 3 c + r); x_p of this group's last solve
+    double u[3] = {0.0, 0.0, 0.0}, UU[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, vnext[3] = {0.0, 0.0, 0.0};   // rank1: H_p,p-1 = u v^T; u u^T; the v of pose p + 1's block (this pose's own J)
 #pragma unroll
     for (int k = 0; k < 6; ++k) D[k] = 0.0;
 #pragma unroll
@@ -270,132 +341,215 @@ __global__ void __launch_bounds__(64) wave3_lm_kernel(const WindowArgs a) {
     while (!done) {
         if (need_lin) {
             double plain;
-            w3_edges<true, JAC>(l, nvm, nr, np, buf, lane, cur_chi, plain);
+            w3_edges<true, JAC>(l, E0, nvm, nr, np, cur, lane, cur_chi, plain);
             last_plain = plain;
             w3_sync();
-            // pose p: its edges' blocks in creation order
+            W3_T(1);
+            // pose pp: its edges' blocks in creation order (every group's lane of the pose holds the same numbers)
 #pragma unroll
             for (int k = 0; k < 6; ++k) D[k] = 0.0;
 #pragma unroll
             for (int k = 0; k < 3; ++k) b[k] = 0.0;
 #pragma unroll
             for (int k = 0; k < 9; ++k) O[k] = 0.0;
-            if (lane < nv) {
+            double uu_[3] = {0.0, 0.0, 0.0}, vv_[3] = {0.0, 0.0, 0.0};
+            if (pose) {
                 const int k1 = lst + deg;
                 for (int k = lst; k < k1; ++k) {
-                    const int code = l.list[k];
-                    const double* r = l.rec + (size_t)(code >> 2) * 8;
-                    const bool second = code & 1;
+                    const double* r = l.rec + (size_t)k * 8;
                     const double wr = r[0], wre = r[1];
-                    double Jm[3], Jo[3];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) { const double j0 = r[2 + c], j1 = r[5 + c]; Jm[c] = second ? j1 : j0; Jo[c] = second ? j0 : j1; }
+                    const double Jm[3] = {r[2], r[3], r[4]}, Jo[3] = {r[5], r[6], r[7]};
                     const double wj[3] = {wr * Jm[0], wr * Jm[1], wr * Jm[2]};
 #pragma unroll
                     for (int rr = 0; rr < 3; ++rr) {
 #pragma unroll
                         for (int cc = 0; cc <= rr; ++cc) D[rr * (rr + 1) / 2 + cc] = __builtin_fma(wj[rr], Jm[cc], D[rr * (rr + 1) / 2 + cc]);
                         b[rr] = __builtin_fma(Jm[rr], wre, b[rr]);
+#pragma unroll
+                        for (int cc = 0; cc < 3; ++cc) O[3 * cc + rr] = __builtin_fma(wj[rr], Jo[cc], O[3 * cc + rr]);
                     }
-                    if (code & 2) {
+                    if (k == kc) {
 #pragma unroll
-                        for (int rr = 0; rr < 3; ++rr)
-#pragma unroll
-                            for (int cc = 0; cc < 3; ++cc) O[3 * cc + rr] = __builtin_fma(wj[rr], Jo[cc], O[3 * cc + rr]);
+                        for (int rr = 0; rr < 3; ++rr) { uu_[rr] = wj[rr]; vv_[rr] = Jo[rr]; }
                     }
                 }
                 for (int pq = 0; pq < np; ++pq) {
-                    if (l.pidx[pq] != lane) continue;
+                    if (l.pidx[pq] != pp) continue;
                     const double* v = l.pv + (size_t)pq * 6;
-                    const double* s = l.T + ((size_t)buf * nvm + lane) * 3;
+                    const double* s = l.T + ((size_t)cur * nvm + pp) * 3;
 #pragma unroll
                     for (int k = 0; k < 3; ++k) { const double er = s[k] + v[k]; D[k * (k + 1) / 2 + k] += v[3 + k]; b[k] += -v[3 + k] * er; }
                 }
             }
+            if (rank1) {
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr) {
+                    u[rr] = uu_[rr];
+                    vnext[rr] = w3_from_next(vv_[rr]);
+#pragma unroll
+                    for (int cc = 0; cc <= rr; ++cc) UU[rr * (rr + 1) / 2 + cc] = uu_[rr] * uu_[cc];
+                }
+            }
             if (it == 0) {
                 const double md = fmax(fmax(fabs(D[0]), fabs(D[2])), fabs(D[5]));
-                lambda = tau * w3_max(lane < nv ? md : 0.0);
+                lambda = tau * w3_max(pose ? md : 0.0);
                 ni = 2.0;
             }
             q = 0;
             need_lin = false;
+            W3_T(2);
         }
-        // ---- (H + lambda I) x = b: forward sweep, pose p on lane p, its factor handed on through SGPRs ---------------------------
+        // ---- one round: (H + lambda_g I) x = b for the lambdas of the next G trials --------------------------------------------------
+        double lamv[4], niv[4];
+        lamv[0] = lambda; niv[0] = ni;
+#pragma unroll
+        for (int g = 1; g < 4; ++g) { lamv[g] = lamv[g - 1] * niv[g - 1]; niv[g] = 2.0 * niv[g - 1]; }   // (a rejected trial: lambda *= ni, ni *= 2)
+        const double mylam = grp == 0 ? lamv[0] : (grp == 1 ? lamv[1] : (grp == 2 ? lamv[2] : lamv[3]));
+        // forward sweep.  Step p needs pose p-1's factor: every lane takes its left neighbour's (G, y) through DPP and redoes its own
+        // 3x3 step each repetition — after repetition r the lanes of poses 0 .. r hold their final values (a lane whose inputs are
+        // final recomputes the same numbers), so nv repetitions factor the chain; all G groups ride in the same instructions.
         double g10 = 0.0, g20 = 0.0, g21 = 0.0, ig[3] = {0.0, 0.0, 0.0}, y[3] = {0.0, 0.0, 0.0};   // this pose's factor (strict lower part, inverse pivots), y
-        double pg10 = 0.0, pg20 = 0.0, pg21 = 0.0, pig[3] = {0.0, 0.0, 0.0}, py[3] = {0.0, 0.0, 0.0};   // the previous pose's, wave-uniform
-        bool ok = true;
-        for (int p = 0; p < nv; ++p) {
-            if (lane == p) {
-                double A[3][3], rhs[3];
+        if (rank1) {
+            // H_p,p-1 = u v^T: W W^T = (z.z) u u^T and W y_{p-1} = (z.y_{p-1}) u with z = G_{p-1}^-1 v, which pose p - 1 computes itself
+            double al = 0.0, be = 0.0;
+            for (int r = 0; r < nv; ++r) {
+                const double pal = w3_from_prev(al), pbe = w3_from_prev(be);
+                if (pose) {
+                    double A[3][3], rhs[3];
 #pragma unroll
-                for (int r = 0; r < 3; ++r) {
+                    for (int rr = 0; rr < 3; ++rr) {
 #pragma unroll
-                    for (int c = 0; c <= r; ++c) A[r][c] = D[r * (r + 1) / 2 + c];
-                    A[r][r] += lambda;
-                    rhs[r] = b[r];
+                        for (int c = 0; c <= rr; ++c) A[rr][c] = __builtin_fma(-pal, UU[rr * (rr + 1) / 2 + c], D[rr * (rr + 1) / 2 + c]);
+                        A[rr][rr] += mylam;
+                        rhs[rr] = __builtin_fma(-pbe, u[rr], b[rr]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const double g = w3_pivot_rsqrt(A[j][j]);
+                        ig[j] = g;
+#pragma unroll
+                        for (int i2 = j + 1; i2 < 3; ++i2) A[i2][j] *= g;
+#pragma unroll
+                        for (int i2 = j + 1; i2 < 3; ++i2)
+#pragma unroll
+                            for (int cc = j + 1; cc <= i2; ++cc) A[i2][cc] = __builtin_fma(-A[i2][j], A[cc][j], A[i2][cc]);
+                    }
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) {
+                        rhs[cc] *= ig[cc];
+#pragma unroll
+                        for (int c2 = cc + 1; c2 < 3; ++c2) rhs[c2] = __builtin_fma(-rhs[cc], A[c2][cc], rhs[c2]);
+                    }
+                    g10 = A[1][0]; g20 = A[2][0]; g21 = A[2][1];
+#pragma unroll
+                    for (int rr = 0; rr < 3; ++rr) y[rr] = rhs[rr];
+                    const double z0 = vnext[0] * ig[0];
+                    const double z1 = __builtin_fma(-z0, g10, vnext[1]) * ig[1];
+                    const double z2 = __builtin_fma(-z1, g21, __builtin_fma(-z0, g20, vnext[2])) * ig[2];
+                    al = __builtin_fma(z2, z2, __builtin_fma(z1, z1, z0 * z0));
+                    be = __builtin_fma(z2, y[2], __builtin_fma(z1, y[1], z0 * y[0]));
                 }
-                if (p > 0) {
-                    // row by row: w = row r of W = H_p,p-1 G_{p-1}^-T; S -= w w^T; rhs_r -= w . y_{p-1}
+            }
+        } else {
+            for (int r = 0; r < nv; ++r) {
+                const double pg10 = w3_from_prev(g10), pg20 = w3_from_prev(g20), pg21 = w3_from_prev(g21);
+                const double pig[3] = {w3_from_prev(ig[0]), w3_from_prev(ig[1]), w3_from_prev(ig[2])};
+                const double py[3] = {w3_from_prev(y[0]), w3_from_prev(y[1]), w3_from_prev(y[2])};
+                if (pose) {
+                    double A[3][3], rhs[3];
+    #pragma unroll
+                    for (int rr = 0; rr < 3; ++rr) {
+    #pragma unroll
+                        for (int c = 0; c <= rr; ++c) A[rr][c] = D[rr * (rr + 1) / 2 + c];
+                        A[rr][rr] += mylam;
+                        rhs[rr] = b[rr];
+                    }
+                    // row by row: w = row r of W = H_p,p-1 G_{p-1}^-T; S -= w w^T; rhs_r -= w . y_{p-1}   (pose 0: O = 0 and a zero neighbour)
                     double Wm[9];
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        double w0 = O[r], w1 = O[3 + r], w2 = O[6 + r];
+    #pragma unroll
+                    for (int rr = 0; rr < 3; ++rr) {
+                        double w0 = O[rr], w1 = O[3 + rr], w2 = O[6 + rr];
                         w0 *= pig[0];
                         w1 = __builtin_fma(-w0, pg10, w1);
                         w2 = __builtin_fma(-w0, pg20, w2);
                         w1 *= pig[1];
                         w2 = __builtin_fma(-w1, pg21, w2);
                         w2 *= pig[2];
-                        Wm[r] = w0; Wm[3 + r] = w1; Wm[6 + r] = w2;
-                        double acc = rhs[r];
+                        Wm[rr] = w0; Wm[3 + rr] = w1; Wm[6 + rr] = w2;
+                        double acc = rhs[rr];
                         acc = __builtin_fma(-w0, py[0], acc);
                         acc = __builtin_fma(-w1, py[1], acc);
                         acc = __builtin_fma(-w2, py[2], acc);
-                        rhs[r] = acc;
+                        rhs[rr] = acc;
                     }
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-#pragma unroll
-                        for (int c2 = 0; c2 <= r; ++c2) {
-                            double s2 = A[r][c2];
-#pragma unroll
-                            for (int k = 0; k < 3; ++k) s2 = __builtin_fma(-Wm[3 * k + r], Wm[3 * k + c2], s2);
-                            A[r][c2] = s2;
+    #pragma unroll
+                    for (int rr = 0; rr < 3; ++rr)
+    #pragma unroll
+                        for (int c2 = 0; c2 <= rr; ++c2) {
+                            double s2 = A[rr][c2];
+    #pragma unroll
+                            for (int k = 0; k < 3; ++k) s2 = __builtin_fma(-Wm[3 * k + rr], Wm[3 * k + c2], s2);
+                            A[rr][c2] = s2;
                         }
+    #pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const double g = w3_pivot_rsqrt(A[j][j]);
+                        ig[j] = g;
+    #pragma unroll
+                        for (int i2 = j + 1; i2 < 3; ++i2) A[i2][j] *= g;
+    #pragma unroll
+                        for (int i2 = j + 1; i2 < 3; ++i2)
+    #pragma unroll
+                            for (int cc = j + 1; cc <= i2; ++cc) A[i2][cc] = __builtin_fma(-A[i2][j], A[cc][j], A[i2][cc]);
+                    }
+    #pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) {
+                        rhs[cc] *= ig[cc];
+    #pragma unroll
+                        for (int c2 = cc + 1; c2 < 3; ++c2) rhs[c2] = __builtin_fma(-rhs[cc], A[c2][cc], rhs[c2]);
+                    }
+                    g10 = A[1][0]; g20 = A[2][0]; g21 = A[2][1];
+    #pragma unroll
+                    for (int rr = 0; rr < 3; ++rr) y[rr] = rhs[rr];
                 }
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const double g = w3_pivot_rsqrt(A[j][j]);
-                    ig[j] = g;
-#pragma unroll
-                    for (int i2 = j + 1; i2 < 3; ++i2) A[i2][j] *= g;
-#pragma unroll
-                    for (int i2 = j + 1; i2 < 3; ++i2)
-#pragma unroll
-                        for (int cc = j + 1; cc <= i2; ++cc) A[i2][cc] = __builtin_fma(-A[i2][j], A[cc][j], A[i2][cc]);
-                }
-#pragma unroll
-                for (int cc = 0; cc < 3; ++cc) {
-                    rhs[cc] *= ig[cc];
-#pragma unroll
-                    for (int c2 = cc + 1; c2 < 3; ++c2) rhs[c2] = __builtin_fma(-rhs[cc], A[c2][cc], rhs[c2]);
-                }
-                g10 = A[1][0]; g20 = A[2][0]; g21 = A[2][1];
-#pragma unroll
-                for (int r = 0; r < 3; ++r) y[r] = rhs[r];
             }
-            pg10 = w3_bcast(g10, p); pg20 = w3_bcast(g20, p); pg21 = w3_bcast(g21, p);
-#pragma unroll
-            for (int r = 0; r < 3; ++r) { pig[r] = w3_bcast(ig[r], p); py[r] = w3_bcast(y[r], p); }
-            ok = ok && ((pig[0] + pig[1]) + pig[2] < DBL_MAX);
         }
-        // back-substitution, x only written when every pivot was positive and finite (g2o leaves its x alone when the factorisation
-        // fails, and LM applies that stale x all the same: SURVEY A.6)
-        if (ok) {
-            double v[3] = {0.0, 0.0, 0.0};   // H_{p+1,p}^T x_{p+1}, wave-uniform
-            for (int p = nv - 1; p >= 0; --p) {
-                double vn[3] = {0.0, 0.0, 0.0};
-                if (lane == p) {
+        // a group whose factorisation met a pivot that is not positive and finite has failed
+        const unsigned long long bad = __ballot(pose && !((ig[0] + ig[1]) + ig[2] < DBL_MAX));
+        W3_T(3);
+#ifdef LOCAMD_WAVE3_TIMING
+        ++w3_ph[7];
+#endif
+        // back-substitution the same way, from the right neighbour: v = H_{p+1,p}^T x_{p+1}
+        double Xn[3] = {0.0, 0.0, 0.0}, vo[3] = {0.0, 0.0, 0.0};
+        if (rank1) {
+            double ga = 0.0;   // u . x of this pose, for the previous one: H_{p+1,p}^T x_{p+1} = v (u . x_{p+1})
+            for (int r = 0; r < nv; ++r) {
+                const double pga = w3_from_next(ga);
+                if (pose) {
+                    double t[3] = {y[0], y[1], y[2]};
+                    double z0 = (pga * vnext[0]) * ig[0];
+                    double z1 = __builtin_fma(-z0, g10, pga * vnext[1]);
+                    double z2 = __builtin_fma(-z0, g20, pga * vnext[2]);
+                    t[0] -= z0;
+                    z1 *= ig[1];
+                    z2 = __builtin_fma(-z1, g21, z2);
+                    t[1] -= z1;
+                    z2 *= ig[2];
+                    t[2] -= z2;
+                    Xn[2] = t[2] * ig[2];
+                    t[0] = __builtin_fma(-g20, Xn[2], t[0]);
+                    t[1] = __builtin_fma(-g21, Xn[2], t[1]);
+                    Xn[1] = t[1] * ig[1];
+                    t[0] = __builtin_fma(-g10, Xn[1], t[0]);
+                    Xn[0] = t[0] * ig[0];
+                    ga = __builtin_fma(u[2], Xn[2], __builtin_fma(u[1], Xn[1], u[0] * Xn[0]));
+                }
+            }
+        } else {
+            for (int r = 0; r < nv; ++r) {
+                const double v[3] = {w3_from_next(vo[0]), w3_from_next(vo[1]), w3_from_next(vo[2])};
+                if (pose) {
                     double t[3] = {y[0], y[1], y[2]};
                     // z = G_p^-1 v (forward substitution), t -= z
                     double z0 = v[0] * ig[0];
@@ -407,66 +561,105 @@ __global__ void __launch_bounds__(64) wave3_lm_kernel(const WindowArgs a) {
                     t[1] -= z1;
                     z2 *= ig[2];
                     t[2] -= z2;
-                    X[2] = t[2] * ig[2];
-                    t[0] = __builtin_fma(-g20, X[2], t[0]);
-                    t[1] = __builtin_fma(-g21, X[2], t[1]);
-                    X[1] = t[1] * ig[1];
-                    t[0] = __builtin_fma(-g10, X[1], t[0]);
-                    X[0] = t[0] * ig[0];
-#pragma unroll
+                    Xn[2] = t[2] * ig[2];
+                    t[0] = __builtin_fma(-g20, Xn[2], t[0]);
+                    t[1] = __builtin_fma(-g21, Xn[2], t[1]);
+                    Xn[1] = t[1] * ig[1];
+                    t[0] = __builtin_fma(-g10, Xn[1], t[0]);
+                    Xn[0] = t[0] * ig[0];
+    #pragma unroll
                     for (int cc = 0; cc < 3; ++cc) {
                         double acc = 0.0;
-#pragma unroll
-                        for (int r = 0; r < 3; ++r) acc = __builtin_fma(O[3 * cc + r], X[r], acc);
-                        vn[cc] = acc;
+    #pragma unroll
+                        for (int rr = 0; rr < 3; ++rr) acc = __builtin_fma(O[3 * cc + rr], Xn[rr], acc);
+                        vo[cc] = acc;
                     }
                 }
-#pragma unroll
-                for (int k = 0; k < 3; ++k) v[k] = w3_bcast(vn[k], p);
             }
         }
-        ++trials;
-        // the trial state t + x (VertexSE3::oplus with R = I) and g2o's computeScale sum
-        double sc = 0.0;
-        if (lane < nv) {
-            const double* s = l.T + ((size_t)buf * nvm + lane) * 3;
-            double* d = l.T + ((size_t)(1 - buf) * nvm + lane) * 3;
+        // x of a failed factorisation: g2o leaves its x alone, and LM applies that stale x all the same — the x of the
+        // trial before, i.e. of the group before (group 0: of the trial consumed last)
+        if (bad) {
+            double st[3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { sc += X[k] * (lambda * X[k] + b[k]); d[k] = s[k] + X[k]; }
+            for (int k = 0; k < 3; ++k) st[k] = __shfl(X[k], jlast * W + pp, 64);
+            for (int g = 0; g < G; ++g) {
+                if (grp == g && ((bad >> (g * W)) & group_mask)) { Xn[0] = st[0]; Xn[1] = st[1]; Xn[2] = st[2]; }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) st[k] = __shfl(Xn[k], g * W + pp, 64);
+            }
         }
-        const double scale = w3_sum(sc) + 1e-3;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) X[k] = Xn[k];
+        W3_T(4);
+        // the trial states t + x (VertexSE3::oplus with R = I) and g2o's computeScale sums, one per group
+        double scv[4];
+        {
+            double sc = 0.0;
+            if (pose) {
+                const int slot = cur + 1 + grp - (cur + 1 + grp >= NSLOT ? NSLOT : 0);
+                const double* s = l.T + ((size_t)cur * nvm + pp) * 3;
+                double* d = l.T + ((size_t)slot * nvm + pp) * 3;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { sc += X[k] * (mylam * X[k] + b[k]); d[k] = s[k] + X[k]; }
+            }
+            // (the DPP tree of w3_sum, read where a group's lanes have been summed: the same bits as the whole-wave sum of one group)
+            sc += w3_dpp<0x111, 0xF>(sc);
+            sc += w3_dpp<0x112, 0xF>(sc);
+            sc += w3_dpp<0x114, 0xF>(sc);
+            sc += w3_dpp<0x118, 0xF>(sc);
+            const double s16 = sc;
+            sc += w3_dpp<0x142, 0xA>(sc);
+            const double s32 = sc;
+            sc += w3_dpp<0x143, 0xC>(sc);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) scv[g] = W == 16 ? w3_bcast(s16, 16 * g + 15) : (W == 32 ? w3_bcast(s32, 32 * (g & 1) + 31) : w3_bcast(sc, 63));
+        }
         w3_sync();
-        double temp_chi, plain2;
-        w3_edges<false, JAC>(l, nvm, nr, np, 1 - buf, lane, temp_chi, plain2);
-        last_plain = plain2;
-        if (!ok) temp_chi = DBL_MAX;
-        const double rho = (cur_chi - temp_chi) / scale;
-        bool iteration_over;
-        if (rho > 0.0 && fabs(temp_chi) <= DBL_MAX) {
-            const double r21 = 2.0 * rho - 1.0;
-            double alpha = 1.0 - r21 * r21 * r21;
-            alpha = fmin(alpha, good_hi);
-            lambda *= fmax(good_lo, alpha);
-            ni = 2.0;
-            cur_chi = temp_chi;
-            buf = 1 - buf;   // the trial state is the state
-            ++q;
-            iteration_over = true;
-        } else {
-            lambda *= ni;
-            ni *= 2.0;      // (pop: the state was never overwritten)
-            ++q;
-            iteration_over = !(rho < 0.0 && q < max_trials);
+        // ---- consume the trials in LM's order until one is accepted (or the iteration ends) -------------------------------------------
+        bool iteration_over = false;
+        double rho = 0.0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g < G && !iteration_over) {
+                const int slot = cur + 1 + g - (cur + 1 + g >= NSLOT ? NSLOT : 0);
+                double temp_chi, plain2;
+                w3_edges<false, JAC>(l, E0, nvm, nr, np, slot, lane, temp_chi, plain2);
+                last_plain = plain2;
+                ++trials;
+                jlast = g;
+                if ((bad >> (g * W)) & group_mask) temp_chi = DBL_MAX;
+                const double scale = scv[g] + 1e-3;
+                rho = (cur_chi - temp_chi) / scale;
+                if (rho > 0.0 && fabs(temp_chi) <= DBL_MAX) {
+                    const double r21 = 2.0 * rho - 1.0;
+                    double alpha = 1.0 - r21 * r21 * r21;
+                    alpha = fmin(alpha, good_hi);
+                    lambda = lamv[g] * fmax(good_lo, alpha);
+                    ni = 2.0;
+                    cur_chi = temp_chi;
+                    cur = slot;   // the trial state is the state
+                    ++q;
+                    iteration_over = true;
+                } else {
+                    lambda = lamv[g] * niv[g];
+                    ni = 2.0 * niv[g];      // (pop: the state was never overwritten)
+                    ++q;
+                    iteration_over = !(rho < 0.0 && q < max_trials);
+                }
+            }
         }
+        W3_T(5);
         if (iteration_over) {
             ++it;
             need_lin = true;
             if (q == max_trials || rho == 0.0) { terminated = 1; done = true; }
             if (it >= a.iterations) done = true;
         }
+        W3_T(6);
     }
     if (lane < nv) {
-        const double* s = l.T + ((size_t)buf * nvm + lane) * 3;
+        const double* s = l.T + ((size_t)cur * nvm + lane) * 3;
 #pragma unroll
         for (int k = 0; k < 9; ++k) gout[lane * 12 + k] = rot[k];
 #pragma unroll
@@ -476,13 +669,18 @@ __global__ void __launch_bounds__(64) wave3_lm_kernel(const WindowArgs a) {
         double* res = a.result + (size_t)inst * 8;
         res[0] = last_plain; res[1] = cur_chi; res[2] = lambda; res[3] = (double)it; res[4] = (double)trials;
         res[5] = (double)terminated; res[6] = (double)shared_edges; res[7] = nv > 0 ? (double)(nv * 65536 + 2 * nv - 1) : 0.0;
+#ifdef LOCAMD_WAVE3_TIMING
+        for (int k = 0; k < 7; ++k) res[k] = (double)w3_ph[k];
+        res[6] = (double)w3_ph[7];   // rounds
+        res[7] = (double)(__builtin_readcyclecounter() - w3_start) + 1e12 * trials;
+#endif
     }
 }
 
 }  // namespace
 
 size_t window_wave3_lds_bytes(const WindowCaps& c) {
-    const size_t doubles = (size_t)2 * c.nv_max * 3 + (size_t)c.nr_max * 13 + (size_t)c.np_max * 6;
+    const size_t doubles = (size_t)5 * c.nv_max * 3 + (size_t)c.nr_max * 21 + (size_t)c.np_max * 6;
     const size_t ints = (size_t)c.nr_max * 4 + c.np_max;
     return doubles * sizeof(double) + ((ints + 1) & ~(size_t)1) * sizeof(int);
 }
