@@ -629,14 +629,14 @@ static int pick_kernel(const loc_window* w, int64_t n, int topology) {
     if (topology == LOC_WINDOW_KERNEL_TREE) return (w->natural_order || n < tree_min_batch(w)) ? LOC_WINDOW_KERNEL_GENERAL : LOC_WINDOW_KERNEL_TREE;
     if (topology == LOC_WINDOW_KERNEL_CHAIN3 && mn > 0 && !w->natural_order && w->caps.nv_max <= 64 && locamd::window_wave3_lds_bytes(w->caps) <= 64 * 1024) {
         // translation-only chains of <= 64 poses below the lane-per-window batch sizes (the node's single window first of all): one
-        // wave per window with 3x3 blocks.  Measured on ten-pose windows: 1.9e7 windows/s from ~4 096 windows on, against chain3's
-        // ~1.1 ms for any batch up to 16 384 — the lane-per-window kernel takes over at ~20 000 windows (an explicit threshold moves
+        // wave per window with 3x3 blocks.  Measured on ten-pose windows: 2.4e7 windows/s from ~4 096 windows on, against chain3's
+        // ~1.1 ms for any batch up to 16 384 — the lane-per-window kernel takes over at 32 768 windows (an explicit threshold moves
         // that point).  LOCAMD_WAVE3=0 / LOCAMD_CHAIN3=0: no such kernel (A/B runs, tests).
         const bool default_rule = w->chain_min < 0 && !getenv("LOCAMD_CHAIN_MIN_BATCH");
         const char* v = getenv("LOCAMD_WAVE3");
         const char* v3 = getenv("LOCAMD_CHAIN3");
-        if (n < (default_rule ? 20480 : mn) && !(v && v[0] == '0') && !(v3 && v3[0] == '0')) return LOC_WINDOW_KERNEL_WAVE3;
-        if (default_rule && n >= 20480 && !(v3 && v3[0] == '0')) return LOC_WINDOW_KERNEL_CHAIN3;
+        if (n < (default_rule ? 32768 : mn) && !(v && v[0] == '0') && !(v3 && v3[0] == '0')) return LOC_WINDOW_KERNEL_WAVE3;
+        if (default_rule && n >= 32768 && !(v3 && v3[0] == '0')) return LOC_WINDOW_KERNEL_CHAIN3;
     }
     if (topology == LOC_WINDOW_KERNEL_CHAIN3 && mn > 0 && !w->natural_order && w->chain_min < 0 && !getenv("LOCAMD_CHAIN_MIN_BATCH") && n >= 4096 && n < mn) {
         // the translation-only kernel is worth it from ~4 096 windows on (it takes ~1 ms for any batch up to 16 384, the wave-per-window

@@ -226,7 +226,7 @@ __device__ __forceinline__ void w3_edges(const W3Lds& l, const W3Edge& E0, int n
 }
 
 template <int JAC>
-__global__ void __launch_bounds__(64) wave3_lm_kernel(const WindowArgs a) {
+__global__ void __launch_bounds__(64, 3) wave3_lm_kernel(const WindowArgs a) {
     const int lane = threadIdx.x;
     const long long inst = blockIdx.x;
     const WindowCaps& cp = a.caps;
@@ -242,10 +242,10 @@ __global__ void __launch_bounds__(64) wave3_lm_kernel(const WindowArgs a) {
     int pv0 = 0, pv1 = 0;
     double pmeas = 0.0, pinfo = 0.0;
 #pragma unroll
-    for (int k = 0; k < 12; ++k) pin[k] = 0.0;
+    for (int k = 9; k < 12; ++k) pin[k] = 0.0;
     if (lane < nvm) {
 #pragma unroll
-        for (int k = 0; k < 12; ++k) pin[k] = gin[lane * 12 + k];
+        for (int k = 9; k < 12; ++k) pin[k] = gin[lane * 12 + k];
     }
     if (lane < cp.nr_max) { pv0 = ridx[2 * lane]; pv1 = ridx[2 * lane + 1]; pmeas = rval[5 * lane]; pinfo = rval[5 * lane + 1]; }
     const int nv = a.counts[inst * 4 + 0], nr = a.counts[inst * 4 + 1], np = a.counts[inst * 4 + 2];
@@ -258,12 +258,7 @@ __global__ void __launch_bounds__(64) wave3_lm_kernel(const WindowArgs a) {
     const unsigned long long group_mask = W == 64 ? ~0ull : ((1ull << W) - 1ull);
     W3_T0();
     // ---- set-up: translations, edges (with their fixed endpoints), priors into LDS; the poses' incidence lists ---------------
-    double rot[9];   // this lane's pose keeps its rotation (it never moves)
-#pragma unroll
-    for (int k = 0; k < 9; ++k) rot[k] = 0.0;
     if (lane < nv) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) rot[k] = pin[k];
 #pragma unroll
         for (int k = 0; k < 3; ++k) l.T[lane * 3 + k] = pin[9 + k];
     }
@@ -660,8 +655,10 @@ __global__ void __launch_bounds__(64) wave3_lm_kernel(const WindowArgs a) {
     }
     if (lane < nv) {
         const double* s = l.T + ((size_t)cur * nvm + lane) * 3;
+        if (gin != gout) {   // the rotations never move
 #pragma unroll
-        for (int k = 0; k < 9; ++k) gout[lane * 12 + k] = rot[k];
+            for (int k = 0; k < 9; ++k) gout[lane * 12 + k] = gin[lane * 12 + k];
+        }
 #pragma unroll
         for (int k = 0; k < 3; ++k) gout[lane * 12 + 9 + k] = s[k];
     }

@@ -151,14 +151,14 @@ def test_chain3_is_taken_only_by_translation_only_batches(gpu):
 @pytest.mark.parametrize("kernel", ["chain3_lm_kernel", "chain_lm_kernel"])
 def test_lane_per_window_kernels_at_the_batch_size_that_selects_them(gpu, kernel):
     """Ten-pose windows of cfg/uwb_only.yaml's topology at the batch sizes where the DEFAULT thresholds pick the lane-per-window
-    kernels (20 480 translation-only windows; 12 288 when the 3-DoF kernels are switched off), nothing is forced: same-mode parity on a
+    kernels (32 768 translation-only windows; 12 288 when the 3-DoF kernels are switched off), nothing is forced: same-mode parity on a
     512-window sample, the cross-mode bound (analytic kernel vs the numeric oracle = the reference's configuration) on 2 048, and the
     numeric kernel against the numeric oracle."""
     import sys
     import localization_amd as la
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "perf"))
     import bench_window as bw
-    B, n_distinct = (20480 if kernel == "chain3_lm_kernel" else 12288), 2048
+    B, n_distinct = (32768 if kernel == "chain3_lm_kernel" else 12288), 2048
     small, graphs, anchors, T = bw.build(n_distinct, "uwb_only", seed=99)
     wb = la.WindowBatch(B, *small.caps)
     for name in ("counts", "poses", "r_idx", "r_val", "p_idx", "p_val", "s_idx", "s_val"):

@@ -54,6 +54,40 @@ def test_ate_of_vicon_against_itself_and_fixture_sanity():
     assert 0.07 < r["rmse"] < 0.1                                # sqrt(3) * 0.05
 
 
+def test_native_ate_tool_matches_the_numpy_evaluation(tmp_path):
+    """tools/loc_ate.cpp ("small native tool") on TUM files written by the node's log writer: the same association,
+    alignment and statistics as localization_amd/ate.py — on the example recording's Vicon track against a rotated, shifted, noisy,
+    time-offset and sub-sampled copy of it, aligned and not, and its error exit when no stamps match."""
+    import json
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "loc_ate")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tools", "loc_ate.cpp"), "-o", exe])
+    z = np.load(os.path.join(GOLD, "bag_example.npz"))
+    truth = np.column_stack([z["vicon_stamp"], z["vicon_pos"], z["vicon_q_xyzw"]])
+    rng = np.random.default_rng(4)
+    from scipy.spatial.transform import Rotation
+    Rm = Rotation.from_rotvec([0.2, -0.4, 1.1]).as_matrix()
+    est = truth[::3].copy()
+    est[:, 1:4] = est[:, 1:4] @ Rm.T + np.array([0.5, -2.0, 0.3]) + rng.normal(0, 0.03, (len(est), 3))
+    est[:, 0] += 0.004 + rng.uniform(-0.003, 0.003, len(est))
+    ft, fe = str(tmp_path / "truth.txt"), str(tmp_path / "est.txt")
+    ate.write_tum(ft, truth, header=["truth"]); ate.write_tum(fe, est, header=["estimate"])
+    t2, e2 = ate.read_tum(ft), ate.read_tum(fe)          # (what the files hold: '%g' keeps six digits of the coordinates)
+    for extra, kw in (([], {}), (["--no-align"], {"align": False}), (["--offset", "-0.004", "--max_difference", "0.01"], {"offset": -0.004, "max_difference": 0.01})):
+        got = json.loads(subprocess.check_output([exe, ft, fe] + extra))
+        want = ate.evaluate_ate(e2, t2, **kw)
+        assert got["pairs"] == want["pairs"] > 600
+        for k in ("rmse", "mean", "median", "std", "min", "max"):
+            assert abs(got[k] - want[k]) < 1e-9 * max(1.0, abs(want[k])), (extra, k, got[k], want[k])
+    far = est.copy(); far[:, 0] += 100.0
+    ate.write_tum(fe, far, header=["estimate"])
+    r = subprocess.run([exe, ft, fe], capture_output=True, text=True)
+    assert r.returncode == 1 and "matching timestamp pairs" in r.stderr
+
+
 @pytest.mark.skipif(not os.path.exists(REF_BAG), reason="the reference tree exists only in the build container")
 def test_bag_reader_reproduces_the_committed_fixture():
     z = np.load(os.path.join(GOLD, "bag_example.npz"))
