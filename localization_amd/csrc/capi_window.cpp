@@ -30,6 +30,8 @@ struct loc_window {
     int iterations = 10;
     int jacobian = LOC_JAC_NUMERIC_G2O, natural_order = 0;   // default = the reference's configuration
     double* d_anchors = nullptr;
+    std::vector<double> h_anchors;   // handles of <= 4 windows (a node's own): the table as last set; the device copy follows on demand
+    bool anchors_dirty = false;
     int32_t *d_counts = nullptr, *d_ridx = nullptr, *d_pidx = nullptr, *d_sidx = nullptr;
     double *d_poses = nullptr, *d_rval = nullptr, *d_pval = nullptr, *d_sval = nullptr, *d_result = nullptr;
     double* d_workspace = nullptr;  // HBM copy of the (H, L) matrices when they do not fit LDS
@@ -149,14 +151,13 @@ int loc_window_create(loc_window** out, int32_t device, int64_t batch, const loc
         loc_window_destroy(w);
         return locamd_fail_hip(e, "loc_window_create");
     }
+    if (batch <= 4 && n_anchors > 0) w->h_anchors.assign(anchors, anchors + (size_t)n_anchors * 3);
     *out = w;
     return LOC_OK;
 }
 
-int loc_window_set_anchors(loc_window* w, int32_t n_anchors, const double* anchors) {
-    if (!w || n_anchors < 0 || (n_anchors > 0 && !anchors)) return locamd_fail(LOC_ERR_INVALID, "set_anchors");
-    if (w->n_resident > 0 && n_anchors < w->resident_min_anchors)
-        return locamd_fail(LOC_ERR_INVALID, "set_anchors: the resident batch references more anchors than the new table holds (upload again first)");
+// the device copy of the anchor table
+static int upload_anchors(loc_window* w, int32_t n_anchors, const double* anchors) {
     LOC_HIP(hipSetDevice(w->device));
     if (w->last_stream) LOC_HIP(hipStreamSynchronize(w->last_stream));   // a resident launch may still be reading the table
     if (n_anchors > w->anchors_cap) {
@@ -168,7 +169,27 @@ int loc_window_set_anchors(loc_window* w, int32_t n_anchors, const double* ancho
     }
     if (n_anchors > 0) LOC_HIP(hipMemcpy(w->d_anchors, anchors, (size_t)n_anchors * 3 * sizeof(double), hipMemcpyHostToDevice));
     w->n_anchors = n_anchors;
+    w->anchors_dirty = false;
     return LOC_OK;
+}
+static int flush_anchors(loc_window* w) {
+    if (!w->anchors_dirty) return LOC_OK;
+    return upload_anchors(w, w->n_anchors, w->h_anchors.data());
+}
+
+int loc_window_set_anchors(loc_window* w, int32_t n_anchors, const double* anchors) {
+    if (!w || n_anchors < 0 || (n_anchors > 0 && !anchors)) return locamd_fail(LOC_ERR_INVALID, "set_anchors");
+    if (w->n_resident > 0 && n_anchors < w->resident_min_anchors)
+        return locamd_fail(LOC_ERR_INVALID, "set_anchors: the resident batch references more anchors than the new table holds (upload again first)");
+    if (w->B <= 4) {
+        // a node's handle: its table changes with every message (the window slides), and its solve usually reads the table from the
+        // page-locked staging block (loc_window_solve_host) — the device copy is refreshed only when a launch needs it
+        w->h_anchors.assign(anchors, anchors + (size_t)n_anchors * 3);
+        w->n_anchors = n_anchors;
+        w->anchors_dirty = true;
+        return LOC_OK;
+    }
+    return upload_anchors(w, n_anchors, anchors);
 }
 
 // host-side shape check: a bad index would fault the GPU
@@ -757,15 +778,23 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
             // A handful of small windows on wave3_lm_kernel (the node's own solve): the kernel reads its few KB of input once and
             // writes 1 KB of results — it does so straight from / to the page-locked staging block (host-coherent memory, mapped
             // into the device's address space), which saves the two DMA operations around a ~75 us kernel.
-            const bool zero_copy = kind == LOC_WINDOW_KERNEL_WAVE3 && n <= 4 && !getenv("LOCAMD_NO_ZERO_COPY");
-            if (zero_copy) d = h;
-            else LOC_HIP(hipMemcpyAsync(d, h, off[9], hipMemcpyHostToDevice, st));
+            const size_t anchor_bytes = (size_t)w->n_anchors * 3 * sizeof(double);
+            const bool zero_copy = kind == LOC_WINDOW_KERNEL_WAVE3 && n <= 4 && w->B <= 4 && w->h_anchors.size() == (size_t)w->n_anchors * 3 &&
+                                   off[9] + anchor_bytes <= kStageBytes && !getenv("LOCAMD_NO_ZERO_COPY");
+            if (zero_copy) {
+                d = h;
+                if (anchor_bytes) std::memcpy(h + off[9], w->h_anchors.data(), anchor_bytes);
+            } else {
+                const int rc = flush_anchors(w);
+                if (rc != LOC_OK) return rc;
+                LOC_HIP(hipMemcpyAsync(d, h, off[9], hipMemcpyHostToDevice, st));
+            }
             locamd::WindowArgs a;
             a.poses = (double*)(d + off[0]); a.poses_in = a.poses; a.jacobian = w->jacobian; a.natural_order = w->natural_order; a.result = (double*)(d + off[1]); a.counts = (const int32_t*)(d + off[2]);
             a.r_val = (const double*)(d + off[3]); a.p_val = (const double*)(d + off[4]); a.s_val = (const double*)(d + off[5]);
             a.r_off1 = w->has_off1 ? w->d_roff1 : nullptr;
             a.r_idx = (const int32_t*)(d + off[6]); a.p_idx = (const int32_t*)(d + off[7]); a.s_idx = (const int32_t*)(d + off[8]);
-            a.anchors = w->d_anchors; a.workspace = w->d_workspace;
+            a.anchors = zero_copy ? (const double*)(h + off[9]) : w->d_anchors; a.workspace = w->d_workspace;
             a.n_anchors = w->n_anchors; a.B = (int)n; a.iterations = w->iterations; a.caps = c;
             LOC_HIP(hipEventRecord(w->ev0, st));
             if (kind == LOC_WINDOW_KERNEL_ARROW3) LOC_HIP(upload_arrow_aux(w, 0, n, st));
@@ -782,6 +811,10 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
             w->last_ms = ms;
             return LOC_OK;
         }
+    }
+    {
+        const int rc = flush_anchors(w);
+        if (rc != LOC_OK) return rc;
     }
     LOC_HIP(hipMemcpyAsync(w->d_counts, counts, N * 4 * sizeof(int32_t), hipMemcpyHostToDevice, st));
     LOC_HIP(hipMemcpyAsync(w->d_poses, poses, N * c.nv_max * 12 * sizeof(double), hipMemcpyHostToDevice, st));
@@ -867,6 +900,10 @@ int loc_window_upload(loc_window* w, int64_t n, const int32_t* counts, const dou
 int loc_window_solve_resident(loc_window* w, void* hip_stream) {
     if (!w || w->n_resident <= 0) return locamd_fail(LOC_ERR_INVALID, "nothing uploaded");
     LOC_HIP(hipSetDevice(w->device));
+    {
+        const int rc = flush_anchors(w);
+        if (rc != LOC_OK) return rc;
+    }
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : w->stream;
     locamd::WindowArgs a;
     a.counts = w->d_counts; a.poses_in = w->d_poses_in; a.poses = w->d_poses; a.r_idx = w->d_ridx; a.r_val = w->d_rval; a.p_idx = w->d_pidx;
