@@ -127,17 +127,19 @@ __device__ __forceinline__ double pivot_rsqrtA(double d) {   // window_kernel.hi
 }
 
 #pragma clang fp contract(off)
-__device__ __forceinline__ double norm3_plainA(double dx, double dy, double dz) { return sqrt_ieee_unscaled(dx * dx + dy * dy + dz * dz); }
-// g2o's central difference along axis D of endpoint `which` (chain3_kernel.hip: range_jac_numeric3)
-template <int D>
-__device__ __forceinline__ double range_jac_numericA(const double* p0, const double* p1, int which, double meas) {
+__device__ __forceinline__ double sq3_plainA(double dx, double dy, double dz) { return dx * dx + dy * dy + dz * dz; }
+// g2o's central difference along axis D of endpoint `which` (chain3_kernel.hip: range_jac_numeric3); NEAR: the perturbed norms
+// from the central one n0 (device_math.h: sqrt_ieee_near — the same correctly rounded numbers)
+template <int D, bool NEAR>
+__device__ __forceinline__ double range_jac_numericA(const double* p0, const double* p1, int which, double meas, double n0, double h0) {
     constexpr double delta = 1e-9;
     constexpr double scalar = 1.0 / (2 * delta);
     double a[3] = {p0[0], p0[1], p0[2]}, b[3] = {p1[0], p1[1], p1[2]}, am[3] = {p0[0], p0[1], p0[2]}, bm[3] = {p1[0], p1[1], p1[2]};
     if (which == 0) { a[D] = delta + p0[D]; am[D] = -delta + p0[D]; }
     else { b[D] = delta + p1[D]; bm[D] = -delta + p1[D]; }
-    const double ep = meas - norm3_plainA(a[0] - b[0], a[1] - b[1], a[2] - b[2]);
-    const double em = meas - norm3_plainA(am[0] - bm[0], am[1] - bm[1], am[2] - bm[2]);
+    const double xp = sq3_plainA(a[0] - b[0], a[1] - b[1], a[2] - b[2]), xm = sq3_plainA(am[0] - bm[0], am[1] - bm[1], am[2] - bm[2]);
+    const double ep = meas - (NEAR ? sqrt_ieee_near(xp, n0, h0) : sqrt_ieee_unscaled(xp));
+    const double em = meas - (NEAR ? sqrt_ieee_near(xm, n0, h0) : sqrt_ieee_unscaled(xm));
     double bak = ep;
     bak -= em;
     return scalar * bak;
@@ -190,8 +192,10 @@ template <bool FULL, int JAC>
 __device__ __forceinline__ EdgeTerms range_terms(const double* p0, const double* p1, bool moving1, double meas, double info) {
     EdgeTerms t;
     double u[3] = {p0[0] - p1[0], p0[1] - p1[1], p0[2] - p1[2]};
-    const double n = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
-    const double err = JAC == 0 ? meas - n : meas - norm3_plainA(u[0], u[1], u[2]);
+    double n = 0.0, x0 = 0.0, h0 = 0.0;
+    if (JAC == 0) n = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    else { x0 = sq3_plainA(u[0], u[1], u[2]); n = sqrt_ieee_unscaled_h(x0, h0); }
+    const double err = meas - n;
     t.chi = err * (info * err);
     const double aux = 1.0 + t.chi;
     t.rho = fast_log_ge1(aux);
@@ -202,14 +206,26 @@ __device__ __forceinline__ EdgeTerms range_terms(const double* p0, const double*
             t.J0[0] = -u[0]; t.J0[1] = -u[1]; t.J0[2] = -u[2];
             t.J1[0] = moving1 ? u[0] : 0.0; t.J1[1] = moving1 ? u[1] : 0.0; t.J1[2] = moving1 ? u[2] : 0.0;
         } else {
-            t.J0[0] = range_jac_numericA<0>(p0, p1, 0, meas);
-            t.J0[1] = range_jac_numericA<1>(p0, p1, 0, meas);
-            t.J0[2] = range_jac_numericA<2>(p0, p1, 0, meas);
-            if (moving1) {
-                t.J1[0] = range_jac_numericA<0>(p0, p1, 1, meas);
-                t.J1[1] = range_jac_numericA<1>(p0, p1, 1, meas);
-                t.J1[2] = range_jac_numericA<2>(p0, p1, 1, meas);
-            } else { t.J1[0] = 0.0; t.J1[1] = 0.0; t.J1[2] = 0.0; }
+            t.J1[0] = 0.0; t.J1[1] = 0.0; t.J1[2] = 0.0;
+            if (x0 >= 1e-5 && x0 < 1e300) {   // endpoints more than ~3 mm apart
+                t.J0[0] = range_jac_numericA<0, true>(p0, p1, 0, meas, n, h0);
+                t.J0[1] = range_jac_numericA<1, true>(p0, p1, 0, meas, n, h0);
+                t.J0[2] = range_jac_numericA<2, true>(p0, p1, 0, meas, n, h0);
+                if (moving1) {
+                    t.J1[0] = range_jac_numericA<0, true>(p0, p1, 1, meas, n, h0);
+                    t.J1[1] = range_jac_numericA<1, true>(p0, p1, 1, meas, n, h0);
+                    t.J1[2] = range_jac_numericA<2, true>(p0, p1, 1, meas, n, h0);
+                }
+            } else {
+                t.J0[0] = range_jac_numericA<0, false>(p0, p1, 0, meas, n, h0);
+                t.J0[1] = range_jac_numericA<1, false>(p0, p1, 0, meas, n, h0);
+                t.J0[2] = range_jac_numericA<2, false>(p0, p1, 0, meas, n, h0);
+                if (moving1) {
+                    t.J1[0] = range_jac_numericA<0, false>(p0, p1, 1, meas, n, h0);
+                    t.J1[1] = range_jac_numericA<1, false>(p0, p1, 1, meas, n, h0);
+                    t.J1[2] = range_jac_numericA<2, false>(p0, p1, 1, meas, n, h0);
+                }
+            }
         }
         t.wr = info / aux;
         t.wre = -t.wr * err;

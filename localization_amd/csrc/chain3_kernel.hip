@@ -71,18 +71,20 @@ __device__ __forceinline__ double pivot_rsqrt3(double d) {   // window_kernel.hi
 
 #pragma clang fp contract(off)
 // ||d|| the way a plain CPU build of computeError evaluates it (numeric_jacobian.h: range_error_plain with a zero lever arm)
-__device__ __forceinline__ double norm3_plain(double dx, double dy, double dz) { return sqrt_ieee_unscaled(dx * dx + dy * dy + dz * dz); }
+__device__ __forceinline__ double sq3_plain(double dx, double dy, double dz) { return dx * dx + dy * dy + dz * dz; }
 // g2o's central difference of e = meas - ||p0 - p1|| along axis D of endpoint `which`'s translation (numeric_jacobian.h /
 // window_kernel.hip: range_jac_numeric with R = I and a zero lever arm: X * fromVectorMQT(+-delta e_D) = (I, t +- delta e_D))
-template <int D>
-__device__ __forceinline__ double range_jac_numeric3(const double* p0, const double* p1, int which, double meas) {
+// NEAR: the perturbed norms from the central one n0 (device_math.h: sqrt_ieee_near — the same correctly rounded numbers)
+template <int D, bool NEAR>
+__device__ __forceinline__ double range_jac_numeric3(const double* p0, const double* p1, int which, double meas, double n0, double h0) {
     constexpr double delta = 1e-9;
     constexpr double scalar = 1.0 / (2 * delta);
     double a[3] = {p0[0], p0[1], p0[2]}, b[3] = {p1[0], p1[1], p1[2]}, am[3] = {p0[0], p0[1], p0[2]}, bm[3] = {p1[0], p1[1], p1[2]};
     if (which == 0) { a[D] = delta + p0[D]; am[D] = -delta + p0[D]; }
     else { b[D] = delta + p1[D]; bm[D] = -delta + p1[D]; }
-    const double ep = meas - norm3_plain(a[0] - b[0], a[1] - b[1], a[2] - b[2]);
-    const double em = meas - norm3_plain(am[0] - bm[0], am[1] - bm[1], am[2] - bm[2]);
+    const double xp = sq3_plain(a[0] - b[0], a[1] - b[1], a[2] - b[2]), xm = sq3_plain(am[0] - bm[0], am[1] - bm[1], am[2] - bm[2]);
+    const double ep = meas - (NEAR ? sqrt_ieee_near(xp, n0, h0) : sqrt_ieee_unscaled(xp));
+    const double em = meas - (NEAR ? sqrt_ieee_near(xm, n0, h0) : sqrt_ieee_unscaled(xm));
     double bak = ep;
     bak -= em;
     return scalar * bak;
@@ -165,8 +167,10 @@ __device__ __forceinline__ void chain3_sweep(const WindowArgs& a, const Ctx3& c,
                 p1[0] = an[0]; p1[1] = an[1]; p1[2] = an[2];
             }
             double u[3] = {p0[0] - p1[0], p0[1] - p1[1], p0[2] - p1[2]};
-            const double n = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
-            const double err = JAC == 0 ? meas - n : meas - norm3_plain(u[0], u[1], u[2]);
+            double n = 0.0, x0 = 0.0, h0 = 0.0;
+            if (JAC == 0) n = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+            else { x0 = sq3_plain(u[0], u[1], u[2]); n = sqrt_ieee_unscaled_h(x0, h0); }
+            const double err = meas - n;
             const double chi = err * (info * err);
             const double aux = 1.0 + chi;
             rsum += fast_log_ge1(aux);
@@ -179,14 +183,26 @@ __device__ __forceinline__ void chain3_sweep(const WindowArgs& a, const Ctx3& c,
                     J0[0] = -u[0]; J0[1] = -u[1]; J0[2] = -u[2];
                     if (v1 >= 0) { J1[0] = u[0]; J1[1] = u[1]; J1[2] = u[2]; } else { J1[0] = 0; J1[1] = 0; J1[2] = 0; }
                 } else {
-                    J0[0] = range_jac_numeric3<0>(p0, p1, 0, meas);
-                    J0[1] = range_jac_numeric3<1>(p0, p1, 0, meas);
-                    J0[2] = range_jac_numeric3<2>(p0, p1, 0, meas);
-                    if (v1 >= 0) {
-                        J1[0] = range_jac_numeric3<0>(p0, p1, 1, meas);
-                        J1[1] = range_jac_numeric3<1>(p0, p1, 1, meas);
-                        J1[2] = range_jac_numeric3<2>(p0, p1, 1, meas);
-                    } else { J1[0] = 0; J1[1] = 0; J1[2] = 0; }
+                    J1[0] = 0; J1[1] = 0; J1[2] = 0;
+                    if (x0 >= 1e-5 && x0 < 1e300) {   // endpoints more than ~3 mm apart
+                        J0[0] = range_jac_numeric3<0, true>(p0, p1, 0, meas, n, h0);
+                        J0[1] = range_jac_numeric3<1, true>(p0, p1, 0, meas, n, h0);
+                        J0[2] = range_jac_numeric3<2, true>(p0, p1, 0, meas, n, h0);
+                        if (v1 >= 0) {
+                            J1[0] = range_jac_numeric3<0, true>(p0, p1, 1, meas, n, h0);
+                            J1[1] = range_jac_numeric3<1, true>(p0, p1, 1, meas, n, h0);
+                            J1[2] = range_jac_numeric3<2, true>(p0, p1, 1, meas, n, h0);
+                        }
+                    } else {
+                        J0[0] = range_jac_numeric3<0, false>(p0, p1, 0, meas, n, h0);
+                        J0[1] = range_jac_numeric3<1, false>(p0, p1, 0, meas, n, h0);
+                        J0[2] = range_jac_numeric3<2, false>(p0, p1, 0, meas, n, h0);
+                        if (v1 >= 0) {
+                            J1[0] = range_jac_numeric3<0, false>(p0, p1, 1, meas, n, h0);
+                            J1[1] = range_jac_numeric3<1, false>(p0, p1, 1, meas, n, h0);
+                            J1[2] = range_jac_numeric3<2, false>(p0, p1, 1, meas, n, h0);
+                        }
+                    }
                 }
                 const double wr = info / aux, wre = -wr * err;
                 // endpoint 0's block and b: into pose p (Dc) or pose p - 1 (Dp)

@@ -57,6 +57,40 @@ __device__ __forceinline__ double sqrt_ieee_unscaled(double x) {
     return (x == 0.0 || x == __builtin_inf()) ? x : s;
 }
 
+// The same, also handing out h ~ 0.5 / sqrt(x) (for sqrt_ieee_near).
+__device__ __forceinline__ double sqrt_ieee_unscaled_h(double x, double& h_out) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double s = x * y;
+    double h = y * 0.5;
+    const double r = __builtin_fma(-h, s, 0.5);
+    s = __builtin_fma(s, r, s);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-s, s, x);
+    s = __builtin_fma(d, h, s);
+    d = __builtin_fma(-s, s, x);
+    s = __builtin_fma(d, h, s);
+    h_out = h;
+    return (x == 0.0 || x == __builtin_inf()) ? x : s;
+}
+// The IEEE square root of an argument NEAR one whose root is known: g2o's central differences evaluate the range at p +- 1e-9 e_d,
+// so the six (or twelve) perturbed squared distances of an edge differ from the central one x0 by ~2e-9 |d| — and the correctly
+// rounded root is a unique number, whichever way it is reached.  From s0 = sqrt(x0), h0 ~ 0.5 / s0 (relative distance e0 ~ 1e-9 / s0
+// from the root of x): one residual correction s <- s0 + (x - s0^2) h0 (error ~1.5 e0^2), one Newton step for h ~ 0.5 / s
+// (h <- h0 + h0 (1 - 2 h0 s): error e0^2 instead of e0), then the compiler's own final correction s <- s + (x - s^2) h.  The value
+// before the last rounding is off by ~e0^4 relative, so a wrong rounding needs the root within that of a rounding boundary:
+// probability ~1e16 e0^4 per evaluation (1e-8 for endpoints a millimetre apart, 1e-12 at a centimetre, nothing at a metre) —
+// callers guard with x0 >= 1e-5 m^2.  (Without the step for h, or with only this one correction of s, the probe below finds 1e-8 /
+// 1e-5 of the arguments one ulp off.)  Bit-identical to sqrt() on 2^28 perturbed arguments (tools/sqrt_probe.hip,
+// profiles/r03_sqrt_probe.txt); 6 instructions instead of 13.
+__device__ __forceinline__ double sqrt_ieee_near(double x, double s0, double h0) {
+    double d = __builtin_fma(-s0, s0, x);
+    double s = __builtin_fma(d, h0, s0);
+    const double r = __builtin_fma(-(h0 + h0), s, 1.0);
+    const double h = __builtin_fma(h0, r, h0);
+    d = __builtin_fma(-s, s, x);
+    return __builtin_fma(d, h, s);
+}
+
 // n = sqrt(x) to 4.1e-15 relative (the Goldschmidt step without the residual correction; profiles/r01_math_probe.txt) and
 // inv = 1/sqrt(x) to 4.2e-15:
 // the range norm of the analytic kernels, where 1e-14 m is five orders below anything the estimate resolves; two

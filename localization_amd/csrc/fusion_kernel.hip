@@ -133,10 +133,20 @@ __device__ __forceinline__ Sys6 evaluate6(const Pose& X, const double (&ax)[M8],
             J[0] = -rx; J[1] = -ry; J[2] = -rz;
             J[3] = ry * o2z - rz * o2y; J[4] = rz * o2x - rx * o2z; J[5] = rx * o2y - ry * o2x;  // 2 (uR x o)
         } else {
-            e = dj - norm_to_plain(P0, ax[j], ay[j], az[j]);
+            const double x0 = sq_to_plain(P0, ax[j], ay[j], az[j]);
+            double h0;
+            const double n0 = sqrt_ieee_unscaled_h(x0, h0);
+            e = dj - n0;
+            if (x0 >= 1e-5 && x0 < 1e300) {   // the twelve perturbed norms from the central one: the same correctly rounded numbers
 #pragma unroll
-            for (int dd = 0; dd < 6; ++dd)
-                J[dd] = central_difference_plain(dj, norm_to_plain(Pp[dd], ax[j], ay[j], az[j]), norm_to_plain(Pm[dd], ax[j], ay[j], az[j]));
+                for (int dd = 0; dd < 6; ++dd)
+                    J[dd] = central_difference_plain(dj, sqrt_ieee_near(sq_to_plain(Pp[dd], ax[j], ay[j], az[j]), n0, h0),
+                                                     sqrt_ieee_near(sq_to_plain(Pm[dd], ax[j], ay[j], az[j]), n0, h0));
+            } else {   // an antenna within millimetres of an anchor (or an estimate that has run away)
+#pragma unroll
+                for (int dd = 0; dd < 6; ++dd)
+                    J[dd] = central_difference_plain(dj, norm_to_plain(Pp[dd], ax[j], ay[j], az[j]), norm_to_plain(Pm[dd], ax[j], ay[j], az[j]));
+            }
         }
         const double we = wj * e;
         const double chi = e * we;

@@ -57,6 +57,12 @@ __device__ __forceinline__ double norm_to_plain(const double* P, double ax, doub
     const double dx = P[0] - ax, dy = P[1] - ay, dz = P[2] - az;
     return sqrt_ieee_unscaled(dx * dx + dy * dy + dz * dz);
 }
+// the squared distance of norm_to_plain (same operation order), and the norm of a PERTURBED point from the central one's
+// (device_math.h: sqrt_ieee_near — the same correctly rounded number; n0 = norm_to_plain of the unperturbed point, h0 ~ 0.5 / n0)
+__device__ __forceinline__ double sq_to_plain(const double* P, double ax, double ay, double az) {
+    const double dx = P[0] - ax, dy = P[1] - ay, dz = P[2] - az;
+    return dx * dx + dy * dy + dz * dz;
+}
 // J = ((meas - n+) - (meas - n-)) / (2 delta), g2o's operation order
 __device__ __forceinline__ double central_difference_plain(double meas, double np, double nm) {
     constexpr double delta = 1e-9;

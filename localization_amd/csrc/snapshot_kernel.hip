@@ -84,6 +84,8 @@ struct System {
 __device__ __forceinline__ double range_norm_plain(double dx, double dy, double dz) {
     return sqrt_ieee_unscaled(dx * dx + dy * dy + dz * dz);
 }
+// the squared distance in the same (plain) operation order
+__device__ __forceinline__ double range_sq_plain(double dx, double dy, double dz) { return dx * dx + dy * dy + dz * dz; }
 #pragma clang fp contract(fast)
 
 // Residuals, robust weights, normal equations and both chi sums at point p, for this lane's APL anchors, combined
@@ -109,13 +111,22 @@ __device__ __forceinline__ System evaluate(const double px, const double py, con
         } else {
             constexpr double delta = 1e-9;
             constexpr double scalar = 1.0 / (2 * delta);
-            n = range_norm_plain(dx, dy, dz);
+            const double x0 = range_sq_plain(dx, dy, dz);
+            double h0;
+            n = sqrt_ieee_unscaled_h(x0, h0);
             const double xp = (px + delta) - ax[j], xm = (px - delta) - ax[j];
             const double yp = (py + delta) - ay[j], ym = (py - delta) - ay[j];
             const double zp = (pz + delta) - az[j], zm = (pz - delta) - az[j];
-            jx = scalar * ((d[j] - range_norm_plain(xp, dy, dz)) - (d[j] - range_norm_plain(xm, dy, dz)));
-            jy = scalar * ((d[j] - range_norm_plain(dx, yp, dz)) - (d[j] - range_norm_plain(dx, ym, dz)));
-            jz = scalar * ((d[j] - range_norm_plain(dx, dy, zp)) - (d[j] - range_norm_plain(dx, dy, zm)));
+            if (x0 >= 1e-5 && x0 < 1e300) {
+                // the six perturbed norms from the central one (device_math.h: sqrt_ieee_near — the same correctly rounded numbers)
+                jx = scalar * ((d[j] - sqrt_ieee_near(range_sq_plain(xp, dy, dz), n, h0)) - (d[j] - sqrt_ieee_near(range_sq_plain(xm, dy, dz), n, h0)));
+                jy = scalar * ((d[j] - sqrt_ieee_near(range_sq_plain(dx, yp, dz), n, h0)) - (d[j] - sqrt_ieee_near(range_sq_plain(dx, ym, dz), n, h0)));
+                jz = scalar * ((d[j] - sqrt_ieee_near(range_sq_plain(dx, dy, zp), n, h0)) - (d[j] - sqrt_ieee_near(range_sq_plain(dx, dy, zm), n, h0)));
+            } else {   // a tag within millimetres of an anchor (or an estimate that has run away)
+                jx = scalar * ((d[j] - range_norm_plain(xp, dy, dz)) - (d[j] - range_norm_plain(xm, dy, dz)));
+                jy = scalar * ((d[j] - range_norm_plain(dx, yp, dz)) - (d[j] - range_norm_plain(dx, ym, dz)));
+                jz = scalar * ((d[j] - range_norm_plain(dx, dy, zp)) - (d[j] - range_norm_plain(dx, dy, zm)));
+            }
         }
         const double e = d[j] - n;
         w[j] = (fabs(e) > gate) ? 0.0 : w[j];  // |d_hat - d| > distance_outlier, localization.cpp:309 (gate = inf: off)

@@ -90,18 +90,20 @@ __device__ __forceinline__ double w3_pivot_rsqrt(double d) {   // window_kernel.
 
 #pragma clang fp contract(off)
 // ||d|| the way a plain CPU build of computeError evaluates it (numeric_jacobian.h: range_error_plain with a zero lever arm)
-__device__ __forceinline__ double w3_norm_plain(double dx, double dy, double dz) { return sqrt_ieee_unscaled(dx * dx + dy * dy + dz * dz); }
+__device__ __forceinline__ double w3_sq_plain(double dx, double dy, double dz) { return dx * dx + dy * dy + dz * dz; }
 // g2o's central difference of e = meas - ||p0 - p1|| along axis D of endpoint `which`'s translation (R = I, zero lever arm:
 // X * fromVectorMQT(+-delta e_D) = (I, t +- delta e_D); chain3_kernel.hip: range_jac_numeric3)
-template <int D>
-__device__ __forceinline__ double w3_jac_numeric(const double* p0, const double* p1, int which, double meas) {
+// NEAR: the perturbed norms from the central one n0 (device_math.h: sqrt_ieee_near — the same correctly rounded numbers)
+template <int D, bool NEAR>
+__device__ __forceinline__ double w3_jac_numeric(const double* p0, const double* p1, int which, double meas, double n0, double h0) {
     constexpr double delta = 1e-9;
     constexpr double scalar = 1.0 / (2 * delta);
     double a[3] = {p0[0], p0[1], p0[2]}, b[3] = {p1[0], p1[1], p1[2]}, am[3] = {p0[0], p0[1], p0[2]}, bm[3] = {p1[0], p1[1], p1[2]};
     if (which == 0) { a[D] = delta + p0[D]; am[D] = -delta + p0[D]; }
     else { b[D] = delta + p1[D]; bm[D] = -delta + p1[D]; }
-    const double ep = meas - w3_norm_plain(a[0] - b[0], a[1] - b[1], a[2] - b[2]);
-    const double em = meas - w3_norm_plain(am[0] - bm[0], am[1] - bm[1], am[2] - bm[2]);
+    const double xp = w3_sq_plain(a[0] - b[0], a[1] - b[1], a[2] - b[2]), xm = w3_sq_plain(am[0] - bm[0], am[1] - bm[1], am[2] - bm[2]);
+    const double ep = meas - (NEAR ? sqrt_ieee_near(xp, n0, h0) : sqrt_ieee_unscaled(xp));
+    const double em = meas - (NEAR ? sqrt_ieee_near(xm, n0, h0) : sqrt_ieee_unscaled(xm));
     double bak = ep;
     bak -= em;
     return scalar * bak;
@@ -160,7 +162,7 @@ __device__ __forceinline__ void w3_edge(const W3Lds& l, const double* T, const W
     const double m1[3] = {s1[0], s1[1], s1[2]};
     const double p1[3] = {v1 >= 0 ? m1[0] : E.fx, v1 >= 0 ? m1[1] : E.fy, v1 >= 0 ? m1[2] : E.fz};
     double u[3] = {p0[0] - p1[0], p0[1] - p1[1], p0[2] - p1[2]};
-    double err, inv = 0.0;
+    double err, inv = 0.0, x0 = 0.0, n0 = 0.0, h0 = 0.0;
     if (JAC == 0) {
         const double x = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
         double n;
@@ -168,7 +170,9 @@ __device__ __forceinline__ void w3_edge(const W3Lds& l, const double* T, const W
         if (!(x > 0.0)) { n = 0.0; inv = 0.0; }   // coincident endpoints: J = 0, what the central difference gives
         err = meas - n;
     } else {
-        err = meas - w3_norm_plain(u[0], u[1], u[2]);
+        x0 = w3_sq_plain(u[0], u[1], u[2]);
+        n0 = sqrt_ieee_unscaled_h(x0, h0);
+        err = meas - n0;
     }
     const double chi = err * (info * err);
     const double aux = 1.0 + chi;
@@ -181,12 +185,21 @@ __device__ __forceinline__ void w3_edge(const W3Lds& l, const double* T, const W
             J0[0] = -u[0]; J0[1] = -u[1]; J0[2] = -u[2];
             J1[0] = u[0]; J1[1] = u[1]; J1[2] = u[2];
         } else {
-            J0[0] = w3_jac_numeric<0>(p0, p1, 0, meas);
-            J0[1] = w3_jac_numeric<1>(p0, p1, 0, meas);
-            J0[2] = w3_jac_numeric<2>(p0, p1, 0, meas);
-            J1[0] = w3_jac_numeric<0>(p0, p1, 1, meas);
-            J1[1] = w3_jac_numeric<1>(p0, p1, 1, meas);
-            J1[2] = w3_jac_numeric<2>(p0, p1, 1, meas);
+            if (x0 >= 1e-5 && x0 < 1e300) {   // endpoints more than ~3 mm apart
+                J0[0] = w3_jac_numeric<0, true>(p0, p1, 0, meas, n0, h0);
+                J0[1] = w3_jac_numeric<1, true>(p0, p1, 0, meas, n0, h0);
+                J0[2] = w3_jac_numeric<2, true>(p0, p1, 0, meas, n0, h0);
+                J1[0] = w3_jac_numeric<0, true>(p0, p1, 1, meas, n0, h0);
+                J1[1] = w3_jac_numeric<1, true>(p0, p1, 1, meas, n0, h0);
+                J1[2] = w3_jac_numeric<2, true>(p0, p1, 1, meas, n0, h0);
+            } else {
+                J0[0] = w3_jac_numeric<0, false>(p0, p1, 0, meas, n0, h0);
+                J0[1] = w3_jac_numeric<1, false>(p0, p1, 0, meas, n0, h0);
+                J0[2] = w3_jac_numeric<2, false>(p0, p1, 0, meas, n0, h0);
+                J1[0] = w3_jac_numeric<0, false>(p0, p1, 1, meas, n0, h0);
+                J1[1] = w3_jac_numeric<1, false>(p0, p1, 1, meas, n0, h0);
+                J1[2] = w3_jac_numeric<2, false>(p0, p1, 1, meas, n0, h0);
+            }
         }
         const double wr = info * fast_rcp(aux), wre = -wr * err;
         const bool c0 = v1 >= 0 && v1 == v0 - 1, c1 = v0 == v1 - 1;   // the endpoint that is the later pose of a consecutive pair keeps the coupling block
