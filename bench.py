@@ -491,8 +491,63 @@ def leg_cfg1_node(D, args):
     out["value"] = out["reference_config"]["ms_per_message_median"]
     out["value_note"] = ("the loc_node_add_range call of a message that triggers a solve, host buffers in, poses out (PCIe inclusive), in the REFERENCE's configuration "
                          "(numeric Jacobians); the kernel is wave3_lm_kernel (one wave per window) whenever the window is translation-only, as this recording's is")
+    # the same recording with cfg/uwb_imu.yaml's parameters: IMU orientation priors interleaved in recorded order + an antenna lever arm
+    # (6-DoF windows of 12 poses: wave6_lm_kernel)
+    kw_imu = dict(trajectory_length=12, maximum_velocity=3.0, distance_outlier=3.0, maximum_iteration=10, minimum_optimize_error=1000.0,
+                  publish_range=True, publish_imu=False)
+    ant_imu = [[0.05, 0.0, -0.02]] * 3
+    ev = [(float(t), 0, i) for i, t in enumerate(bag["uwb_rectime"])] + [(float(t), 1, i) for i, t in enumerate(bag["imu_rectime"]) if t <= bag["uwb_rectime"][-1]]
+    ev.sort()
+    imu_st = [float(x) for x in bag["imu_stamp"]]
+    imu_q = np.ascontiguousarray(bag["imu_q_xyzw"], dtype=np.float64)
+    imu_cov = np.ascontiguousarray(np.stack([np.diag(c).ravel() for c in bag["imu_orientation_cov_diag"]]), dtype=np.float64)
+
+    def replay_imu(add_range, add_imu):
+        call, xyz = [], []
+        for _, kind, i in ev:
+            if kind == 0:
+                t0 = time.perf_counter()
+                solved, p = add_range(i)
+                dt = time.perf_counter() - t0
+                if solved:
+                    call.append(dt * 1e3); xyz.append(p)
+            else:
+                add_imu(i)
+        return np.array(call[20:]), np.array(xyz)
+
+    node = la.LocalizationNode(ids, pos, jacobian="numeric", device=D.local_rank, antenna_offsets=ant_imu, **kw_imu)
+    L, h, o = node.L, node.h, NodeOutput()
+    ref = C.byref(o)
+    dp = C.POINTER(C.c_double)
+    frame_imu = b"imu_link"
+
+    def g_range(i):
+        if L.loc_node_add_range(h, 200, resp[i], st[i], dist[i], derr[i], ant[i], fr, ref) < 0:
+            raise RuntimeError(L.loc_last_error().decode(errors="replace"))
+        return bool(o.solved), list(o.realtime[1:4])
+
+    def g_imu(i):
+        if L.loc_node_add_imu(h, imu_st[i], imu_q[i].ctypes.data_as(dp), imu_cov[i].ctypes.data_as(dp), frame_imu, ref) < 0:
+            raise RuntimeError(L.loc_last_error().decode(errors="replace"))
+    c_imu, xyz_imu = replay_imu(g_range, g_imu)
+    pt = node.last_timing()
+    node.close()
+    out["uwb_imu"] = {"workload": "cfg/uwb_imu.yaml on the same recording: 12-pose 6-DoF window, IMU orientation priors, antenna lever arm; numeric Jacobians",
+                      "solves": int(len(c_imu) + 20), "ms_per_message_median": float(np.median(c_imu)), "p99": float(np.percentile(c_imu, 99)),
+                      "last_solve_inside_library": {"pack_host": pt[0], "window_solve_call": pt[1], "of_which_kernel": pt[2]}}
     if not args.no_cpu_baseline:
         from oracle import oracle as O
+        ora_imu = O.LocalizationOracle(ids, pos, jac_mode=O.JAC_NUMERIC_G2O, antenna_offsets=ant_imu, **kw_imu)
+
+        def o_range(i):
+            r = ora_imu.add_range(200, resp[i], st[i], dist[i], derr[i], ant[i], "uwb")
+            return r["solved"], list(r["realtime"][1:4])
+        oc_imu, oxyz_imu = replay_imu(o_range, lambda i: ora_imu.add_imu(imu_st[i], imu_q[i], imu_cov[i], "imu_link"))
+        n = min(len(oxyz_imu), len(xyz_imu))
+        out["uwb_imu"]["cpu_baseline"] = {"value": float(np.median(oc_imu)), "unit": "ms", "cores": 1, "kind": "port",
+                                          "sample": "the same messages through oracle/localization_oracle.c, numeric Jacobians, one thread",
+                                          "median_abs_diff_vs_gpu_m": float(np.median(np.abs(oxyz_imu[:n] - xyz_imu[:n]).max(axis=1))),
+                                          "max_abs_diff_vs_gpu_m": float(np.abs(oxyz_imu[:n] - xyz_imu[:n]).max())}
         ora = O.LocalizationOracle(ids, pos, jac_mode=O.JAC_NUMERIC_G2O, **kw)
         oc, oxyz = [], []
         for i in range(n_msg):

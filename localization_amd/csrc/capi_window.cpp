@@ -602,8 +602,10 @@ static int batch_topology(loc_window* w, int which, int64_t n, const int32_t* co
                           const int32_t* p_idx, const double* p_val, const int32_t* s_idx) {
     const locamd::WindowCaps& c = w->caps;
     bool chain = true;
+    bool single_pairs = true;   // no EdgeSE3 anywhere and at most one range edge per pair of consecutive poses (wave6_lm_kernel's rank-1 couplings)
     for (int64_t i = 0; i < n && chain; ++i) {
         const int32_t* cn = counts + i * 4;
+        if (cn[3] != 0) single_pairs = false;
         int last = 0;
         for (int e = 0; e < cn[3]; ++e) {   // EdgeSE3 factors: between consecutive poses, ordered by their later pose (addTwistEdge)
             const int32_t* ix = s_idx + ((size_t)i * c.ns_max + e) * 4;
@@ -612,10 +614,12 @@ static int batch_topology(loc_window* w, int which, int64_t n, const int32_t* co
             last = key;
         }
         last = 0;
+        int last_pair = -1;
         for (int e = 0; e < cn[1] && chain; ++e) {
             const int32_t* ix = r_idx + ((size_t)i * c.nr_max + e) * 2;
             const int key = ix[1] > ix[0] ? ix[1] : ix[0];
             if (key < last) chain = false;
+            if (ix[1] >= 0) { if (key == last_pair) single_pairs = false; last_pair = key; }
             last = key;
             if (ix[1] >= 0 && ix[0] - ix[1] != 1 && ix[1] - ix[0] != 1) chain = false;
         }
@@ -626,7 +630,10 @@ static int batch_topology(loc_window* w, int which, int64_t n, const int32_t* co
             last = v;
         }
     }
-    if (chain) return translation_only(w, n, counts, poses, r_val, p_val) ? LOC_WINDOW_KERNEL_CHAIN3 : LOC_WINDOW_KERNEL_CHAIN;
+    if (chain) {
+        if (translation_only(w, n, counts, poses, r_val, p_val)) return LOC_WINDOW_KERNEL_CHAIN3;
+        return (single_pairs && c.nv_max <= 64 && locamd::window_wave6_lds_bytes(c) <= locamd::kWave6MaxLds) ? LOC_WINDOW_KERNEL_WAVE6 : LOC_WINDOW_KERNEL_CHAIN;
+    }
     {
         // (LOCAMD_ARROW3: 0 = never, 1 = whenever the batch qualifies; default: windows of more than 64 poses — below that the
         //  wave-per-window kernel keeps everything in LDS and is the better choice)
@@ -646,6 +653,14 @@ static int batch_topology(loc_window* w, int which, int64_t n, const int32_t* co
 static int pick_kernel(const loc_window* w, int64_t n, int topology) {
     const long long mn = w->chain_min >= 0 ? w->chain_min : chain_min_batch();
     if (w->has_off1) return LOC_WINDOW_KERNEL_GENERAL;   // (lever arms on endpoint 1: only the general kernel evaluates them)
+    if (topology == LOC_WINDOW_KERNEL_WAVE6) {
+        // a 6-DoF chain batch that also qualifies for wave6_lm_kernel: one lane per window from the chain threshold on, one wave per
+        // window with rank-1 couplings below it (LOCAMD_WAVE6=0: the general kernel, for A/B runs)
+        if (mn <= 0 || w->natural_order) return LOC_WINDOW_KERNEL_GENERAL;
+        if (n >= mn) return LOC_WINDOW_KERNEL_CHAIN;
+        const char* v = getenv("LOCAMD_WAVE6");
+        return (v && v[0] == '0') ? LOC_WINDOW_KERNEL_GENERAL : LOC_WINDOW_KERNEL_WAVE6;
+    }
     if (topology == LOC_WINDOW_KERNEL_ARROW3) return w->natural_order ? LOC_WINDOW_KERNEL_GENERAL : LOC_WINDOW_KERNEL_ARROW3;   // (one wave per window: any batch size)
     if (topology == LOC_WINDOW_KERNEL_TREE) return (w->natural_order || n < tree_min_batch(w)) ? LOC_WINDOW_KERNEL_GENERAL : LOC_WINDOW_KERNEL_TREE;
     if (topology == LOC_WINDOW_KERNEL_CHAIN3 && mn > 0 && !w->natural_order && w->caps.nv_max <= 64 && locamd::window_wave3_lds_bytes(w->caps) <= 64 * 1024) {
@@ -697,6 +712,7 @@ static hipError_t launch_any(loc_window* w, int which, const locamd::WindowArgs&
         return locamd::launch_window_chain3(a, w->d_chain3_ws, st);
     }
     if (kind == LOC_WINDOW_KERNEL_WAVE3) return locamd::launch_window_wave3(a, st);
+    if (kind == LOC_WINDOW_KERNEL_WAVE6) return locamd::launch_window_wave6(a, st);
     if (kind == LOC_WINDOW_KERNEL_GENERAL) return locamd::launch_window(a, st);
     if (!w->d_chain_ws) {
         hipError_t e = hipMalloc((void**)&w->d_chain_ws, locamd::window_chain_workspace_doubles(w->caps, w->B) * sizeof(double));
@@ -779,7 +795,7 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
             // writes 1 KB of results — it does so straight from / to the page-locked staging block (host-coherent memory, mapped
             // into the device's address space), which saves the two DMA operations around a ~75 us kernel.
             const size_t anchor_bytes = (size_t)w->n_anchors * 3 * sizeof(double);
-            const bool zero_copy = kind == LOC_WINDOW_KERNEL_WAVE3 && n <= 4 && w->B <= 4 && w->h_anchors.size() == (size_t)w->n_anchors * 3 &&
+            const bool zero_copy = (kind == LOC_WINDOW_KERNEL_WAVE3 || kind == LOC_WINDOW_KERNEL_WAVE6) && n <= 4 && w->B <= 4 && w->h_anchors.size() == (size_t)w->n_anchors * 3 &&
                                    off[9] + anchor_bytes <= kStageBytes && !getenv("LOCAMD_NO_ZERO_COPY");
             if (zero_copy) {
                 d = h;

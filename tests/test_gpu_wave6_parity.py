@@ -1,0 +1,169 @@
+"""GPU parity of wave6_lm_kernel (wave6_kernel.hip) — 6-DoF chain windows, one WAVE per window: what the drop-in node's own solve
+takes when the poses turn (cfg/uwb_imu.yaml: IMU orientation priors, an antenna lever arm; cfg/uwb_imu_lidar.yaml: a second prior per
+pose) and small batches of such windows — against the oracle, against the general wave-per-window kernel on the same batches, and
+the selection rules.
+
+Tolerances as for the other window kernels: analytic 1e-7 m / rad on every pose entry, numeric (delta = 1e-9) 3e-5."""
+import os
+
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation
+
+from test_gpu_window_parity import ANCH, _random_window
+
+pytestmark = pytest.mark.gpu
+
+
+def _copy_batch(la, wb):
+    out = la.WindowBatch(wb.B, *wb.caps)
+    for name in ("counts", "poses", "r_idx", "r_val", "p_idx", "p_val", "s_idx", "s_val"):
+        getattr(out, name)[:] = getattr(wb, name)
+    return out
+
+
+def _chain_batch(la, rng, B, T, with_imu, lever, lidar=False):
+    """Windows in the reference's creation order (a pose's anchor range, then its smoothness edge to the previous pose), ragged
+    lengths, some with a missing link; IMU rotation priors, optionally a lidar-style z prior as a second prior of every other pose."""
+    nr_max, np_max = max(2 * T + 2, 4), ((2 * T if lidar else T) if with_imu else 0)
+    wb = la.WindowBatch(B, T, nr_max, np_max, 0)
+    for i in range(B):
+        Ti = T if i % 7 else max(T // 2, 1)
+        est_t, est_R, off, ranges, smooth, priors, _ = _random_window(rng, Ti, with_imu, False, lever)
+        for k in range(Ti):
+            wb.add_pose(i, est_t[k], est_R[k])
+        for k in range(Ti):
+            for (kk, a, d, info) in ranges:
+                if kk == k: wb.add_range(i, k, a, d, info, off, anchor=True)
+            for (k0, k1, d, info) in smooth:
+                if k1 == k and not (i % 5 == 2 and k == 3):   # (some windows miss a link: two independent chains)
+                    if i % 3 == 1: wb.add_range(i, k1, k0, d, info)   # (stored the other way round)
+                    else: wb.add_range(i, k0, k1, d, info)
+        for (k, t, R, dg) in priors:
+            wb.add_prior(i, k, t, R, dg)
+            if lidar and k % 2 == 0:   # addLidarEdge: z prior, information only on (2, 2), measurement = the pose with another z
+                wb.add_prior(i, k, np.array([est_t[k, 0], est_t[k, 1], est_t[k, 2] + rng.normal(0, 0.02)]), est_R[k], np.array([0, 0, 1 / 0.05, 0, 0, 0.0]))
+    return wb
+
+
+@pytest.mark.parametrize("T,with_imu,lever,jac,lidar", [
+    (12, True, True, "analytic", False),    # cfg/uwb_imu.yaml's window: IMU priors, lever arm
+    (12, True, True, "numeric", False),     # ... in the reference's Jacobian mode
+    (10, False, True, "analytic", False),   # a lever arm alone makes the poses turn
+    (1, True, True, "numeric", False),      # a lone pose
+    (20, True, True, "numeric", True),      # cfg/uwb_imu_lidar.yaml: two priors per pose; two groups of 32 lanes
+    (40, True, False, "analytic", False),   # one group: every lane a pose or idle
+    (64, True, True, "analytic", False),    # every lane a pose, three passes over the edges (91 KB of LDS per window)
+])
+def test_wave6_kernel_matches_oracle_and_general_kernel(gpu, T, with_imu, lever, jac, lidar):
+    import localization_amd as la
+    from oracle import oracle as O
+    from _oracle_window import oracle_solve_instance
+    B = 70 if T < 40 else 20
+    rng = np.random.default_rng(3000 + 10 * T + len(jac))
+    wb = _chain_batch(la, rng, B, T, with_imu, lever, lidar)
+    wb.counts[3, 1:] = 0   # an instance whose poses have no edge at all: comes back untouched
+    before = wb.poses.copy()
+    mode = O.JAC_ANALYTIC if jac == "analytic" else O.JAC_NUMERIC_G2O
+    want = [oracle_solve_instance(wb, i, ANCH, jac_mode=mode) for i in range(B)]
+    ref = _copy_batch(la, wb)
+    general = la.WindowSolver(ANCH, B, *wb.caps, jacobian=jac, chain_threshold=0)
+    res_general = general.solve(ref).copy()
+    assert general.last_kernel_kind() == "window_lm_kernel"
+    general.close()
+    s = la.WindowSolver(ANCH, B, *wb.caps, jacobian=jac)       # default thresholds: a small batch
+    res = s.solve(wb).copy()
+    assert s.last_kernel_kind() == "wave6_lm_kernel"
+    tol = 1e-7 if jac == "analytic" else 3e-5
+    same_it = 0
+    for i in range(B):
+        nv = int(wb.counts[i, 0])
+        if nv == 0 or wb.counts[i, 1] + wb.counts[i, 2] == 0:
+            assert np.array_equal(wb.poses[i, :nv], before[i, :nv]) and res[i, 4] == 0
+            same_it += 1
+            continue
+        poses, chi, st = want[i]
+        d = np.abs(wb.poses[i, :nv] - poses).max()
+        dg = np.abs(ref.poses[i, :nv] - poses).max()
+        assert d < tol or (jac == "numeric" and d < max(2 * dg, tol) and d < 1e-3), (i, d, dg)
+        assert abs(res[i, 0] - chi) <= (1e-6 if jac == "analytic" else 1e-4) * max(1.0, abs(chi)), (i, res[i, 0], chi)
+        assert res[i, 7] == nv * 65536 + 2 * nv - 1
+        same_it += res[i, 3] == st.outer_iterations
+    assert same_it >= 0.9 * B or T == 1
+    assert np.abs(wb.poses - ref.poses).max() < (tol if jac == "analytic" else 1e-3)
+    if T > 1:
+        assert (res[:, 4] != res_general[:, 4]).mean() < 0.06   # LM trial counts
+    # the same window in another workgroup: the same bits; resident API: the same answer again
+    wb2 = _copy_batch(la, wb); wb2.poses[:] = before
+    wb2.poses[5] = before[1]
+    for name in ("counts", "r_idx", "r_val", "p_idx", "p_val"):
+        getattr(wb2, name)[5] = getattr(wb2, name)[1]
+    s.upload(wb2); s.solve_resident(); s.download(wb2)
+    assert s.last_kernel_kind() == "wave6_lm_kernel"
+    n1 = int(wb.counts[1, 0])
+    assert np.array_equal(wb2.poses[5, :n1], wb.poses[1, :n1]) and np.array_equal(wb2.result[5], res[1])
+    for i in range(B):
+        if i != 5:
+            nv = int(wb.counts[i, 0])
+            assert np.array_equal(wb2.poses[i, :nv], wb.poses[i, :nv]) and np.array_equal(wb2.result[i], res[i]), i
+    s.close()
+
+
+def test_wave6_failed_cholesky_like_g2o(gpu):
+    """A window whose every range has zero information and that has no prior (H = 0, lambda_0 = 0: the factorisation fails in every
+    trial): 10 trials, 1 outer iteration, terminated, poses untouched — next to healthy windows of the same launch."""
+    import localization_amd as la
+    from _oracle_window import oracle_solve_instance
+    rng = np.random.default_rng(9)
+    B, T = 5, 6
+    wb = _chain_batch(la, rng, B, T, False, True)
+    wb.r_val[2, :, 1] = 0.0
+    before = wb.poses.copy()
+    want = [oracle_solve_instance(wb, i, ANCH) for i in range(B)]
+    s = la.WindowSolver(ANCH, B, *wb.caps, jacobian="analytic")
+    res = s.solve(wb).copy()
+    assert s.last_kernel_kind() == "wave6_lm_kernel"
+    s.close()
+    assert res[2, 5] == 1 and res[2, 4] == 10 and res[2, 3] == 1 and np.array_equal(wb.poses[2], before[2])
+    assert want[2][2].terminated == 1 and want[2][2].lm_trials == 10
+    for i in (0, 1, 3, 4):
+        nv = int(wb.counts[i, 0])
+        assert np.abs(wb.poses[i, :nv] - want[i][0]).max() < 1e-7
+
+
+def test_wave6_selection_rules(gpu):
+    import localization_amd as la
+    rng = np.random.default_rng(5)
+    B, T = 16, 6
+    base = _chain_batch(la, rng, B, T, True, True)
+    caps = (T, 2 * T + 2, T, 1)
+    wbase = la.WindowBatch(B, *caps)
+    for name in ("counts", "poses", "r_idx", "r_val", "p_idx", "p_val"):
+        getattr(wbase, name)[:] = getattr(base, name)
+    s = la.WindowSolver(ANCH, B, *caps, jacobian="analytic")
+
+    def kind(mut):
+        wb = _copy_batch(la, wbase)
+        mut(wb)
+        s.solve(wb)
+        return s.last_kernel_kind()
+
+    assert kind(lambda wb: None) == "wave6_lm_kernel"
+
+    def doubled(wb): wb.add_range(9, 2, 1, 0.02, 10.0)                        # a second edge on one pair of consecutive poses — not in creation order either
+    def doubled_in_order(wb):                                                  # ... and one that keeps the chain order (the last pose's anchor range becomes a second smoothness edge)
+        n = int(wb.counts[9, 1]); wb.r_idx[9, n - 2] = wb.r_idx[9, n - 1]
+    def se3(wb): wb.add_se3(4, 1, 2, np.zeros(3), np.eye(3), np.eye(6), True)  # an EdgeSE3 (twist / pose factors)
+    def far_pair(wb): wb.r_idx[11, int(wb.counts[11, 1]) - 1] = (4, 1)        # not a chain
+    for mut in (doubled, doubled_in_order, se3, far_pair):
+        assert kind(mut) == "window_lm_kernel", mut.__name__
+    os.environ["LOCAMD_WAVE6"] = "0"
+    try:
+        assert kind(lambda wb: None) == "window_lm_kernel"
+    finally:
+        del os.environ["LOCAMD_WAVE6"]
+    s.L.loc_window_set_chain_threshold(s.h, 0)                                # 0: never anything but the general kernel
+    assert kind(lambda wb: None) == "window_lm_kernel"
+    s.L.loc_window_set_chain_threshold(s.h, 8)                                # a batch of 16 is then large enough for one lane per window
+    assert kind(lambda wb: None) == "chain_lm_kernel"
+    s.close()
