@@ -664,15 +664,15 @@ static int pick_kernel(const loc_window* w, int64_t n, int topology) {
     if (topology == LOC_WINDOW_KERNEL_ARROW3) return w->natural_order ? LOC_WINDOW_KERNEL_GENERAL : LOC_WINDOW_KERNEL_ARROW3;   // (one wave per window: any batch size)
     if (topology == LOC_WINDOW_KERNEL_TREE) return (w->natural_order || n < tree_min_batch(w)) ? LOC_WINDOW_KERNEL_GENERAL : LOC_WINDOW_KERNEL_TREE;
     if (topology == LOC_WINDOW_KERNEL_CHAIN3 && mn > 0 && !w->natural_order && w->caps.nv_max <= 64 && locamd::window_wave3_lds_bytes(w->caps) <= 64 * 1024) {
-        // translation-only chains of <= 64 poses below the lane-per-window batch sizes (the node's single window first of all): one
-        // wave per window with 3x3 blocks.  Measured on ten-pose windows: 2.4e7 windows/s from ~4 096 windows on, against chain3's
-        // ~1.1 ms for any batch up to 16 384 — the lane-per-window kernel takes over at 32 768 windows (an explicit threshold moves
-        // that point).  LOCAMD_WAVE3=0 / LOCAMD_CHAIN3=0: no such kernel (A/B runs, tests).
+        // translation-only chains of <= 64 poses (the node's single window first of all): one wave per window with 3x3 blocks, rank-1
+        // couplings and speculative LM trials.  Measured on ten-pose windows: 0.056 ms for one window, 3.6e7 windows/s (numeric) /
+        // 4.0e7 (analytic) from ~8 000 windows on — level with chain3_lm_kernel at 65 536 windows, ahead of it everywhere else — so by
+        // default it takes every batch; an explicit threshold (loc_window_set_chain_threshold / LOCAMD_CHAIN_MIN_BATCH) hands batches
+        // from that size on to the lane-per-window kernel.  LOCAMD_WAVE3=0 / LOCAMD_CHAIN3=0: no such kernel (A/B runs, tests).
         const bool default_rule = w->chain_min < 0 && !getenv("LOCAMD_CHAIN_MIN_BATCH");
         const char* v = getenv("LOCAMD_WAVE3");
         const char* v3 = getenv("LOCAMD_CHAIN3");
-        if (n < (default_rule ? 32768 : mn) && !(v && v[0] == '0') && !(v3 && v3[0] == '0')) return LOC_WINDOW_KERNEL_WAVE3;
-        if (default_rule && n >= 32768 && !(v3 && v3[0] == '0')) return LOC_WINDOW_KERNEL_CHAIN3;
+        if ((default_rule || n < mn) && !(v && v[0] == '0') && !(v3 && v3[0] == '0')) return LOC_WINDOW_KERNEL_WAVE3;
     }
     if (topology == LOC_WINDOW_KERNEL_CHAIN3 && mn > 0 && !w->natural_order && w->chain_min < 0 && !getenv("LOCAMD_CHAIN_MIN_BATCH") && n >= 4096 && n < mn) {
         // the translation-only kernel is worth it from ~4 096 windows on (it takes ~1 ms for any batch up to 16 384, the wave-per-window

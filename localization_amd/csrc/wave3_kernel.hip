@@ -413,52 +413,109 @@ __global__ void __launch_bounds__(64, 3) wave3_lm_kernel(const WindowArgs a) {
 #pragma unroll
         for (int g = 1; g < 4; ++g) { lamv[g] = lamv[g - 1] * niv[g - 1]; niv[g] = 2.0 * niv[g - 1]; }   // (a rejected trial: lambda *= ni, ni *= 2)
         const double mylam = grp == 0 ? lamv[0] : (grp == 1 ? lamv[1] : (grp == 2 ? lamv[2] : lamv[3]));
-        // forward sweep.  Step p needs pose p-1's factor: every lane takes its left neighbour's (G, y) through DPP and redoes its own
-        // 3x3 step each repetition — after repetition r the lanes of poses 0 .. r hold their final values (a lane whose inputs are
-        // final recomputes the same numbers), so nv repetitions factor the chain; all G groups ride in the same instructions.
-        double g10 = 0.0, g20 = 0.0, g21 = 0.0, ig[3] = {0.0, 0.0, 0.0}, y[3] = {0.0, 0.0, 0.0};   // this pose's factor (strict lower part, inverse pivots), y
+        // The solve.  rank1 (every coupling H_p,p-1 = u_p v_p^T): the Schur complement of pose p is S_p = A_p - alpha_p u_p u_p^T with
+        // A_p = H_pp + lambda I and the SCALAR alpha_p = v_p^T S_{p-1}^-1 v_p, its right-hand side b_p - beta_p u_p with
+        // beta_p = v_p^T S_{p-1}^-1 (b_{p-1} - beta_{p-1} u_{p-1}).  Sherman-Morrison gives S_p^-1 from A_p^-1:
+        //   S^-1 = A^-1 + k (A^-1 u)(A^-1 u)^T,  k = alpha / den,  den = 1 - alpha u^T A^-1 u   (S positive definite <=> A is and den > 0)
+        // so everything that needs a 3x3 factorisation — A_p = G G^T, A^-1 u, A^-1 v, A^-1 b and their five dot products — is done by ALL
+        // poses AT ONCE, and the sequential part of the block-tridiagonal elimination shrinks to a recurrence on two scalars per pose
+        // (forward: alpha, beta; backward: gamma = u_{p+1} . x_{p+1}).  Each repetition every lane takes its neighbour's scalars through
+        // DPP and redoes its own step: after repetition r the poses 0 .. r hold final values (a lane whose inputs are final recomputes
+        // the same numbers); all G groups ride in the same instructions.
+        double Xn[3] = {0.0, 0.0, 0.0};
+        unsigned long long bad = 0ull;
         if (rank1) {
-            // H_p,p-1 = u v^T: W W^T = (z.z) u u^T and W y_{p-1} = (z.y_{p-1}) u with z = G_{p-1}^-1 v, which pose p - 1 computes itself
-            double al = 0.0, be = 0.0;
-            for (int r = 0; r < nv; ++r) {
-                const double pal = w3_from_prev(al), pbe = w3_from_prev(be);
+            double pA[3] = {0.0, 0.0, 0.0}, qA[3] = {0.0, 0.0, 0.0}, rA[3] = {0.0, 0.0, 0.0};   // A^-1 u, A^-1 v_next, A^-1 b
+            double uu = 0.0, uv = 0.0, vvq = 0.0, ub = 0.0, vb = 0.0;
+            bool piv_ok = true;
+            if (pose) {
+                double A[3][3], ig[3];
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr) {
+#pragma unroll
+                    for (int c = 0; c <= rr; ++c) A[rr][c] = D[rr * (rr + 1) / 2 + c];
+                    A[rr][rr] += mylam;
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const double g = w3_pivot_rsqrt(A[j][j]);
+                    ig[j] = g;
+#pragma unroll
+                    for (int i2 = j + 1; i2 < 3; ++i2) A[i2][j] *= g;
+#pragma unroll
+                    for (int i2 = j + 1; i2 < 3; ++i2)
+#pragma unroll
+                        for (int cc = j + 1; cc <= i2; ++cc) A[i2][cc] = __builtin_fma(-A[i2][j], A[cc][j], A[i2][cc]);
+                }
+                piv_ok = (ig[0] + ig[1]) + ig[2] < DBL_MAX;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { pA[k] = u[k]; qA[k] = vnext[k]; rA[k] = b[k]; }
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) {
+                    pA[cc] *= ig[cc]; qA[cc] *= ig[cc]; rA[cc] *= ig[cc];
+#pragma unroll
+                    for (int c2 = cc + 1; c2 < 3; ++c2) {
+                        pA[c2] = __builtin_fma(-pA[cc], A[c2][cc], pA[c2]);
+                        qA[c2] = __builtin_fma(-qA[cc], A[c2][cc], qA[c2]);
+                        rA[c2] = __builtin_fma(-rA[cc], A[c2][cc], rA[c2]);
+                    }
+                }
+#pragma unroll
+                for (int cc = 2; cc >= 0; --cc) {
+                    double a0 = pA[cc], a1 = qA[cc], a2 = rA[cc];
+#pragma unroll
+                    for (int c2 = cc + 1; c2 < 3; ++c2) {
+                        a0 = __builtin_fma(-A[c2][cc], pA[c2], a0);
+                        a1 = __builtin_fma(-A[c2][cc], qA[c2], a1);
+                        a2 = __builtin_fma(-A[c2][cc], rA[c2], a2);
+                    }
+                    pA[cc] = a0 * ig[cc]; qA[cc] = a1 * ig[cc]; rA[cc] = a2 * ig[cc];
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    uu = __builtin_fma(u[k], pA[k], uu); uv = __builtin_fma(u[k], qA[k], uv); vvq = __builtin_fma(vnext[k], qA[k], vvq);
+                    ub = __builtin_fma(u[k], rA[k], ub); vb = __builtin_fma(vnext[k], rA[k], vb);
+                }
+            }
+            W3_T(3);
+            double bin = 0.0, kk = 0.0, rden = 1.0, den = 1.0;
+            {
+                double al = 0.0, be = 0.0;
+                for (int r = 0; r < nv; ++r) {
+                    const double pal = w3_from_prev(al), pbe = w3_from_prev(be);
+                    if (pose) {
+                        bin = pbe;
+                        den = __builtin_fma(-pal, uu, 1.0);
+                        rden = fast_rcp(den);
+                        kk = pal * rden;
+                        const double kuv = kk * uv;
+                        al = __builtin_fma(kuv, uv, vvq);
+                        be = __builtin_fma(kuv, __builtin_fma(-pbe, uu, ub), __builtin_fma(-pbe, uv, vb));
+                    }
+                }
+            }
+            // a group in which some A_p or some Schur complement is not positive definite (or not finite) has failed
+            bad = __ballot(pose && !(piv_ok && den > 0.0 && den < DBL_MAX));
+            {
+                double ga = 0.0, gin = 0.0, cfin = 0.0;
+                for (int r = 0; r < nv; ++r) {
+                    const double pga = w3_from_next(ga);
+                    if (pose) {
+                        gin = pga;
+                        cfin = __builtin_fma(-pga, uv, __builtin_fma(-bin, uu, ub));   // u^T A^-1 (b - beta u - gamma v)
+                        ga = cfin * rden;
+                    }
+                }
                 if (pose) {
-                    double A[3][3], rhs[3];
+                    const double cb = __builtin_fma(-kk, cfin, bin);   // x = A^-1 b - (beta - k c) A^-1 u - gamma A^-1 v
 #pragma unroll
-                    for (int rr = 0; rr < 3; ++rr) {
-#pragma unroll
-                        for (int c = 0; c <= rr; ++c) A[rr][c] = __builtin_fma(-pal, UU[rr * (rr + 1) / 2 + c], D[rr * (rr + 1) / 2 + c]);
-                        A[rr][rr] += mylam;
-                        rhs[rr] = __builtin_fma(-pbe, u[rr], b[rr]);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        const double g = w3_pivot_rsqrt(A[j][j]);
-                        ig[j] = g;
-#pragma unroll
-                        for (int i2 = j + 1; i2 < 3; ++i2) A[i2][j] *= g;
-#pragma unroll
-                        for (int i2 = j + 1; i2 < 3; ++i2)
-#pragma unroll
-                            for (int cc = j + 1; cc <= i2; ++cc) A[i2][cc] = __builtin_fma(-A[i2][j], A[cc][j], A[i2][cc]);
-                    }
-#pragma unroll
-                    for (int cc = 0; cc < 3; ++cc) {
-                        rhs[cc] *= ig[cc];
-#pragma unroll
-                        for (int c2 = cc + 1; c2 < 3; ++c2) rhs[c2] = __builtin_fma(-rhs[cc], A[c2][cc], rhs[c2]);
-                    }
-                    g10 = A[1][0]; g20 = A[2][0]; g21 = A[2][1];
-#pragma unroll
-                    for (int rr = 0; rr < 3; ++rr) y[rr] = rhs[rr];
-                    const double z0 = vnext[0] * ig[0];
-                    const double z1 = __builtin_fma(-z0, g10, vnext[1]) * ig[1];
-                    const double z2 = __builtin_fma(-z1, g21, __builtin_fma(-z0, g20, vnext[2])) * ig[2];
-                    al = __builtin_fma(z2, z2, __builtin_fma(z1, z1, z0 * z0));
-                    be = __builtin_fma(z2, y[2], __builtin_fma(z1, y[1], z0 * y[0]));
+                    for (int k = 0; k < 3; ++k) Xn[k] = __builtin_fma(-gin, qA[k], __builtin_fma(-cb, pA[k], rA[k]));
                 }
             }
         } else {
+            // windows with several edges on a pair of consecutive poses: 3x3 coupling blocks, the factor (G, y) of pose p - 1 handed to
+            // pose p through DPP the same way
+            double g10 = 0.0, g20 = 0.0, g21 = 0.0, ig[3] = {0.0, 0.0, 0.0}, y[3] = {0.0, 0.0, 0.0};   // this pose's factor (strict lower part, inverse pivots), y
             for (int r = 0; r < nv; ++r) {
                 const double pg10 = w3_from_prev(g10), pg20 = w3_from_prev(g20), pg21 = w3_from_prev(g21);
                 const double pig[3] = {w3_from_prev(ig[0]), w3_from_prev(ig[1]), w3_from_prev(ig[2])};
@@ -521,40 +578,11 @@ __global__ void __launch_bounds__(64, 3) wave3_lm_kernel(const WindowArgs a) {
                     for (int rr = 0; rr < 3; ++rr) y[rr] = rhs[rr];
                 }
             }
-        }
-        // a group whose factorisation met a pivot that is not positive and finite has failed
-        const unsigned long long bad = __ballot(pose && !((ig[0] + ig[1]) + ig[2] < DBL_MAX));
-        W3_T(3);
-#ifdef LOCAMD_WAVE3_TIMING
-        ++w3_ph[7];
-#endif
-        // back-substitution the same way, from the right neighbour: v = H_{p+1,p}^T x_{p+1}
-        double Xn[3] = {0.0, 0.0, 0.0}, vo[3] = {0.0, 0.0, 0.0};
-        if (rank1) {
-            double ga = 0.0;   // u . x of this pose, for the previous one: H_{p+1,p}^T x_{p+1} = v (u . x_{p+1})
-            for (int r = 0; r < nv; ++r) {
-                const double pga = w3_from_next(ga);
-                if (pose) {
-                    double t[3] = {y[0], y[1], y[2]};
-                    double z0 = (pga * vnext[0]) * ig[0];
-                    double z1 = __builtin_fma(-z0, g10, pga * vnext[1]);
-                    double z2 = __builtin_fma(-z0, g20, pga * vnext[2]);
-                    t[0] -= z0;
-                    z1 *= ig[1];
-                    z2 = __builtin_fma(-z1, g21, z2);
-                    t[1] -= z1;
-                    z2 *= ig[2];
-                    t[2] -= z2;
-                    Xn[2] = t[2] * ig[2];
-                    t[0] = __builtin_fma(-g20, Xn[2], t[0]);
-                    t[1] = __builtin_fma(-g21, Xn[2], t[1]);
-                    Xn[1] = t[1] * ig[1];
-                    t[0] = __builtin_fma(-g10, Xn[1], t[0]);
-                    Xn[0] = t[0] * ig[0];
-                    ga = __builtin_fma(u[2], Xn[2], __builtin_fma(u[1], Xn[1], u[0] * Xn[0]));
-                }
-            }
-        } else {
+                    // a group whose factorisation met a pivot that is not positive and finite has failed
+            bad = __ballot(pose && !((ig[0] + ig[1]) + ig[2] < DBL_MAX));
+            W3_T(3);
+            // back-substitution the same way, from the right neighbour: v = H_{p+1,p}^T x_{p+1}
+            double vo[3] = {0.0, 0.0, 0.0};
             for (int r = 0; r < nv; ++r) {
                 const double v[3] = {w3_from_next(vo[0]), w3_from_next(vo[1]), w3_from_next(vo[2])};
                 if (pose) {
@@ -584,7 +612,10 @@ __global__ void __launch_bounds__(64, 3) wave3_lm_kernel(const WindowArgs a) {
                     }
                 }
             }
-        }
+                }
+#ifdef LOCAMD_WAVE3_TIMING
+        ++w3_ph[7];
+#endif
         // x of a failed factorisation: g2o leaves its x alone, and LM applies that stale x all the same — the x of the
         // trial before, i.e. of the group before (group 0: of the trial consumed last)
         if (bad) {

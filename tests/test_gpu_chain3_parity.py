@@ -148,17 +148,17 @@ def test_chain3_is_taken_only_by_translation_only_batches(gpu):
     s.close()
 
 
-@pytest.mark.parametrize("kernel", ["chain3_lm_kernel", "chain_lm_kernel"])
+@pytest.mark.parametrize("kernel", ["wave3_lm_kernel", "chain3_lm_kernel", "chain_lm_kernel"])
 def test_lane_per_window_kernels_at_the_batch_size_that_selects_them(gpu, kernel):
-    """Ten-pose windows of cfg/uwb_only.yaml's topology at the batch sizes where the DEFAULT thresholds pick the lane-per-window
-    kernels (32 768 translation-only windows; 12 288 when the 3-DoF kernels are switched off), nothing is forced: same-mode parity on a
-    512-window sample, the cross-mode bound (analytic kernel vs the numeric oracle = the reference's configuration) on 2 048, and the
-    numeric kernel against the numeric oracle."""
+    """12 288 ten-pose windows of cfg/uwb_only.yaml's topology with the DEFAULT thresholds, no threshold forced: wave3_lm_kernel (what
+    such a batch takes), chain3_lm_kernel (with LOCAMD_WAVE3=0: what it took before, and what windows of more than 64 poses take) and
+    chain_lm_kernel (with the 3-DoF kernels switched off): same-mode parity on a 512-window sample, the cross-mode bound (analytic
+    kernel vs the numeric oracle = the reference's configuration) on 2 048, and the numeric kernel against the numeric oracle."""
     import sys
     import localization_amd as la
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "perf"))
     import bench_window as bw
-    B, n_distinct = (32768 if kernel == "chain3_lm_kernel" else 12288), 2048
+    B, n_distinct = 12288, 2048
     small, graphs, anchors, T = bw.build(n_distinct, "uwb_only", seed=99)
     wb = la.WindowBatch(B, *small.caps)
     for name in ("counts", "poses", "r_idx", "r_val", "p_idx", "p_val", "s_idx", "s_val"):
@@ -167,6 +167,8 @@ def test_lane_per_window_kernels_at_the_batch_size_that_selects_them(gpu, kernel
     poses0 = wb.poses.copy()
     if kernel == "chain_lm_kernel":
         os.environ["LOCAMD_CHAIN3"] = "0"
+    if kernel == "chain3_lm_kernel":
+        os.environ["LOCAMD_WAVE3"] = "0"
     try:
         out = {}
         for jac in ("analytic", "numeric"):
@@ -179,6 +181,7 @@ def test_lane_per_window_kernels_at_the_batch_size_that_selects_them(gpu, kernel
             assert np.array_equal(out[jac][:n_distinct], out[jac][n_distinct:2 * n_distinct])     # repeated windows, other lanes / waves: same bits
     finally:
         os.environ.pop("LOCAMD_CHAIN3", None)
+        os.environ.pop("LOCAMD_WAVE3", None)
     want_num = bw.oracle_time(graphs, anchors, T, 2048)[1]
     want_ana = bw.oracle_time(graphs, anchors, T, 512, analytic=True)[1]
     same = np.abs(out["analytic"][:512] - want_ana).max(axis=(1, 2))

@@ -61,7 +61,7 @@ def test_wave3_kernel_matches_6dof_oracle_and_general_kernel(gpu, T, jac, with_z
         assert res[i, 7] == nv * 65536 + 2 * nv - 1
         same_it += res[i, 3] == st.outer_iterations
     assert same_it >= 0.9 * B or T == 1   # (a lone well-observed pose converges early: g2o's Terminate is then a rounding-edge event)
-    assert np.abs(wb.poses - ref.poses).max() < (tol if jac == "analytic" or T < 64 else 1e-3)
+    assert np.abs(wb.poses - ref.poses).max() < (tol if jac == "analytic" or T < 64 else 2e-3)   # (both within 1e-3 of the oracle)
     assert np.array_equal(res[:, 6], res_general[:, 6])     # edges sharing their pair with another
     if T > 1:   # (a lone well-observed pose converges early: its remaining accept / reject decisions are taken on rounding-level chi differences)
         assert (res[:, 4] != res_general[:, 4]).mean() < 0.06

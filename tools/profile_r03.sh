@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round-3 rocprofv3 evidence on the GPU box:  tools/profile_r03.sh OUTDIR   (run from the repo root; summaries land in OUTDIR, copy them to profiles/)
 #   headline snapshot kernel (analytic = `value`, numeric = the reference's configuration), fusion kernel (both modes),
-#   chain3_lm_kernel (cfg1 windows, 65 536), wave3_lm_kernel (cfg1 windows, 8 192 = one GPU's share of the 8-GPU job, and the node's own
-#   one-window launches), arrow3_lm_kernel (cfg4: 128 and 1 024 hypotheses), tree_wave_kernel (cfg5, 16 384):
+#   wave3_lm_kernel (cfg1 windows: 65 536, 8 192 = one GPU's share of the 8-GPU job, and the node's own one-window launches),
+#   chain3_lm_kernel (the same 65 536 windows with LOCAMD_WAVE3=0), arrow3_lm_kernel (cfg4: 128 and 1 024 hypotheses), tree_wave_kernel (cfg5, 16 384):
 #   each --kernel-trace --stats once, then separate --pmc passes (never combined with a trace domain).
 set -eo pipefail
 OUT=$1
@@ -32,7 +32,9 @@ profile cfg3_analytic fusion_lm_kernel -- python3 $FUS
 profile cfg3_numeric fusion_lm_kernel -- python3 $FUS --jacobian numeric
 W="tests/perf/bench_window.py --reps 3 --no-latency --cpu-n 0"
 python3 $W --shape uwb_only --batch 65536 --tile 4096 --cache /tmp/wb_t10.npz --bw 1 > /dev/null
-profile cfg1_windows chain3_lm_kernel -- python3 $W --shape uwb_only --batch 65536 --cache /tmp/wb_t10.npz --bw 1
+profile cfg1_windows wave3_lm_kernel -- python3 $W --shape uwb_only --batch 65536 --cache /tmp/wb_t10.npz --bw 1
+# the lane-per-window kernel on the same batch (what windows of more than 64 poses take; LOCAMD_WAVE3=0 selects it here)
+LOCAMD_WAVE3=0 profile cfg1_windows_chain3 chain3_lm_kernel -- python3 $W --shape uwb_only --batch 65536 --cache /tmp/wb_t10.npz --bw 1
 python3 $W --shape uwb_only --batch 8192 --tile 4096 --cache /tmp/wb_t10_8k.npz --bw 1 --jacobian numeric > /dev/null
 profile cfg1_windows_8192_numeric wave3_lm_kernel -- python3 $W --shape uwb_only --batch 8192 --cache /tmp/wb_t10_8k.npz --bw 1 --jacobian numeric
 # the node's own launches (one ten-pose window per range message of the example recording): kernel trace only
