@@ -96,33 +96,34 @@ __device__ __forceinline__ void w6_mat_tvec(const double* A, const double* v, do
 #pragma unroll
     for (int i = 0; i < 3; ++i) o[i] = A[0 * 3 + i] * v[0] + A[1 * 3 + i] * v[1] + A[2 * 3 + i] * v[2];
 }
-// Eigen::Quaternion(Matrix3) — q = (w, x, y, z)
+// Eigen::Quaternion(Matrix3) — q = (w, x, y, z); the square root and its reciprocal from one v_rsq_f64 seed (device_math.h:
+// sqrt_and_rsqrt, 1e-16 / 4e-15 relative: the prior's error and Jacobian carry them at that level)
 __device__ __forceinline__ void w6_mat_to_quat(const double* R, double* q) {
-    double qw, qx, qy, qz;
-    double t = R[0] + R[4] + R[8];
+    double qw, qx, qy, qz, n, inv;
+    const double t = R[0] + R[4] + R[8];
     if (t > 0) {
-        t = sqrt(t + 1.0);
-        qw = 0.5 * t; t = 0.5 / t;
-        qx = (R[7] - R[5]) * t; qy = (R[2] - R[6]) * t; qz = (R[3] - R[1]) * t;
+        sqrt_and_rsqrt(t + 1.0, n, inv);
+        qw = 0.5 * n; inv *= 0.5;
+        qx = (R[7] - R[5]) * inv; qy = (R[2] - R[6]) * inv; qz = (R[3] - R[1]) * inv;
     } else if (R[0] >= R[4] && R[0] >= R[8]) {
-        t = sqrt(R[0] - R[4] - R[8] + 1.0);
-        qx = 0.5 * t; t = 0.5 / t;
-        qw = (R[7] - R[5]) * t; qy = (R[3] + R[1]) * t; qz = (R[6] + R[2]) * t;
+        sqrt_and_rsqrt(R[0] - R[4] - R[8] + 1.0, n, inv);
+        qx = 0.5 * n; inv *= 0.5;
+        qw = (R[7] - R[5]) * inv; qy = (R[3] + R[1]) * inv; qz = (R[6] + R[2]) * inv;
     } else if (R[4] > R[0] && R[4] >= R[8]) {
-        t = sqrt(R[4] - R[8] - R[0] + 1.0);
-        qy = 0.5 * t; t = 0.5 / t;
-        qw = (R[2] - R[6]) * t; qz = (R[7] + R[5]) * t; qx = (R[1] + R[3]) * t;
+        sqrt_and_rsqrt(R[4] - R[8] - R[0] + 1.0, n, inv);
+        qy = 0.5 * n; inv *= 0.5;
+        qw = (R[2] - R[6]) * inv; qz = (R[7] + R[5]) * inv; qx = (R[1] + R[3]) * inv;
     } else {
-        t = sqrt(R[8] - R[0] - R[4] + 1.0);
-        qz = 0.5 * t; t = 0.5 / t;
-        qw = (R[3] - R[1]) * t; qx = (R[2] + R[6]) * t; qy = (R[5] + R[7]) * t;
+        sqrt_and_rsqrt(R[8] - R[0] - R[4] + 1.0, n, inv);
+        qz = 0.5 * n; inv *= 0.5;
+        qw = (R[3] - R[1]) * inv; qx = (R[2] + R[6]) * inv; qy = (R[5] + R[7]) * inv;
     }
     q[0] = qw; q[1] = qx; q[2] = qy; q[3] = qz;
 }
 // g2o internal::normalize: unit norm, w >= 0
 __device__ __forceinline__ void w6_quat_normalize_sign(double* q) {
-    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-    double s = 1.0 / n;
+    double n, s;
+    sqrt_and_rsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3], n, s);
     if (q[0] < 0) s = -s;
     q[0] *= s; q[1] *= s; q[2] *= s; q[3] *= s;
 }
