@@ -68,7 +68,7 @@ namespace {
 extern __shared__ double ldsA[];
 #ifdef LOCAMD_ARROW_TIMING   // diagnostic build: cycle stamps of the phases go to result[1..7] (never benchmarked, never shipped)
 #define AT_DECL long long at_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long at_t = clock64()
-#if LOCAMD_ARROW_TIMING == 2   // the phases of the linearisation instead of the solve's
+#if LOCAMD_ARROW_TIMING == 2   // the phases of the linearisation instead of the solve's (3: the forward sweep split, see arrow_solve)
 #define AT(slot) do { at_t = clock64(); } while (0)
 #define AT2(slot) do { const long long t_ = clock64(); at_[slot] += t_ - at_t; at_t = t_; } while (0)
 #else
@@ -87,6 +87,21 @@ __device__ __forceinline__ double dpp_or_zero(double v, double identity) {
     const int ilo = __double2loint(identity), ihi = __double2hiint(identity);
     const int lo = __builtin_amdgcn_update_dpp(ilo, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
     const int hi = __builtin_amdgcn_update_dpp(ihi, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+// the value of lane - 1 / lane + 1 (wave_shr:1 / wave_shl:1 cross the 16-lane rows on gfx9; no neighbour: 0), of lane l (wave-uniform l)
+__device__ __forceinline__ double lane_from_prev(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_from_next(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double read_lane_dyn(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double read_lane63(double v) {
@@ -116,6 +131,13 @@ __device__ __forceinline__ void wsync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// the same for data that only THIS wave exchanges through LDS while global loads are in flight: the workgroup-scope fences of wsync()
+// also wait for every outstanding global load (vmcnt(0)) — in the forward sweep that serialised the prefetch of the next B rows
+// (an HBM round trip per four rows).  LDS operations of one wave complete in order; this waits for them only.
+__device__ __forceinline__ void wsync_lds() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
 }
 __device__ __forceinline__ double pivot_rsqrtA(double d) {   // window_kernel.hip: pivot_rsqrt
     const double y = __builtin_amdgcn_rsq(d);
@@ -464,74 +486,154 @@ __device__ __forceinline__ bool arrow_solve(const ArrowCtx& c, double lambda, in
     const bool brow = lane < D;
     const bool sweeps = wv < c.nseg;
     const int s0 = sweeps ? c.seg[wv] : 0, s1 = sweeps ? c.seg[wv + 1] : 0;
-    // ---- forward sweep over this wave's segment (every lane runs the 3x3 recurrence; lane r < D carries border row r) ---------------
+    // ---- forward sweep over this wave's segment ----------------------------------------------------------------------------------------
+    // (1) the chain's factor with LANE = ROW (chunks of 64 rows).  The couplings are rank-1, H_p,p-1 = u_p v_p^T, so the Schur complement
+    //     of row p is S_p = A_p - alpha_p u_p u_p^T (A_p = H_pp + lambda I) with the SCALAR alpha_p = v_p^T S_{p-1}^-1 v_p and right-hand
+    //     side b_p - beta_p u_p; Sherman-Morrison gives S^-1 from A^-1 (wave3_kernel.hip), so all rows factor their A_p and solve for
+    //     A^-1 u, A^-1 v, A^-1 b AT ONCE, two scalars run from row to row through DPP (every repetition every lane redoes its own step),
+    //     and then all rows AT ONCE factor S_p = G_p G_p^T and form y_p = G_p^-1 (b_p - beta_p u_p), g_{p+1} = G_p^-1 v_{p+1}.
+    //     (One row per iteration — every lane redoing the row's 3x3 recurrence from LDS — cost ~1 700 cycles per row.)
+    if (sweeps) {
+        double cal = 0.0, cbe = 0.0, cg0 = 0.0, cg1 = 0.0, cg2 = 0.0;   // into the chunk's first row: alpha, beta, g
+        for (int c0 = s0; c0 < s1; c0 += 64) {
+            const int p = c0 + lane;
+            const bool live = p < s1;
+            const int rows = s1 - c0 < 64 ? s1 - c0 : 64;
+            double pk[12], vn0 = 0.0, vn1 = 0.0, vn2 = 0.0;   // H_pp (6), b (3), u (3); the v of row p + 1
+#pragma unroll
+            for (int k = 0; k < 12; ++k) pk[k] = live ? c.PK[16 * p + k] : 0.0;
+            if (p + 1 < s1) { vn0 = c.PK[16 * (p + 1) + 12]; vn1 = c.PK[16 * (p + 1) + 13]; vn2 = c.PK[16 * (p + 1) + 14]; }
+            const double u0 = pk[9], u1 = pk[10], u2 = pk[11];
+            // A = G_A G_A^T; A^-1 u, A^-1 v_next, A^-1 b and their dot products
+            double uu, uv, vvq, ub, vb;
+            {
+                double a00 = pk[0] + lambda, a10 = pk[1], a11 = pk[2] + lambda, a20 = pk[3], a21 = pk[4], a22 = pk[5] + lambda;
+                const double i0 = pivot_rsqrtA(a00);
+                a10 *= i0; a20 *= i0;
+                a11 = __builtin_fma(-a10, a10, a11); a21 = __builtin_fma(-a20, a10, a21); a22 = __builtin_fma(-a20, a20, a22);
+                const double i1 = pivot_rsqrtA(a11);
+                a21 *= i1;
+                a22 = __builtin_fma(-a21, a21, a22);
+                const double i2 = pivot_rsqrtA(a22);
+                double P0 = u0 * i0, Q0 = vn0 * i0, R0 = pk[6] * i0;
+                double P1 = __builtin_fma(-P0, a10, u1) * i1, Q1 = __builtin_fma(-Q0, a10, vn1) * i1, R1 = __builtin_fma(-R0, a10, pk[7]) * i1;
+                double P2 = __builtin_fma(-P1, a21, __builtin_fma(-P0, a20, u2)) * i2, Q2 = __builtin_fma(-Q1, a21, __builtin_fma(-Q0, a20, vn2)) * i2;
+                double R2 = __builtin_fma(-R1, a21, __builtin_fma(-R0, a20, pk[8])) * i2;
+                // (G_A^-1 applied: u^T A^-1 v = (G_A^-1 u) . (G_A^-1 v), no back-substitution needed for the dot products)
+                uu = P0 * P0 + P1 * P1 + P2 * P2; uv = P0 * Q0 + P1 * Q1 + P2 * Q2; vvq = Q0 * Q0 + Q1 * Q1 + Q2 * Q2;
+                ub = P0 * R0 + P1 * R1 + P2 * R2; vb = Q0 * R0 + Q1 * R1 + Q2 * R2;
+            }
+            double ain = 0.0, bin = 0.0, al = 0.0, be = 0.0;
+            for (int r = 0; r < rows; ++r) {
+                double pal = lane_from_prev(al), pbe = lane_from_prev(be);
+                if (lane == 0) { pal = cal; pbe = cbe; }
+                ain = pal; bin = pbe;
+                const double den = __builtin_fma(-pal, uu, 1.0);
+                const double kuv = pal * fast_rcp(den) * uv;
+                al = __builtin_fma(kuv, uv, vvq);
+                be = __builtin_fma(kuv, __builtin_fma(-pbe, uu, ub), __builtin_fma(-pbe, uv, vb));
+            }
+            cal = read_lane_dyn(al, rows - 1); cbe = read_lane_dyn(be, rows - 1);
+            // S_p = A_p - alpha_p u u^T = G_p G_p^T; y_p; g of the next row
+            const double su0 = ain * u0, su1 = ain * u1, su2 = ain * u2;
+            double a00 = __builtin_fma(-su0, u0, pk[0] + lambda), a10 = __builtin_fma(-su1, u0, pk[1]), a11 = __builtin_fma(-su1, u1, pk[2] + lambda);
+            double a20 = __builtin_fma(-su2, u0, pk[3]), a21 = __builtin_fma(-su2, u1, pk[4]), a22 = __builtin_fma(-su2, u2, pk[5] + lambda);
+            const double r0 = __builtin_fma(-u0, bin, pk[6]), r1 = __builtin_fma(-u1, bin, pk[7]), r2 = __builtin_fma(-u2, bin, pk[8]);
+            const double ig0 = pivot_rsqrtA(a00);
+            a10 *= ig0; a20 *= ig0;
+            a11 = __builtin_fma(-a10, a10, a11); a21 = __builtin_fma(-a20, a10, a21); a22 = __builtin_fma(-a20, a20, a22);
+            const double ig1 = pivot_rsqrtA(a11);
+            a21 *= ig1;
+            a22 = __builtin_fma(-a21, a21, a22);
+            const double ig2 = pivot_rsqrtA(a22);
+            if (__ballot(live && !((ig0 + ig1) + ig2 < DBL_MAX))) ok = false;
+            const double y0 = r0 * ig0;
+            const double y1 = __builtin_fma(-y0, a10, r1) * ig1;
+            const double y2 = __builtin_fma(-y1, a21, __builtin_fma(-y0, a20, r2)) * ig2;
+            const double z0 = vn0 * ig0;
+            const double z1 = __builtin_fma(-z0, a10, vn1) * ig1;
+            const double z2 = __builtin_fma(-z1, a21, __builtin_fma(-z0, a20, vn2)) * ig2;
+            double g0 = lane_from_prev(z0), g1 = lane_from_prev(z1), g2 = lane_from_prev(z2);
+            if (lane == 0) { g0 = cg0; g1 = cg1; g2 = cg2; }
+            cg0 = read_lane_dyn(z0, rows - 1); cg1 = read_lane_dyn(z1, rows - 1); cg2 = read_lane_dyn(z2, rows - 1);
+            if (live) {
+                double* gz = c.GZ + 12 * p;
+                gz[0] = a10; gz[1] = a20; gz[2] = a21; gz[3] = ig0; gz[4] = ig1; gz[5] = ig2; gz[6] = y0; gz[7] = y1; gz[8] = y2;
+                gz[9] = g0; gz[10] = g1; gz[11] = g2;
+            }
+        }
+    }
+    wsync();
+#if defined(LOCAMD_ARROW_TIMING) && LOCAMD_ARROW_TIMING == 3
+    AT(2);   // (level 3: slot 2 = the chain's factor alone, slot 6 += the border rows + matrix cores)
+#endif
+    // (2) the border's rows of the factor, lane r < D = border row r: F_p = (B_p - (F_{p-1} . g_p) u_p^T) G_p^-T, four rows per step
+    //     into the f64 matrix cores (P += F F^T)
     {
-        double l10 = 0.0, l20 = 0.0, l21 = 0.0, ig0 = 0.0, ig1 = 0.0, ig2 = 0.0, y0 = 0.0, y1 = 0.0, y2 = 0.0;
         double F0 = 0.0, F1 = 0.0, F2 = 0.0, racc = 0.0;
         const double* Brow = c.BB + (size_t)lane * 3;
         const size_t bst = (size_t)D * 3;
         double* FX = c.FX + (size_t)wv * 4 * D16 * 3;
-        double nb_[4][3];   // the next four rows' B entries of this lane, in flight
+        // B streams from the HBM workspace: the rows of the next PD groups of four are kept in flight (with one group ahead the loop waited
+        // an HBM round trip per group: ~5 700 cycles for ~1 300 cycles of work)
+        constexpr int PD = 3;
+        double nbq[PD][4][3];
+        // (unconditional loads from a clamped row — a lane beyond the border reads the neighbouring entries of the workspace — so that
+        //  the compiler can count them: with a branch around every load it waited for ALL loads in flight, vmcnt(0), at the first use)
+        const int plast = s1 > s0 ? s1 - 1 : s0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int q = 0; q < PD; ++q)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) nb_[j][k] = (brow && s0 + j < s1) ? Brow[(size_t)(s0 + j) * bst + k] : 0.0;
-        for (int p0 = s0; p0 < s1; p0 += 4) {
+            for (int j = 0; j < 4; ++j) {
+                const int pr = s0 + 4 * q + j < s1 ? s0 + 4 * q + j : plast;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) nbq[q][j][k] = sweeps ? Brow[(size_t)pr * bst + k] : 0.0;
+            }
+        for (int pq = s0; pq < s1; pq += 4 * PD) {
+#pragma unroll
+          for (int q = 0; q < PD; ++q) {
+            const int p0 = pq + 4 * q;
+            if (p0 >= s1) break;
             double cb[4][3];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int k = 0; k < 3; ++k) cb[j][k] = nb_[j][k];
+                for (int k = 0; k < 3; ++k) cb[j][k] = (brow && p0 + j < s1) ? nbq[q][j][k] : 0.0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j) {
+                const int pr = p0 + 4 * PD + j < s1 ? p0 + 4 * PD + j : plast;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) nb_[j][k] = (brow && p0 + 4 + j < s1) ? Brow[(size_t)(p0 + 4 + j) * bst + k] : 0.0;
+                for (int k = 0; k < 3; ++k) nbq[q][j][k] = Brow[(size_t)pr * bst + k];
+            }
+            // the four rows' factor entries first, all LDS reads in flight together (left to itself the compiler issues each read where
+            // the recurrence needs it: ~24 LDS round trips in sequence per group)
+            double gzr[4][12], ur[4][3];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int pr = p0 + j < s1 ? p0 + j : plast;
+#pragma unroll
+                for (int k = 0; k < 12; ++k) gzr[j][k] = c.GZ[12 * pr + k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) ur[j][k] = c.PK[16 * pr + 9 + k];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int p = p0 + j;
                 double o0 = 0.0, o1 = 0.0, o2 = 0.0;
                 if (p < s1) {
-                    const double* pk = c.PK + 16 * p;
-                    const double u0 = pk[9], u1 = pk[10], u2 = pk[11], v0 = pk[12], v1 = pk[13], v2 = pk[14];
-                    // g = G_{p-1}^-1 v: W_p = u g^T
-                    const double g0 = v0 * ig0;
-                    const double g1 = __builtin_fma(-g0, l10, v1) * ig1;
-                    const double g2 = __builtin_fma(-g1, l21, __builtin_fma(-g0, l20, v2)) * ig2;
-                    const double gg = g0 * g0 + g1 * g1 + g2 * g2, gy = g0 * y0 + g1 * y1 + g2 * y2;
-                    const double su0 = gg * u0, su1 = gg * u1, su2 = gg * u2;
-                    double a00 = __builtin_fma(-su0, u0, pk[0] + lambda), a10 = __builtin_fma(-su1, u0, pk[1]), a11 = __builtin_fma(-su1, u1, pk[2] + lambda);
-                    double a20 = __builtin_fma(-su2, u0, pk[3]), a21 = __builtin_fma(-su2, u1, pk[4]), a22 = __builtin_fma(-su2, u2, pk[5] + lambda);
-                    const double r0 = __builtin_fma(-u0, gy, pk[6]), r1 = __builtin_fma(-u1, gy, pk[7]), r2 = __builtin_fma(-u2, gy, pk[8]);
-                    // border row: f = B_p[r] - (F_{p-1}[r] . g) u   (with the PREVIOUS row's F), then F = f G_p^-T
-                    const double fg = F0 * g0 + F1 * g1 + F2 * g2;
-                    const double f0 = __builtin_fma(-fg, u0, cb[j][0]), f1 = __builtin_fma(-fg, u1, cb[j][1]), f2 = __builtin_fma(-fg, u2, cb[j][2]);
-                    // 3x3 Cholesky (right-looking, reciprocal square roots of the pivots)
-                    ig0 = pivot_rsqrtA(a00);
-                    a10 *= ig0; a20 *= ig0;
-                    a11 = __builtin_fma(-a10, a10, a11); a21 = __builtin_fma(-a20, a10, a21); a22 = __builtin_fma(-a20, a20, a22);
-                    ig1 = pivot_rsqrtA(a11);
-                    a21 *= ig1;
-                    a22 = __builtin_fma(-a21, a21, a22);
-                    ig2 = pivot_rsqrtA(a22);
-                    ok = ok && ((ig0 + ig1) + ig2 < DBL_MAX);
-                    l10 = a10; l20 = a20; l21 = a21;
-                    y0 = r0 * ig0;
-                    y1 = __builtin_fma(-y0, l10, r1) * ig1;
-                    y2 = __builtin_fma(-y1, l21, __builtin_fma(-y0, l20, r2)) * ig2;
-                    F0 = f0 * ig0;
-                    F1 = __builtin_fma(-F0, l10, f1) * ig1;
-                    F2 = __builtin_fma(-F1, l21, __builtin_fma(-F0, l20, f2)) * ig2;
-                    racc = __builtin_fma(F0, y0, __builtin_fma(F1, y1, __builtin_fma(F2, y2, racc)));
-                    if (lane == 0) {
-                        double* gz = c.GZ + 12 * p;
-                        gz[0] = l10; gz[1] = l20; gz[2] = l21; gz[3] = ig0; gz[4] = ig1; gz[5] = ig2; gz[6] = y0; gz[7] = y1; gz[8] = y2;
-                        gz[9] = g0; gz[10] = g1; gz[11] = g2;
-                    }
+                    const double* gz = gzr[j];
+                    const double fg = F0 * gz[9] + F1 * gz[10] + F2 * gz[11];
+                    const double f0 = __builtin_fma(-fg, ur[j][0], cb[j][0]), f1 = __builtin_fma(-fg, ur[j][1], cb[j][1]), f2 = __builtin_fma(-fg, ur[j][2], cb[j][2]);
+                    F0 = f0 * gz[3];
+                    F1 = __builtin_fma(-F0, gz[0], f1) * gz[4];
+                    F2 = __builtin_fma(-F1, gz[2], __builtin_fma(-F0, gz[1], f2)) * gz[5];
+                    racc = __builtin_fma(F0, gz[6], __builtin_fma(F1, gz[7], __builtin_fma(F2, gz[8], racc)));
                     o0 = brow ? F0 : 0.0; o1 = brow ? F1 : 0.0; o2 = brow ? F2 : 0.0;
                 }
                 if (lane < D16) { double* fx = FX + ((size_t)j * D16 + lane) * 3; fx[0] = o0; fx[1] = o1; fx[2] = o2; }
             }
-            wsync();
+            wsync_lds();
             // P += F F^T over these four rows' twelve columns: three k-steps (one per component), lane (row li of a tile, chain row lk)
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -544,12 +646,17 @@ __device__ __forceinline__ bool arrow_solve(const ArrowCtx& c, double lambda, in
 #pragma unroll
                     for (int tj = 0; tj <= ti; ++tj) { acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[ti], fr[tj], acc[t], 0, 0, 0); ++t; }
             }
-            wsync();
+            wsync_lds();
+                  }
         }
         if (brow) c.RA[wv * D + lane] = sweeps ? racc : 0.0;
     }
     __syncthreads();
+#if defined(LOCAMD_ARROW_TIMING) && LOCAMD_ARROW_TIMING == 3
+    AT(6);
+#else
     AT(2);
+#endif
     // ---- S = C + lambda I - sum of the segments' F F^T (lower triangle, packed); row D = b_b - sum of the segments' F y ---------------
     for (int i = tid; i < D * (D + 1) / 2; i += 64 * ARROW_NW) c.S[i] = c.C0[i];
     for (int r = tid; r < D; r += 64 * ARROW_NW) c.S[tri(D, r)] = c.bB[r] - (((c.RA[r] + c.RA[D + r]) + c.RA[2 * D + r]) + c.RA[3 * D + r]);
@@ -654,33 +761,65 @@ __device__ __forceinline__ bool arrow_solve(const ArrowCtx& c, double lambda, in
     __syncthreads();
     AT(4);
     if (sweeps) {
-        double z0 = 0.0, z1 = 0.0, z2 = 0.0;
-        for (int p = s0; p < s1; ++p) {
-            const double* gz = c.GZ + 12 * p;
-            const double* pk = c.PK + 16 * p;
-            const double gz_ = gz[9] * z0 + gz[10] * z1 + gz[11] * z2;   // g_p . z_{p-1}
-            const double r0 = __builtin_fma(-pk[9], gz_, gz[6]), r1 = __builtin_fma(-pk[10], gz_, gz[7]), r2 = __builtin_fma(-pk[11], gz_, gz[8]);
-            z0 = r0 * gz[3];
-            z1 = __builtin_fma(-z0, gz[0], r1) * gz[4];
-            z2 = __builtin_fma(-z1, gz[2], __builtin_fma(-z0, gz[1], r2)) * gz[5];
-            if (lane == 0) { c.GZ[12 * p + 6] = z0; c.GZ[12 * p + 7] = z1; c.GZ[12 * p + 8] = z2; }
+        // The two sweeps of a segment with LANE = ROW (chunks of 64 rows): a row's factor, g, u and right-hand side are loaded once
+        // into its lane's registers; every repetition every lane takes its neighbour's 3-vector through DPP and redoes its own step —
+        // after repetition r the rows 0 .. r of the chunk hold final values (wave3_kernel.hip).  One row per iteration with the row's
+        // data read from LDS inside the loop was bound by the LDS round trip of every row (~480 cycles per row and sweep).
+        double cz0 = 0.0, cz1 = 0.0, cz2 = 0.0;   // z of the row before this chunk
+        for (int c0 = s0; c0 < s1; c0 += 64) {
+            const int p = c0 + lane;
+            const bool live = p < s1;
+            const int rows = s1 - c0 < 64 ? s1 - c0 : 64;
+            double G[12], u0 = 0.0, u1 = 0.0, u2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) G[k] = live ? c.GZ[12 * p + k] : 0.0;
+            if (live) { u0 = c.PK[16 * p + 9]; u1 = c.PK[16 * p + 10]; u2 = c.PK[16 * p + 11]; }
+            double z0 = 0.0, z1 = 0.0, z2 = 0.0;
+            for (int r = 0; r < rows; ++r) {
+                double i0 = lane_from_prev(z0), i1 = lane_from_prev(z1), i2 = lane_from_prev(z2);
+                if (lane == 0) { i0 = cz0; i1 = cz1; i2 = cz2; }
+                const double gz_ = G[9] * i0 + G[10] * i1 + G[11] * i2;   // g_p . z_{p-1}
+                const double r0 = __builtin_fma(-u0, gz_, G[6]), r1 = __builtin_fma(-u1, gz_, G[7]), r2 = __builtin_fma(-u2, gz_, G[8]);
+                z0 = r0 * G[3];
+                z1 = __builtin_fma(-z0, G[0], r1) * G[4];
+                z2 = __builtin_fma(-z1, G[2], __builtin_fma(-z0, G[1], r2)) * G[5];
+            }
+            if (live) { c.GZ[12 * p + 6] = z0; c.GZ[12 * p + 7] = z1; c.GZ[12 * p + 8] = z2; }
+            cz0 = read_lane_dyn(z0, rows - 1); cz1 = read_lane_dyn(z1, rows - 1); cz2 = read_lane_dyn(z2, rows - 1);
         }
         wsync();
-        // x_p = G_p^-T (z_p - g_{p+1} (u_{p+1} . x_{p+1}))
-        double x0 = 0.0, x1 = 0.0, x2 = 0.0, nu0 = 0.0, nu1 = 0.0, nu2 = 0.0, ng0 = 0.0, ng1 = 0.0, ng2 = 0.0;
-        for (int p = s1 - 1; p >= s0; --p) {
-            const double* gz = c.GZ + 12 * p;
-            const double* pk = c.PK + 16 * p;
-            const double a10 = gz[0], a20 = gz[1], a21 = gz[2], i0 = gz[3], i1 = gz[4], i2 = gz[5];
-            const double ux = nu0 * x0 + nu1 * x1 + nu2 * x2;
-            double t0 = __builtin_fma(-ng0, ux, gz[6]), t1 = __builtin_fma(-ng1, ux, gz[7]), t2 = __builtin_fma(-ng2, ux, gz[8]);
-            x2 = t2 * i2;
-            t1 = __builtin_fma(-a21, x2, t1); t0 = __builtin_fma(-a20, x2, t0);
-            x1 = t1 * i1;
-            t0 = __builtin_fma(-a10, x1, t0);
-            x0 = t0 * i0;
-            nu0 = pk[9]; nu1 = pk[10]; nu2 = pk[11]; ng0 = gz[9]; ng1 = gz[10]; ng2 = gz[11];
-            if (lane == 0) { c.GZ[12 * p + 6] = x0; c.GZ[12 * p + 7] = x1; c.GZ[12 * p + 8] = x2; }
+        // x_p = G_p^-T (z_p - g_{p+1} (u_{p+1} . x_{p+1})), chunks from the segment's end
+        double cx0 = 0.0, cx1 = 0.0, cx2 = 0.0, cu0 = 0.0, cu1 = 0.0, cu2 = 0.0, cg0 = 0.0, cg1 = 0.0, cg2 = 0.0;   // x, u, g of the row after this chunk
+        const int nchunks = (s1 - s0 + 63) / 64;
+        for (int ch = nchunks - 1; ch >= 0; --ch) {
+            const int c0 = s0 + 64 * ch;
+            const int p = c0 + lane;
+            const bool live = p < s1;
+            const int rows = s1 - c0 < 64 ? s1 - c0 : 64;
+            double G[12], u0 = 0.0, u1 = 0.0, u2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) G[k] = live ? c.GZ[12 * p + k] : 0.0;
+            if (live) { u0 = c.PK[16 * p + 9]; u1 = c.PK[16 * p + 10]; u2 = c.PK[16 * p + 11]; }
+            double nu0 = lane_from_next(u0), nu1 = lane_from_next(u1), nu2 = lane_from_next(u2);
+            double ng0 = lane_from_next(G[9]), ng1 = lane_from_next(G[10]), ng2 = lane_from_next(G[11]);
+            const bool last = lane == rows - 1;
+            if (last) { nu0 = cu0; nu1 = cu1; nu2 = cu2; ng0 = cg0; ng1 = cg1; ng2 = cg2; }
+            double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+            for (int r = 0; r < rows; ++r) {
+                double i0 = lane_from_next(x0), i1 = lane_from_next(x1), i2 = lane_from_next(x2);
+                if (last) { i0 = cx0; i1 = cx1; i2 = cx2; }
+                const double ux = nu0 * i0 + nu1 * i1 + nu2 * i2;
+                double t0 = __builtin_fma(-ng0, ux, G[6]), t1 = __builtin_fma(-ng1, ux, G[7]), t2 = __builtin_fma(-ng2, ux, G[8]);
+                x2 = t2 * G[5];
+                t1 = __builtin_fma(-G[2], x2, t1); t0 = __builtin_fma(-G[1], x2, t0);
+                x1 = t1 * G[4];
+                t0 = __builtin_fma(-G[0], x1, t0);
+                x0 = t0 * G[3];
+            }
+            if (live) { c.GZ[12 * p + 6] = x0; c.GZ[12 * p + 7] = x1; c.GZ[12 * p + 8] = x2; }
+            cx0 = read_lane_dyn(x0, 0); cx1 = read_lane_dyn(x1, 0); cx2 = read_lane_dyn(x2, 0);
+            cu0 = read_lane_dyn(u0, 0); cu1 = read_lane_dyn(u1, 0); cu2 = read_lane_dyn(u2, 0);
+            cg0 = read_lane_dyn(G[9], 0); cg1 = read_lane_dyn(G[10], 0); cg2 = read_lane_dyn(G[11], 0);
         }
     }
     __syncthreads();
