@@ -778,7 +778,21 @@ __device__ __forceinline__ bool arrow_solve(const ArrowCtx& c, double lambda, in
     for (int q = tid; q < n; q += 64 * ARROW_NW) {
         double t0 = c.PK[16 * q + 6], t1 = c.PK[16 * q + 7], t2 = c.PK[16 * q + 8];
         const double* bp = c.BB + (size_t)q * D * 3;
-        for (int r = 0; r < D; ++r) {
+        // (a thread streams its own row of B: twelve border components per step, their 36 loads in flight together — one component per
+        //  step waited an HBM round trip per component)
+        int r = 0;
+        for (; r + 12 <= D; r += 12) {
+            double bv[36], xv[12];
+#pragma unroll
+            for (int k = 0; k < 36; ++k) bv[k] = bp[3 * r + k];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) xv[k] = c.xB[r + k];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                t0 = __builtin_fma(-bv[3 * k], xv[k], t0); t1 = __builtin_fma(-bv[3 * k + 1], xv[k], t1); t2 = __builtin_fma(-bv[3 * k + 2], xv[k], t2);
+            }
+        }
+        for (; r < D; ++r) {
             const double xr = c.xB[r];
             t0 = __builtin_fma(-bp[3 * r], xr, t0); t1 = __builtin_fma(-bp[3 * r + 1], xr, t1); t2 = __builtin_fma(-bp[3 * r + 2], xr, t2);
         }
