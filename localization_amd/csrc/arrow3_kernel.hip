@@ -214,17 +214,19 @@ template <bool FULL, int JAC>
 __device__ __forceinline__ EdgeTerms range_terms(const double* p0, const double* p1, bool moving1, double meas, double info) {
     EdgeTerms t;
     double u[3] = {p0[0] - p1[0], p0[1] - p1[1], p0[2] - p1[2]};
-    double n = 0.0, x0 = 0.0, h0 = 0.0;
-    if (JAC == 0) n = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
-    else { x0 = sq3_plainA(u[0], u[1], u[2]); n = sqrt_ieee_unscaled_h(x0, h0); }
+    double n = 0.0, x0 = 0.0, h0 = 0.0, inv_n = 0.0;
+    if (JAC == 0) {   // (norm and reciprocal norm from one v_rsq_f64 seed: 1e-16 / 4e-15 relative)
+        const double x = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
+        sqrt_and_rsqrt(x, n, inv_n);
+        if (!(x > 0.0)) { n = 0.0; inv_n = 0.0; }   // coincident endpoints: J = 0, what the central difference gives
+    } else { x0 = sq3_plainA(u[0], u[1], u[2]); n = sqrt_ieee_unscaled_h(x0, h0); }
     const double err = meas - n;
     t.chi = err * (info * err);
     const double aux = 1.0 + t.chi;
     t.rho = fast_log_ge1(aux);
     if (FULL) {
         if (JAC == 0) {
-            const double inv = n > 0.0 ? 1.0 / n : 0.0;   // coincident endpoints: J = 0, what the central difference gives
-            u[0] *= inv; u[1] *= inv; u[2] *= inv;
+            u[0] *= inv_n; u[1] *= inv_n; u[2] *= inv_n;
             t.J0[0] = -u[0]; t.J0[1] = -u[1]; t.J0[2] = -u[2];
             t.J1[0] = moving1 ? u[0] : 0.0; t.J1[1] = moving1 ? u[1] : 0.0; t.J1[2] = moving1 ? u[2] : 0.0;
         } else {
@@ -249,7 +251,7 @@ __device__ __forceinline__ EdgeTerms range_terms(const double* p0, const double*
                 }
             }
         }
-        t.wr = info / aux;
+        t.wr = info * fast_rcp(aux);
         t.wre = -t.wr * err;
     }
     return t;
