@@ -363,8 +363,7 @@ __global__ void __launch_bounds__(64, 3) wave3_lm_kernel(const WindowArgs a) {
             double uu_[3] = {0.0, 0.0, 0.0}, vv_[3] = {0.0, 0.0, 0.0};
             if (pose) {
                 const int k1 = lst + deg;
-                for (int k = lst; k < k1; ++k) {
-                    const double* r = l.rec + (size_t)k * 8;
+                auto fold = [&](int k, const double* r) __attribute__((always_inline)) {
                     const double wr = r[0], wre = r[1];
                     const double Jm[3] = {r[2], r[3], r[4]}, Jo[3] = {r[5], r[6], r[7]};
                     const double wj[3] = {wr * Jm[0], wr * Jm[1], wr * Jm[2]};
@@ -380,7 +379,17 @@ __global__ void __launch_bounds__(64, 3) wave3_lm_kernel(const WindowArgs a) {
 #pragma unroll
                         for (int rr = 0; rr < 3; ++rr) { uu_[rr] = wj[rr]; vv_[rr] = Jo[rr]; }
                     }
-                }
+                };
+                // the first three records together (their LDS reads in flight at once: a pose of the reference's window has three), then the rest
+                double r3[3][8];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int c8 = 0; c8 < 8; ++c8) r3[i][c8] = lst + i < k1 ? l.rec[(size_t)(lst + i) * 8 + c8] : 0.0;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    if (lst + i < k1) fold(lst + i, r3[i]);
+                for (int k = lst + 3; k < k1; ++k) fold(k, l.rec + (size_t)k * 8);
                 for (int pq = 0; pq < np; ++pq) {
                     if (l.pidx[pq] != pp) continue;
                     const double* v = l.pv + (size_t)pq * 6;
