@@ -13,12 +13,14 @@
 //        [ B   C   ]   B  dense (3 nb) x (3 n), C dense (3 nb) x (3 nb)
 // and is solved the way its shape asks, not by a general sparse factorisation (window_lm_kernel runs this very graph through
 // ordering + symbolic + 19 elimination levels of scattered 6x6 blocks: 425x the algorithmic bytes, one instance per CU):
-//   forward    one sequential sweep over the chain: G_p = chol(H_pp + lambda I - W_p W_p^T), y_p; the border's rows of the factor ride
-//              along, lane = border row: F_p = (B_p - F_{p-1} W_p^T) G_p^-T (three numbers per lane, in registers), r_b -= F_p y_p;
+//   forward    the chain's factor with LANE = ROW: the couplings are rank-1, so Sherman-Morrison turns G_p = chol(H_pp + lambda I -
+//              W_p W_p^T), y_p into two scalars (alpha, beta) that run from row to row through DPP, all rows factoring AT ONCE
+//              before and after (wave3_kernel.hip); then ONE sequential loop carries the border's rows of the factor, lane = border
+//              row: F_p = (B_p - (F_{p-1} . g_p) u_p^T) G_p^-T (three numbers per lane, in registers), r_b -= F_p y_p;
 //   Schur      S = C + lambda I - sum_p F_p F_p^T: a (3 nb) x (3 n) x (3 nb) SYRK — the one GEMM-shaped piece, on the f64 matrix
 //              cores (v_mfma_f64_16x16x4_f64), four poses per step, accumulators in registers for the whole sweep;
 //   border     dense Cholesky of S in LDS (<= 45 x 45, lower triangle packed), the right-hand side riding along as one more row;
-//   chain      z = L^-1 (b_c - B^T x_b), x_c = L^-T z: two more sweeps over the chain that touch only 3x3 data.
+//   chain      z = L^-1 (b_c - B^T x_b), x_c = L^-T z: two more sweeps with lane = row, the 3-vector handed from lane to lane by DPP.
 // F is never stored (it would be 184 KB per instance and trial); B is (dense 3x3 blocks in an HBM workspace, streamed: 3 D doubles
 // per chain row, read twice per trial).  What the sequential sweeps touch lives in LDS (26 doubles per chain row + the border's
 // dense arrays), what only thread-parallel phases touch (translations, the stale step, edge records) in HBM with coalesced access.
@@ -33,9 +35,13 @@
 // order (no atomics; 32 loads in flight per wave).  The border's dense factorisation runs on the whole block, one border pose
 // (three columns) per step.  Measured on config 4 (256 + 10 poses, 16 LM trials per solve, 128 hypotheses = one GPU's share):
 // window_lm_kernel 15.1 ms; this kernel with one wave per instance 6.9 ms; four waves + separators 3.0 ms; + blocked dense
-// factorisation, g kept from the forward sweep, the reduction's loads in flight: 2.7 ms (all 1 024 hypotheses on one GPU: 11.5 ms,
-// 8.9e4 solves/s against 8.5e3).  Cycle shares now (tools/dev/probe_arrow3.py, -DLOCAMD_ARROW_TIMING): forward sweep + Schur
-// 28 %, linearisation 22 %, chain z / x sweeps 17 %, dense factorisation 13 %, B^T x 8 %, trial scoring 7 %.  Tried and dropped:
+// factorisation, g kept from the forward sweep, the reduction's loads in flight: 2.7 ms; + the latency round (the sequential parts were
+// bound by LDS / HBM round trips per row, not by arithmetic: lane = row sweeps with DPP hand-over, LDS reads issued together, LDS-only
+// synchronisation next to loads in flight, deeper prefetch of B rows and edge records, the border's back-substitution in registers):
+// 1.9 ms (all 1 024 hypotheses on one GPU: 7.8 ms, 1.3e5 solves/s against 8.5e3).  Cycle shares now (tools/dev/probe_arrow3.py,
+// make arrowtiming): linearisation 29 %, forward sweep + Schur 28 %, dense factorisation 17 %, chain z / x sweeps 11 %, trial scoring
+// 10 %, B^T x 5 %.  Tried and dropped: the border's dense Cholesky on one wave — rows in registers with v_readlane hand-outs (2.5x
+// slower), or in LDS with one row of the trailing update per lane (1.7x slower: 36 dependent LDS round trips per step);
 // B transposed to [border row][component][chain row] (coalesced for the thread-parallel phases, but the forward sweep's 39 lanes
 // then touch 39 cache lines per load: the sweep +20 %, the whole solve +7 %).
 #include "window_kernel.h"
@@ -618,12 +624,6 @@ __device__ __forceinline__ bool arrow_solve(const ArrowCtx& c, double lambda, in
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int k = 0; k < 3; ++k) cb[j][k] = (brow && p0 + j < s1) ? nbq[q][j][k] : 0.0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int pr = p0 + 4 * PD + j < s1 ? p0 + 4 * PD + j : plast;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) nbq[q][j][k] = Brow[(size_t)pr * bst + k];
-            }
             // the four rows' factor entries first, all LDS reads in flight together (left to itself the compiler issues each read where
             // the recurrence needs it: ~24 LDS round trips in sequence per group)
             double gzr[4][12], ur[4][3];
@@ -651,6 +651,14 @@ __device__ __forceinline__ bool arrow_solve(const ArrowCtx& c, double lambda, in
                     o0 = brow ? F0 : 0.0; o1 = brow ? F1 : 0.0; o2 = brow ? F2 : 0.0;
                 }
                 if (lane < D16) { double* fx = FX + ((size_t)j * D16 + lane) * 3; fx[0] = o0; fx[1] = o1; fx[2] = o2; }
+            }
+            // the B rows of the group PD steps ahead, requested HERE: the compiler waits for every load in flight (vmcnt(0)) at the next
+            // group's first use of its own rows, so the youngest loads should have the matrix-core phase behind them by then
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int pr = p0 + 4 * PD + j < s1 ? p0 + 4 * PD + j : plast;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) nbq[q][j][k] = Brow[(size_t)pr * bst + k];
             }
             wsync_lds();
             // P += F F^T over these four rows' twelve columns: three k-steps (one per component), lane (row li of a tile, chain row lk)

@@ -1,25 +1,30 @@
 // gfx950 (MI355X / CDNA4): TRANSLATION-ONLY chain windows, one WAVE per window — the drop-in node's own solve (one window per
-// range message, cfg/uwb_only.yaml) and small batches of such windows.
+// range message, cfg/uwb_only.yaml) and batches of such windows of any size.
 //
 // What it solves (reference file:line): the graph Localization::addRangeEdge builds per range message
 // (localization.cpp:297-376) — per pose one EdgeSE3Range to an anchor (:331) and the zero-range smoothness edge to the previous
 // pose (:338-340), Cauchy kernels (:608-627) — solved by Localization::solve() = g2o Levenberg-Marquardt (:164-170), chi2() (:197).
 // The 3-DoF form is exact for these graphs (chain3_kernel.hip's header: identity antenna offsets, identity rotations, no rotation
 // information — every dropped term of the 6x6-block system is an exact zero); the host takes this kernel under the same
-// conditions as chain3_lm_kernel, for batches too small for one lane per window.
+// conditions as chain3_lm_kernel, for windows of <= 64 poses (capi_window.cpp: pick_kernel).
 //
-// MI355X mapping.  A single window is a latency problem: one wave issues one f64 instruction per ~8 cycles whatever its 64 lanes
-// hold, so the general wave-per-window kernel's 6x6-block schedule (~9 k instructions per LM iteration on a ten-pose window,
-// 0.36 ms per solve) is cut to what this graph needs:
+// MI355X mapping.  A single window is a latency problem: one wave issues one f64 instruction per 4 .. 8 cycles whatever its 64
+// lanes hold, so the general wave-per-window kernel's 6x6-block schedule (~9 k instructions per LM iteration on a ten-pose window,
+// 0.36 ms per solve) is cut to what this graph needs — 0.056 ms:
 //   * lane = EDGE for everything per edge (residual, robust weight, the twelve perturbed norms of g2o's numeric Jacobian): one
-//     pass of ~300 instructions whatever the edge count (<= 64 per pass); an edge leaves (w, -w e, J0, J1) in LDS;
-//   * lane = POSE for the normal equations: pose p sums its own edges' records (host order = g2o's accumulation order) into
-//     H_pp (6), b_p (3) and the 3x3 coupling block with pose p - 1, all in that lane's registers for every trial of the iteration;
-//   * the block-tridiagonal Cholesky is inherently sequential: step p runs on lane p alone (3x3 blocks: ~100 instructions) and
-//     hands G_p, y_p to step p + 1 through v_readlane (SGPRs, no LDS round trip); the back-substitution hands O_p^T x_p back the
-//     same way;
+//     pass whatever the edge count (<= 64 per pass; the first 64 edges stay in registers); an edge writes one record per moving
+//     endpoint (w, -w e, its J, the other endpoint's J when that is the previous pose) into the slot of that pose's list;
+//   * lane = POSE for the normal equations: pose p sums its records (host order = g2o's accumulation order) into H_pp (6), b_p (3)
+//     and the coupling with pose p - 1, all in that lane's registers for every trial of the iteration;
+//   * the block-tridiagonal solve: with one edge per consecutive pair the couplings are rank-1, H_p,p-1 = u v^T, the Schur complement
+//     of pose p is A_p - alpha_p u u^T, and Sherman-Morrison turns the sequential elimination into a recurrence on TWO SCALARS per
+//     pose (see "The solve" in the kernel); every repetition every lane takes its neighbour's scalars through DPP (wave_shr:1 /
+//     wave_shl:1) and redoes its own step — no exec masking, no LDS, no v_readlane round trips.  Windows with several edges on a pair
+//     keep 3x3 blocks handed over the same way;
+//   * LM's next trials are solved SPECULATIVELY in the idle lanes: up to four groups of 16 lanes solve the same H with the lambdas
+//     of this trial and of the next ones (what LM would try after a rejection), and are scored in LM's order;
 //   * nothing but the poses and the per-edge records ever leaves registers; no barriers (one wave per workgroup), no HBM
-//     workspace, 4 KB of LDS for a ten-pose window.
+//     workspace, 6 KB of LDS for a ten-pose window; 168 registers: three waves per SIMD in batches (3.7e7 windows/s).
 #include "window_kernel.h"
 #include "device_math.h"
 
