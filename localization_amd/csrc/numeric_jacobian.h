@@ -22,9 +22,10 @@ __device__ __forceinline__ double range_error_plain(const double* R, const doubl
     const double dx = (px + t[0]) - q1[0], dy = (py + t[1]) - q1[1], dz = (pz + t[2]) - q1[2];
     return meas - sqrt_ieee_unscaled(dx * dx + dy * dy + dz * dz);
 }
-// X * fromVectorMQT(dl e_D): (R Rinc, R tinc + t)
+// X * fromVectorMQT(dl e_D): (R Rinc, R tinc + t) — the textbook evaluation, every product with the increment's zeros and ones spelled out
+// (kept as the definition; tools/oplus_probe.hip checks oplus_axis_plain against it bit for bit)
 template <int D>
-__device__ __forceinline__ void oplus_axis_plain(const double* R, const double* t, double dl, double* Ro, double* to) {
+__device__ __forceinline__ void oplus_axis_plain_reference(const double* R, const double* t, double dl, double* Ro, double* to) {
     double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     v[D] = dl;
     double Ri[9];
@@ -43,6 +44,39 @@ __device__ __forceinline__ void oplus_axis_plain(const double* R, const double* 
 #pragma unroll
         for (int j = 0; j < 3; ++j) Ro[i * 3 + j] = R[i * 3 + 0] * Ri[0 * 3 + j] + R[i * 3 + 1] * Ri[1 * 3 + j] + R[i * 3 + 2] * Ri[2 * 3 + j];
         to[i] = (R[i * 3 + 0] * v[0] + R[i * 3 + 1] * v[1] + R[i * 3 + 2] * v[2]) + t[i];
+    }
+}
+// The same numbers without the arithmetic on exact zeros and ones.  The increment of g2o's central differences has ONE non-zero entry,
+// dl = +-1e-9: for a translation axis Rinc is exactly I and tinc = dl e_D, so R' = R and t'_i = fl(fl(R_iD dl) + t_i); for a rotation
+// axis a = D - 3 the quaternion is (fl(sqrt(fl(1 - dl^2))), dl e_a) = (1, dl e_a) exactly (dl^2 = 1e-18 is below half an ulp of 1), so
+// Rinc = I + [2 dl e_a]x with exact entries 1, 0, +-2 dl (1 - 2 dl^2 rounds to 1 as well), R' differs from R in the two columns other
+// than a — each entry one multiplication and one addition, in the textbook's order — and t' = t.  (Products with +-0 only ever add a
+// signed zero to a sum; the one thing that can differ is the SIGN of a result that is exactly zero.)  A perturbed rotation costs 12
+// operations instead of 60, a perturbed translation 6.
+template <int D>
+__device__ __forceinline__ void oplus_axis_plain(const double* R, const double* t, double dl, double* Ro, double* to) {
+    static_assert(D >= 0 && D < 6, "axis");
+    if (D < 3) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) Ro[i * 3 + j] = R[i * 3 + j];
+            to[i] = R[i * 3 + D] * dl + t[i];
+        }
+    } else {
+        const double tw = 2 * dl;   // (t_a q_w with q_w = 1)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double r0 = R[i * 3 + 0], r1 = R[i * 3 + 1], r2 = R[i * 3 + 2];
+            if (D == 3) {          // Rinc = [[1, 0, 0], [0, 1, -tw], [0, tw, 1]]
+                Ro[i * 3 + 0] = r0; Ro[i * 3 + 1] = r1 + r2 * tw; Ro[i * 3 + 2] = r1 * -tw + r2;
+            } else if (D == 4) {   // Rinc = [[1, 0, tw], [0, 1, 0], [-tw, 0, 1]]
+                Ro[i * 3 + 0] = r0 + r2 * -tw; Ro[i * 3 + 1] = r1; Ro[i * 3 + 2] = r0 * tw + r2;
+            } else {               // Rinc = [[1, -tw, 0], [tw, 1, 0], [0, 0, 1]]
+                Ro[i * 3 + 0] = r0 + r1 * tw; Ro[i * 3 + 1] = r0 * -tw + r1; Ro[i * 3 + 2] = r2;
+            }
+            to[i] = t[i];
+        }
     }
 }
 // the lever-arm point (X * fromVectorMQT(dl e_D)) * o = R' o + t'

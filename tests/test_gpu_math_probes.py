@@ -24,3 +24,15 @@ def test_sqrt_variants_are_bit_identical_to_sqrt(gpu):
     for l in lines:
         assert ": 0 mismatches" in l, l
     assert "DIFFERENT" not in out.stdout and out.stdout.count("same bits") == 8
+
+
+def test_single_axis_oplus_is_the_textbook_evaluation(gpu):
+    """numeric_jacobian.h: oplus_axis_plain (X * fromVectorMQT(+-1e-9 e_d) without the arithmetic on the increment's exact zeros and
+    ones) against the textbook evaluation, bit for bit up to the sign of exact zeros — tools/oplus_probe.hip on the device."""
+    exe = os.path.join(ROOT, "tools", "oplus_probe.bin")
+    if not os.path.exists(exe):
+        hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-I", os.path.join(ROOT, "localization_amd", "csrc"),
+                               os.path.join(ROOT, "tools", "oplus_probe.hip"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and ": 0 mismatches" in out.stdout, (out.returncode, out.stdout, out.stderr)
