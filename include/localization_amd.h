@@ -225,7 +225,8 @@ int loc_window_set_chain_threshold(loc_window* w, int64_t min_batch);
 /* Which kernel the last solve of this handle ran (the choice depends on the batch: its size and structure).
  *   GENERAL  window_lm_kernel: one wave (65 ... 512 poses: eight waves) per window, sparse block Cholesky in a minimum-degree order
  *   CHAIN    chain_lm_kernel: one lane per window, block-tridiagonal 6x6 (batches >= the chain threshold of chain windows)
- *   CHAIN3   chain3_lm_kernel: the same (from 4 096 windows on, unless a threshold was set) for TRANSLATION-ONLY batches — no EdgeSE3, every lever arm zero, every rotation the
+ *   CHAIN3   chain3_lm_kernel: the same for TRANSLATION-ONLY batches (windows of more than 64 poses from 4 096 windows on; windows of <= 64
+ *            poses only past an explicit threshold: WAVE3 serves those at every batch size) — no EdgeSE3, every lever arm zero, every rotation the
  *            identity (what Robot::init, robot.cpp:47, and the default identity antenna offsets, localization.h:170, give:
  *            cfg/uwb_only.yaml on the example bag), priors without rotation information: the 6-DoF problem then reduces EXACTLY
  *            to 3x3 blocks (types_edge_se3range.cpp:105-114 does not see the rotation; SURVEY.md §8(a) note)
@@ -240,17 +241,17 @@ int loc_window_set_chain_threshold(loc_window* w, int64_t min_batch);
  *            elimination schedule is computed once on the host; one wave per window with LANE = POSE and a pose's whole solver
  *            state in that lane's registers (no workspace in memory), elimination by height.  (Nodes with several EdgeSE3 to
  *            their parent: tree_lm_kernel, one lane per window on the same schedule.)
- *   WAVE3   a translation-only chain batch (as CHAIN3) of windows of <= 64 poses that is too small for one lane per window — in
- *            particular the drop-in node's own solve, one window per range message: wave3_lm_kernel, one wave per window, lane =
- *            edge for the residuals / Jacobians, lane = pose for the 3x3-block normal equations, the sequential block-tridiagonal
- *            factorisation handed from lane to lane through scalar registers.
+ *   WAVE3   a translation-only chain batch (as CHAIN3) of windows of <= 64 poses, any batch size — in particular the drop-in node's
+ *            own solve, one window per range message: wave3_lm_kernel, one wave per window, lane = edge for the residuals /
+ *            Jacobians, lane = pose for the 3x3-block normal equations, rank-1 couplings solved by a scalar recurrence handed from
+ *            lane to lane, the next LM trials' lambdas solved speculatively in the idle lanes.
  *   WAVE6   the 6-DoF sibling of WAVE3 (IMU / lidar priors, an antenna lever arm on the pose): chain windows of <= 64 poses without
  *            EdgeSE3 factors and with at most one range edge per pair of consecutive poses, below the lane-per-window batch size.
  * All of them run the same LM and agree to the tolerances of DESIGN.md §3; result[6] / result[7] keep their meaning (the
  * lane-per-window kernels eliminate in pose order: result[7] = nv * 65536 + 2 nv - 1). */
 enum { LOC_WINDOW_KERNEL_NONE = -1, LOC_WINDOW_KERNEL_GENERAL = 0, LOC_WINDOW_KERNEL_CHAIN = 1, LOC_WINDOW_KERNEL_CHAIN3 = 2, LOC_WINDOW_KERNEL_ARROW3 = 3, LOC_WINDOW_KERNEL_TREE = 4,
        LOC_WINDOW_KERNEL_TREE_LANE = 5 /* reported only: the lane-per-window variant of TREE ran */,
-       LOC_WINDOW_KERNEL_WAVE3 = 6 /* translation-only chains of <= 64 poses below the lane-per-window batch sizes: one wave per window (wave3_lm_kernel) */,
+       LOC_WINDOW_KERNEL_WAVE3 = 6 /* translation-only chains of <= 64 poses: one wave per window (wave3_lm_kernel) */,
        LOC_WINDOW_KERNEL_WAVE6 = 7 /* 6-DoF chains of <= 64 poses (no EdgeSE3, one range edge per consecutive pair) below the lane-per-window batch size: wave6_lm_kernel */ };
 int loc_window_last_kernel_kind(const loc_window* w, int32_t* kind);
 /* Device-resident operation: upload n instances once (same host layouts as loc_window_solve_host), then run
