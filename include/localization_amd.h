@@ -246,13 +246,14 @@ int loc_window_set_chain_threshold(loc_window* w, int64_t min_batch);
  *            Jacobians, lane = pose for the 3x3-block normal equations, rank-1 couplings solved by a scalar recurrence handed from
  *            lane to lane, the next LM trials' lambdas solved speculatively in the idle lanes.
  *   WAVE6   the 6-DoF sibling of WAVE3 (IMU / lidar priors, an antenna lever arm on the pose): chain windows of <= 64 poses without
- *            EdgeSE3 factors and with at most one range edge per pair of consecutive poses, below the lane-per-window batch size.
+ *            EdgeSE3 factors and with at most one range edge per pair of consecutive poses, any batch size (an explicit chain threshold
+ *            hands larger batches to CHAIN).
  * All of them run the same LM and agree to the tolerances of DESIGN.md §3; result[6] / result[7] keep their meaning (the
  * lane-per-window kernels eliminate in pose order: result[7] = nv * 65536 + 2 nv - 1). */
 enum { LOC_WINDOW_KERNEL_NONE = -1, LOC_WINDOW_KERNEL_GENERAL = 0, LOC_WINDOW_KERNEL_CHAIN = 1, LOC_WINDOW_KERNEL_CHAIN3 = 2, LOC_WINDOW_KERNEL_ARROW3 = 3, LOC_WINDOW_KERNEL_TREE = 4,
        LOC_WINDOW_KERNEL_TREE_LANE = 5 /* reported only: the lane-per-window variant of TREE ran */,
        LOC_WINDOW_KERNEL_WAVE3 = 6 /* translation-only chains of <= 64 poses: one wave per window (wave3_lm_kernel) */,
-       LOC_WINDOW_KERNEL_WAVE6 = 7 /* 6-DoF chains of <= 64 poses (no EdgeSE3, one range edge per consecutive pair) below the lane-per-window batch size: wave6_lm_kernel */ };
+       LOC_WINDOW_KERNEL_WAVE6 = 7 /* 6-DoF chains of <= 64 poses (no EdgeSE3, one range edge per consecutive pair): wave6_lm_kernel */ };
 int loc_window_last_kernel_kind(const loc_window* w, int32_t* kind);
 /* Device-resident operation: upload n instances once (same host layouts as loc_window_solve_host), then run
  * loc_window_solve_resident any number of times — each launch starts from the uploaded estimates, is asynchronous on

@@ -654,12 +654,16 @@ static int pick_kernel(const loc_window* w, int64_t n, int topology) {
     const long long mn = w->chain_min >= 0 ? w->chain_min : chain_min_batch();
     if (w->has_off1) return LOC_WINDOW_KERNEL_GENERAL;   // (lever arms on endpoint 1: only the general kernel evaluates them)
     if (topology == LOC_WINDOW_KERNEL_WAVE6) {
-        // a 6-DoF chain batch that also qualifies for wave6_lm_kernel: one lane per window from the chain threshold on, one wave per
-        // window with rank-1 couplings below it (LOCAMD_WAVE6=0: the general kernel, for A/B runs)
+        // a 6-DoF chain batch that also qualifies for wave6_lm_kernel (one wave per window, rank-1 couplings).  Measured on twelve-pose
+        // cfg/uwb_imu.yaml windows: 1.15e7 windows/s at 4 096, 16 384 and 65 536 windows against chain_lm_kernel's 1.1e6 / 4.3e6 / 6.9e6 —
+        // so by default it takes every batch; an explicit threshold hands batches from that size on to the lane-per-window kernel.
+        // LOCAMD_WAVE6=0: as before (the general kernel below the threshold, chain_lm_kernel from it on), for A/B runs.
         if (mn <= 0 || w->natural_order) return LOC_WINDOW_KERNEL_GENERAL;
-        if (n >= mn) return LOC_WINDOW_KERNEL_CHAIN;
+        const bool default_rule = w->chain_min < 0 && !getenv("LOCAMD_CHAIN_MIN_BATCH");
         const char* v = getenv("LOCAMD_WAVE6");
-        return (v && v[0] == '0') ? LOC_WINDOW_KERNEL_GENERAL : LOC_WINDOW_KERNEL_WAVE6;
+        const bool off = v && v[0] == '0';
+        if (n >= mn && (off || !default_rule)) return LOC_WINDOW_KERNEL_CHAIN;
+        return off ? LOC_WINDOW_KERNEL_GENERAL : LOC_WINDOW_KERNEL_WAVE6;
     }
     if (topology == LOC_WINDOW_KERNEL_ARROW3) return w->natural_order ? LOC_WINDOW_KERNEL_GENERAL : LOC_WINDOW_KERNEL_ARROW3;   // (one wave per window: any batch size)
     if (topology == LOC_WINDOW_KERNEL_TREE) return (w->natural_order || n < tree_min_batch(w)) ? LOC_WINDOW_KERNEL_GENERAL : LOC_WINDOW_KERNEL_TREE;
