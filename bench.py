@@ -62,9 +62,10 @@ def window_traffic(leg, world):
     return pj.get("legs", {}).get(leg)
 
 
-def cpu_baseline(anchors, dist_tiles, err_tiles, init, n_tags, n_epochs, gpu_pos, M):
+def cpu_baseline(anchors, dist_tiles, err_tiles, init, n_tags, n_epochs, gpu_pos, M, gpu_jacobian="numeric"):
     """The oracle (CPU restatement of the reference's g2o path: 6-DoF vertices, numeric Jacobians, LM) timed on one
-    host core over a bounded sample of the same workload: the first n_tags tags x the first n_epochs epochs."""
+    host core over a bounded sample of the same workload: the first n_tags tags x the first n_epochs epochs.
+    Returns (json object, oracle positions [n_epochs][3][n_tags])."""
     import numpy as np
     from localization_amd.snapshot import unpack_ranges
     from oracle import oracle as O
@@ -82,7 +83,11 @@ def cpu_baseline(anchors, dist_tiles, err_tiles, init, n_tags, n_epochs, gpu_pos
     if gpu_pos is not None:
         g = gpu_pos[:n_epochs, :, :n_tags].cpu().numpy()
         out["max_abs_diff_vs_gpu_m"] = float(np.abs(g - rp).max())
-    return out
+        out["median_abs_diff_vs_gpu_m"] = float(np.median(np.abs(g - rp).max(axis=1)))
+        out["diff_note"] = (f"GPU headline (jacobian = {gpu_jacobian}) against the oracle (numeric) on the sample: " +
+                            ("the same Jacobian mode on both sides (tests assert <= 1e-5 m)" if gpu_jacobian == "numeric" else
+                             "CROSS-mode, fixed 10 LM iterations, iterates not converged"))
+    return out, rp
 
 
 def host_core_share(cap=16):
@@ -227,6 +232,66 @@ class Dist:
             dist.destroy_process_group()
 
 
+def reporting_collectives(D, args, out_pos, out_chi2, out_trials, dist_tiles, E, total_steps, B):
+    """SURVEY §8(e)(1)-(2), run AFTER the timed region (the solve path itself has no collective):
+    (2) all-reduce(SUM) of four reporting scalars — sum chi2, sum LM trials, #non-finite estimates, #ranges the outlier gate
+        rejected in the last epoch (localization.cpp:306-313, recomputed here from the last two epochs' outputs);
+    (1) all-gather of one result slab per rank (the last epoch: [3 position + 1 chi2][B] doubles) as one consumer of the whole batch
+        would ask for it; every rank checks that its own slice of the gathered batch is bit-identical to what it sent and that the
+        gathered batch's checksum equals the all-reduced sum of the per-rank checksums.
+    RCCL (backend nccl) on device tensors on a GPU node; gloo on host tensors in the one-GPU rehearsal.  Every rank returns the object."""
+    import numpy as np
+    torch = D.torch
+    from localization_amd.synthetic import ANCHORS_8
+    w0 = args.warmup * E
+    chi = out_chi2[w0:]
+    fin = torch.isfinite(chi)
+    nonfinite = int((~torch.isfinite(out_pos[w0:])).any(dim=1).sum().item())
+    anchors = torch.from_numpy(np.asarray(ANCHORS_8, dtype=np.float64)).to(out_pos.device)
+    prior = out_pos[-2]                                                     # [3][B]: the estimate the last epoch's gate looked at
+    d_last = dist_tiles[total_steps * E - 1].permute(0, 2, 1).reshape(-1, B)[: anchors.shape[0]].double()   # [M][B]
+    pred = (prior[None, :, :] - anchors[:, :, None]).norm(dim=1)           # [M][B]
+    gated = int(((pred - d_last).abs() > 1.0).sum().item())
+    local = [float(torch.where(fin, chi, torch.zeros_like(chi)).sum().item()), float(out_trials[w0:].double().sum().item()), float(nonfinite), float(gated)]
+    slab = torch.cat([out_pos[-1], out_chi2[-1][None, :]], dim=0).contiguous()   # [4][B] f64
+    csum_local = int(slab.view(torch.int64).sum().item())                   # wrap-around sum of the bit patterns
+    out = {"backend": ("rccl (torch.distributed nccl)" if D.backend == "nccl" else "gloo (rehearsal)") if D.world > 1 else "none (1 rank)",
+           "ranks": D.world, "scalars": ["sum_chi2", "sum_lm_trials", "n_nonfinite_estimates", "n_gated_ranges_last_epoch"]}
+    if D.world == 1:
+        out.update({"all_reduce": {"values": local, "bytes": 0, "ms": 0.0}, "all_gather": {"bytes": 0, "ms": 0.0, "checksum_ok": True},
+                    "bytes": 0, "ms": 0.0, "note": "one rank: nothing to exchange (the sums are rank 0's own)"})
+        return out
+    import torch.distributed as dist
+    cdev = D.dev if D.backend == "nccl" else "cpu"
+    D.barrier()
+    t0 = time.perf_counter()
+    v = torch.tensor(local, dtype=torch.float64, device=cdev)
+    dist.all_reduce(v, op=dist.ReduceOp.SUM)
+    if D.backend == "nccl":
+        torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    send = slab if D.backend == "nccl" else slab.cpu()
+    parts = [torch.empty_like(send) for _ in range(D.world)]
+    dist.all_gather(parts, send)
+    if D.backend == "nccl":
+        torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    cs = torch.tensor([csum_local], dtype=torch.int64, device=cdev)
+    dist.all_reduce(cs, op=dist.ReduceOp.SUM)
+    whole = torch.cat(parts, dim=1)                                         # [4][world * B]
+    ok = bool(torch.equal(parts[D.rank].view(torch.int64), send.view(torch.int64))) and int(whole.view(torch.int64).sum().item()) == int(cs.item())
+    okt = torch.tensor([1 if ok else 0], dtype=torch.int64, device=cdev)
+    dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+    nb_red, nb_gat = v.numel() * 8, send.numel() * 8 * D.world
+    out.update({"all_reduce": {"values": [float(x) for x in v.tolist()], "rank0_values": local, "bytes": nb_red, "ms": (t1 - t0) * 1e3},
+                "all_gather": {"bytes": nb_gat, "slab_shape_per_rank": list(send.shape), "ms": (t2 - t1) * 1e3, "checksum_ok": bool(okt.item() == 1)},
+                "bytes": nb_red + nb_gat, "ms": (t2 - t0) * 1e3,
+                "note": "first call of each collective on this process group (connection set-up included); reporting only, outside the timed region"})
+    if not out["all_gather"]["checksum_ok"]:
+        raise SystemExit("bench.py: the all-gathered result slab does not match what the ranks sent")
+    return out
+
+
 def hbm_roofline(kernel, algo_bytes_per_launch, kern_ms_avg, n_launch, unit_note):
     ach = algo_bytes_per_launch / (kern_ms_avg * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
@@ -236,13 +301,15 @@ def hbm_roofline(kernel, algo_bytes_per_launch, kern_ms_avg, n_launch, unit_note
 
 
 # ---------------------------------------------------------------------------------------------------------------- legs
-def leg_cfg2_numeric(D, args, stream, B, E, M):
-    """cfg2 in the REFERENCE's configuration: g2o's central-difference range Jacobians (types_edge_se3range.h:45-74)."""
+def leg_cfg2_mode(D, args, stream, B, E, M, jac, oracle_sample=None):
+    """cfg2 in the Jacobian mode the headline did NOT run.  With the default headline (numeric = g2o's central differences,
+    types_edge_se3range.h:45-74: the reference's configuration) this is the opt-in analytic fast mode."""
+    import numpy as np
     import localization_amd as la
     from localization_amd.synthetic import ANCHORS_8
     torch = D.torch
     steps, warmup = max(2, min(args.steps, 5)), 1
-    solver = la.SnapshotSolver(ANCHORS_8, B, maximum_iteration=10, distance_outlier=1.0, jacobian="numeric", device=D.local_rank)
+    solver = la.SnapshotSolver(ANCHORS_8, B, maximum_iteration=10, distance_outlier=1.0, jacobian=jac, device=D.local_rank)
     solver.set_positions(stream["init"])
     n_ep = stream["dist_tiles"].shape[0]
     out_pos = torch.empty((E, 3, B), dtype=torch.float64, device=D.dev)
@@ -252,8 +319,14 @@ def leg_cfg2_numeric(D, args, stream, B, E, M):
         k = (i * E) % (n_ep - E + 1)
         solver.solve_device(stream["dist_tiles"][k:k + E], stream["err_tiles"][k:k + E], out_pos, out_chi2, None)
 
+    cross = None
     for i in range(warmup):
         step(i)
+        if i == 0 and oracle_sample is not None:   # the first epochs from the initial estimates: what the CPU sample solved
+            ne, nt, rp = oracle_sample
+            ne = min(ne, E)
+            torch.cuda.synchronize()
+            cross = float(np.abs(out_pos[:ne, :, :nt].cpu().numpy() - rp[:ne]).max())
     D.barrier()
     solver.timing_begin(steps)
     t0 = time.perf_counter()
@@ -264,56 +337,77 @@ def leg_cfg2_numeric(D, args, stream, B, E, M):
     n_launch, _, kern_ms = solver.timing_end()
     solver.close()
     upd = float(B) * E
-    return {"workload": "BASELINE cfg2 with g2o's numeric range Jacobians (delta = 1e-9): the reference's exact configuration",
-            "metric": "localization updates/sec", "value": upd * steps * D.world / elapsed, "unit": "updates/s", "steps": steps,
-            "ms_per_step": elapsed / steps * 1e3, "scaling": "weak", "dtype": "f64", "batch_per_gpu": B, "epochs_per_step": E,
-            "roofline": hbm_roofline("snapshot_lm_kernel<.., JAC = numeric>", ALGO_BYTES_PER_UPDATE * upd, kern_ms, n_launch,
-                                     "120 B/update; VALU-bound (six extra IEEE square roots per edge)")}
+    numeric = jac == "numeric"
+    res = {"workload": "BASELINE cfg2 with " + ("g2o's numeric range Jacobians (delta = 1e-9): the reference's exact configuration" if numeric else
+                                                 "the analytic range Jacobian: the opt-in fast mode (loc_snapshot_params.jacobian = LOC_JAC_ANALYTIC)"),
+           "metric": "localization updates/sec", "value": upd * steps * D.world / elapsed, "unit": "updates/s", "steps": steps,
+           "ms_per_step": elapsed / steps * 1e3, "scaling": "weak", "dtype": "f64", "batch_per_gpu": B, "epochs_per_step": E, "jacobian": jac,
+           "roofline": hbm_roofline(f"snapshot_lm_kernel<.., JAC = {jac}>", ALGO_BYTES_PER_UPDATE * upd, kern_ms, n_launch,
+                                    "120 B/update; VALU-issue bound" + (" (six extra IEEE square roots per edge)" if numeric else ""))}
+    if cross is not None:
+        res["max_abs_diff_vs_cpu_baseline_m"] = cross
+        res["diff_note"] = ("this leg's Jacobian mode against the headline's cpu_baseline sample (oracle, numeric Jacobians): a CROSS-mode figure at the "
+                            "reference's fixed 10 LM iterations, i.e. iterates that are not converged (SURVEY §8(c)'s 1e-5 m holds at convergence)")
+    return res
 
 
 def leg_cfg3(D, args):
-    """BASELINE cfg3: 8 anchors + IMU rotation prior + antenna lever arm, 6-DoF, B = 65 536 tags per GPU (fusion kernel)."""
+    """BASELINE cfg3: 8 anchors + IMU rotation prior + antenna lever arm, 6-DoF, B = 65 536 tags per GPU (fusion kernel).
+    A step = one launch over 64 resident epochs; odd steps replay them in reverse order (the random walk walked back: still a
+    continuous trajectory from where the previous step ended), so no state is re-uploaded and `value` is wall time like every other leg."""
     import numpy as np
     import localization_amd as la
     from localization_amd.synthetic import make_fusion_stream
     torch = D.torch
     B, E = args.batch, 64
-    steps, warmup = max(2, min(args.steps, 5)), 1
+    steps, warmup = max(2, min(args.steps, 6)), 2
     s = make_fusion_stream(B, E, seed=args.seed + 1000 * D.rank)
     dist = torch.from_numpy(la.pack_ranges(s["dist"])).to(D.dev)
     err = torch.from_numpy(la.pack_ranges(s["err"])).to(D.dev)
     imu = torch.from_numpy(s["imu"]).to(D.dev)
+    fwd = (dist, err, imu)
+    rev = tuple(x.flip(0).contiguous() for x in fwd)
     out_pose = torch.empty((E, 7, B), dtype=torch.float64, device=D.dev)
     out_chi2 = torch.empty((E, B), dtype=torch.float64, device=D.dev)
-    kms = []
-
-    def step(i):
-        # every step replays the same 64 resident epochs from the same start (the state reset is a 3.7 MB upload)
-        f.set_poses(s["init"])
-        torch.cuda.synchronize()
-        f.solve_device(dist, err, imu, out_pose, out_chi2, None)
-        torch.cuda.synchronize()
-        kms.append(f.last_kernel_ms())
-
-    # the reference's configuration (numeric range Jacobians) first, then the analytic fast mode (`value`)
-    f = la.FusionSolver(s["anchors"], B, antenna_offset=s["offset"], maximum_iteration=10, distance_outlier=3.0, device=D.local_rank, jacobian="numeric")
-    D.timed(step, warmup, steps)
-    kern_ms_num = D.max_over_ranks(float(np.mean(kms[warmup:])))
-    f.close()
-    kms.clear()
-    f = la.FusionSolver(s["anchors"], B, antenna_offset=s["offset"], maximum_iteration=10, distance_outlier=3.0, device=D.local_rank, jacobian="analytic")
-    elapsed = D.timed(step, warmup, steps)
-    kern_ms = D.max_over_ranks(float(np.mean(kms[warmup:])))   # the slowest rank's kernel time: comparable with the wall-time legs
     upd = float(B) * E
+    modes = {}
+    first_pose = None
+    for jac in ("analytic", "numeric"):   # (the reference's configuration last: its first-step output is what the CPU sample is compared with)
+        f = la.FusionSolver(s["anchors"], B, antenna_offset=s["offset"], maximum_iteration=10, distance_outlier=3.0, device=D.local_rank, jacobian=jac)
+        f.set_poses(s["init"])
+        kms = []
+
+        def step(i):
+            d, e, q = fwd if i % 2 == 0 else rev
+            f.solve_device(d, e, q, out_pose, out_chi2, None)
+
+        step(0)
+        torch.cuda.synchronize()
+        first_pose = out_pose.clone()
+        for i in range(1, warmup):
+            step(i)
+        D.barrier()
+        t0 = time.perf_counter()
+        for i in range(warmup, warmup + steps):
+            step(i)
+            if args.cfg3_kernel_times:   # (HIP-event time of every launch: costs a synchronize per step, so it is not the default)
+                torch.cuda.synchronize(); kms.append(f.last_kernel_ms())
+        D.barrier()
+        elapsed = D.max_over_ranks(time.perf_counter() - t0)
+        kern_ms = D.max_over_ranks(f.last_kernel_ms())   # the last launch's HIP-event time on the slowest rank
+        f.close()
+        modes[jac] = {"elapsed": elapsed, "kern_ms": kern_ms}
+    num, ana = modes["numeric"], modes["analytic"]
     res = {"workload": "BASELINE cfg3: 8 anchors + IMU rotation prior + antenna lever arm, 6-DoF, g2o-style LM, 10 iterations",
-           "metric": "localization updates/sec", "value": upd * D.world / (kern_ms * 1e-3), "unit": "updates/s", "steps": steps,
-           "ms_per_step": elapsed / steps * 1e3, "value_note": "updates / kernel time (HIP events on the launch stream): the step also "
-           "re-uploads the initial poses, which is not part of the hot path", "scaling": "weak", "dtype": "f64", "batch_per_gpu": B,
-           "epochs_per_step": E, "jacobian": "analytic",
-           "value_reference_config": float(B) * E * D.world / (kern_ms_num * 1e-3),
-           "reference_config": {"jacobian": "numeric (g2o central differences)", "kernel": "fusion_lm_kernel<JAC = numeric>", "kernel_ms_avg": kern_ms_num,
-                                "roofline_frac": ALGO_BYTES_CFG3 * float(B) * E / (kern_ms_num * 1e-3) / 1e9 / HBM_PEAK_GBS},
-           "roofline": hbm_roofline("fusion_lm_kernel", ALGO_BYTES_CFG3 * upd, kern_ms, len(kms) - warmup, "248 B/update; VALU-issue bound")}
+           "metric": "localization updates/sec", "value": upd * steps * D.world / num["elapsed"], "unit": "updates/s", "steps": steps,
+           "ms_per_step": num["elapsed"] / steps * 1e3, "scaling": "weak", "dtype": "f64", "batch_per_gpu": B,
+           "epochs_per_step": E, "jacobian": "numeric",
+           "value_note": "wall time of the timed steps (barrier + synchronize on both sides), numeric Jacobians = the reference's configuration",
+           "value_fast_mode": upd * steps * D.world / ana["elapsed"],
+           "fast_mode": {"jacobian": "analytic", "ms_per_step": ana["elapsed"] / steps * 1e3, "kernel_ms_last": ana["kern_ms"],
+                         "roofline_frac": ALGO_BYTES_CFG3 * upd / (ana["kern_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+           "roofline": hbm_roofline("fusion_lm_kernel<JAC = numeric>", ALGO_BYTES_CFG3 * upd, num["kern_ms"], 1,
+                                    "248 B/update; VALU-issue bound; kernel time = HIP events around the last timed launch")}
     if D.rank == 0 and D.world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
         nt, ne = 512, 32
@@ -323,8 +417,8 @@ def leg_cfg3(D, args):
         dt = time.perf_counter() - t0
         res["cpu_baseline"] = {"value": nt * ne / dt, "unit": "updates/s", "cores": 1, "kind": "port",
                                "sample": f"first {nt} tags x {ne} epochs ({dt:.1f} s): oracle g2o restatement, numeric Jacobians, 1 thread",
-                               "max_abs_diff_vs_gpu": float(np.abs(out_pose[:ne, :, :nt].cpu().numpy() - rp).max())}
-    f.close()
+                               "max_abs_diff_vs_gpu": float(np.abs(first_pose[:ne, :, :nt].cpu().numpy() - rp).max()),
+                               "diff_note": "numeric Jacobians on both sides (pose entries: metres and quaternion components)"}
     return res
 
 
@@ -357,19 +451,19 @@ def _window_leg(D, args, wb, anchors, bw_max, name, workload, metric, unit, algo
         solver.close()
         return el, n_l, k_ms, kind
 
-    # the reference's configuration first (g2o's numeric range Jacobians), then the analytic fast mode (`value`, as in earlier rounds)
-    el_num, _, k_ms_num, kind_num = run("numeric")
-    poses_numeric = wb.poses[:, :, 9:].copy()
-    elapsed, n_launch, kern_ms, kind = run("analytic")
+    # the analytic fast mode first, then the reference's configuration (g2o's numeric range Jacobians): `value`, and what stays in wb
+    el_ana, _, k_ms_ana, kind_ana = run("analytic")
+    poses_analytic = wb.poses[:, :, 9:].copy()
+    elapsed, n_launch, kern_ms, kind = run("numeric")
     res = {"workload": workload, "metric": metric, "value": float(total_instances) * steps / elapsed, "unit": unit, "steps": steps,
            "ms_per_step": elapsed / steps * 1e3, "scaling": "strong", "dtype": "f64", "instances_per_gpu": B,
-           "instances_total": int(total_instances), "jacobian": "analytic", "mean_lm_trials": float(wb.result[:, 4].mean()),
+           "instances_total": int(total_instances), "jacobian": "numeric", "mean_lm_trials": float(wb.result[:, 4].mean()),
+           "jacobian_note": "g2o's central differences, delta = 1e-9 (types_edge_se3range.h:45-74): the reference's configuration, the library default",
            "elimination_levels": float(wb.result[0, 7] // 65536), "factor_blocks": float(int(wb.result[0, 7]) % 65536),
            "root_supernode_poses": float(round((wb.result[0, 7] % 1.0) * 16)),
-           "value_reference_config": float(total_instances) * steps / el_num,
-           "reference_config": {"jacobian": "numeric (g2o central differences, delta = 1e-9: types_edge_se3range.h:45-74)", "kernel": kind_num,
-                                "ms_per_step": el_num / steps * 1e3, "kernel_ms_avg": k_ms_num,
-                                "roofline_frac": algo_bytes_per_instance * B / (k_ms_num * 1e-3) / 1e9 / HBM_PEAK_GBS},
+           "value_fast_mode": float(total_instances) * steps / el_ana,
+           "fast_mode": {"jacobian": "analytic (opt-in)", "kernel": kind_ana, "ms_per_step": el_ana / steps * 1e3, "kernel_ms_avg": k_ms_ana,
+                         "roofline_frac": algo_bytes_per_instance * B / (k_ms_ana * 1e-3) / 1e9 / HBM_PEAK_GBS},
            "roofline": hbm_roofline(kind, algo_bytes_per_instance * B, kern_ms, n_launch, name)}
     tr = window_traffic(leg, D.world) if leg else None
     if tr and "stale" in tr:
@@ -395,15 +489,16 @@ def _window_leg(D, args, wb, anchors, bw_max, name, workload, metric, unit, algo
                                "sample": f"first {n_cpu} instances ({dt:.1f} s): oracle g2o restatement (dense Cholesky, numeric range Jacobians), 1 thread",
                                "max_abs_diff_vs_gpu_m": float(np.abs(wb.poses[:n_cpu, :, 9:] - want).max()),
                                "median_abs_diff_vs_gpu_m": float(np.median(np.abs(wb.poses[:n_cpu, :, 9:] - want).max(axis=(1, 2)))),
-                               "max_abs_diff_vs_gpu_reference_config_m": float(np.abs(poses_numeric[:n_cpu] - want).max()),
-                               "median_abs_diff_vs_gpu_reference_config_m": float(np.median(np.abs(poses_numeric[:n_cpu] - want).max(axis=(1, 2)))),
-                               "diff_note": "oracle: g2o's central differences (the reference's configuration). *_vs_gpu_m: the analytic GPU leg; "
-                                            "*_reference_config_m: the numeric GPU leg (same mode on both sides).  Unconverged iterates of a few "
-                                            "instances follow different, equally valid LM accept / reject sequences (DESIGN.md §3)"}
-        if parity_fn is not None and n_parity > 0:   # the same Jacobian mode on both sides
+                               "max_abs_diff_vs_gpu_fast_mode_m": float(np.abs(poses_analytic[:n_cpu] - want).max()),
+                               "median_abs_diff_vs_gpu_fast_mode_m": float(np.median(np.abs(poses_analytic[:n_cpu] - want).max(axis=(1, 2)))),
+                               "diff_note": "oracle: g2o's central differences (the reference's configuration). *_vs_gpu_m: the numeric GPU leg = `value` "
+                                            "(the same mode on both sides); *_fast_mode_m: the analytic GPU leg against the same oracle run (cross-mode, "
+                                            "fixed 10 LM iterations).  Unconverged iterates of a few instances follow different, equally valid LM "
+                                            "accept / reject sequences (DESIGN.md §3)"}
+        if parity_fn is not None and n_parity > 0:   # the analytic mode on both sides
             same = parity_fn(n_parity)
-            res["cpu_baseline"]["max_abs_diff_vs_gpu_same_jacobian_mode_m"] = float(np.abs(wb.poses[:n_parity, :, 9:] - same).max())
-            res["cpu_baseline"]["same_mode_sample"] = f"first {n_parity} instances, oracle with analytic Jacobians like the GPU leg"
+            res["cpu_baseline"]["max_abs_diff_fast_mode_vs_analytic_oracle_m"] = float(np.abs(poses_analytic[:n_parity] - same).max())
+            res["cpu_baseline"]["fast_mode_sample"] = f"first {n_parity} instances, oracle with analytic Jacobians like the GPU's fast mode"
     wb.poses[:] = poses0
     return res
 
@@ -571,6 +666,122 @@ def leg_cfg1_node(D, args):
     return out
 
 
+def leg_node_se3(D, args, which):
+    """The drop-in node on windows WITH EdgeSE3 factors, per message, in the reference's configuration (numeric Jacobians), rank 0 only:
+      node_uwb_twist       cfg/uwb_twist.yaml (T = 15, 12 LM iterations, vmax 1): ranges to four anchors interleaved with twist messages
+                           (addTwistEdge: EdgeSE3 between consecutive poses, localization.cpp:438-459, 560-605); a solve per range message;
+      node_uwb_pose_T500   cfg/uwb_pose.yaml AT ITS OWN SIZE (trajectory_length 500, cfg/uwb_pose.yaml:3,8): ranges + key-frame pose factors
+                           (addPoseEdge, localization.cpp:254-290); the window is filled with publishing off, then the 500-pose solve is timed.
+    Synthetic messages (the example recording has neither topic), the oracle front-end timed on the same messages."""
+    if D.rank != 0:
+        return {"skipped": "rank 0 only (a latency figure, not a throughput one)"}
+    import numpy as np
+    import localization_amd as la
+    anch = np.array([[3, -3, 0.58], [3, 3, 1.97], [-3, 3, 0.54], [-3, -3, 1.76]], dtype=float)   # the example recording's anchors
+    ids = [100, 101, 102, 103, 200]
+    pos = np.concatenate([anch, [[0.0, 0.0, 1.0]]])
+    rng = np.random.default_rng(args.seed + 31)
+    if which == "node_uwb_twist":
+        cfg = dict(trajectory_length=15, maximum_velocity=1.0, distance_outlier=1.0, maximum_iteration=12, minimum_optimize_error=1000.0,
+                   publish_range=True, publish_twist=False)
+        msgs, truth, t = [], np.array([0.3, -0.2, 1.0]), 50.0
+        vel = np.array([0.25, 0.1, 0.0])
+        for step in range(600):
+            t += 1.0 / 60.0
+            truth = truth + vel / 60.0
+            if step % 2 == 0:
+                tw = np.concatenate([vel + rng.normal(0, 0.02, 3), rng.normal(0, 0.01, 3)])
+                msgs.append(("twist", t, tw, (np.eye(6) * 1e-2).ravel()))
+            else:
+                a = (step // 2) % 4
+                msgs.append(("range", t, ids[a], float(np.float32(np.linalg.norm(truth - anch[a]) + rng.normal(0, 0.03)))))
+
+        def replay(obj):
+            lat, xyz = [], []
+            for m in msgs:
+                if m[0] == "twist":
+                    obj.add_twist(m[1], m[2], m[3], "uwb")
+                else:
+                    t0 = time.perf_counter()
+                    o = obj.add_range(200, m[2], m[1], m[3], 0.055, 0, "uwb")
+                    dt = time.perf_counter() - t0
+                    if o["solved"]:
+                        lat.append(dt * 1e3); xyz.append(np.array(o["realtime"][1:4]))
+            return np.array(lat[20:]), np.array(xyz)
+
+        node = la.LocalizationNode(ids, pos, jacobian="numeric", device=D.local_rank, **cfg)
+        lat, xyz = replay(node)
+        pt, kind = node.last_timing(), node.last_kernel_kind()
+        node.close()
+        out = {"metric": "latency per range message (one sliding-window solve, EdgeSE3 chain)", "unit": "ms", "higher_is_better": False,
+               "workload": "cfg/uwb_twist.yaml: 15-pose window, range edges + twist EdgeSE3 between consecutive poses, Cauchy, 12 LM iterations; numeric Jacobians",
+               "value": float(np.median(lat)), "p99": float(np.percentile(lat, 99)), "solves": int(len(lat) + 20), "kernel": kind, "jacobian": "numeric",
+               "last_solve_inside_library": {"pack_host": pt[0], "window_solve_call": pt[1], "of_which_kernel": pt[2]}}
+        if not args.no_cpu_baseline:
+            from oracle import oracle as O
+            ora = O.LocalizationOracle(ids, pos, jac_mode=O.JAC_NUMERIC_G2O, **cfg)
+            olat, oxyz = replay(ora)
+            n = min(len(xyz), len(oxyz))
+            out["cpu_baseline"] = {"value": float(np.median(olat)), "unit": "ms", "cores": 1, "kind": "port",
+                                   "sample": "the same 600 messages through oracle/localization_oracle.c (g2o restatement, numeric Jacobians), one thread, median per solved message",
+                                   "median_abs_diff_vs_gpu_m": float(np.median(np.abs(xyz[:n] - oxyz[:n]).max(axis=1))),
+                                   "max_abs_diff_vs_gpu_m": float(np.abs(xyz[:n] - oxyz[:n]).max())}
+        return out
+    # ---- cfg/uwb_pose.yaml at trajectory_length 500
+    cfg = dict(trajectory_length=500, maximum_velocity=0.5, distance_outlier=1.0, maximum_iteration=10, minimum_optimize_error=1000.0,
+               publish_range=False, publish_pose=False)
+    cov = (np.eye(6) * 1e-4).ravel()
+    msgs, truth, t = [], np.array([0.0, 0.0, 1.0]), 100.0
+    for step in range(520):
+        t += 0.05
+        truth = truth + np.array([0.004, 0.002 * np.sin(step / 20.0), 0.0])
+        rel = np.array([0.004 * ((step % 8) + 1), 0.0, 0.0, 0.0, 0.0, 0.0, 1.0]) + np.concatenate([rng.normal(0, 1e-3, 3), np.zeros(4)])
+        msgs.append((t, rel, f"key_{step // 8}", ids[step % 4], float(np.float32(np.linalg.norm(truth - anch[step % 4]) + rng.normal(0, 0.02)))))
+
+    def fill(obj):
+        t0 = time.perf_counter()
+        for (tt, rel, frame, aid, d) in msgs:
+            obj.add_pose(tt, rel, cov, frame)
+            obj.add_range(200, aid, tt + 0.01, d, 0.055, 0, "uwb")
+        return (time.perf_counter() - t0) * 1e3 / (2 * len(msgs))
+
+    node = la.LocalizationNode(ids, pos, jacobian="numeric", device=D.local_rank, **cfg)
+    ingest_ms = fill(node)
+    lat, parts = [], []
+    g = None
+    for rep in range(4):
+        t0 = time.perf_counter()
+        g = node.solve()
+        lat.append((time.perf_counter() - t0) * 1e3)
+        parts.append(node.last_timing())
+    kind = node.last_kernel_kind()
+    gpath = node.path(200)
+    first = lat[0]
+    out = {"metric": "latency of one 500-pose window solve (cfg/uwb_pose.yaml at its own trajectory_length)", "unit": "ms", "higher_is_better": False,
+           "workload": "cfg/uwb_pose.yaml: trajectory_length 500 (3 000 unknowns), one anchor range + one key-frame EdgeSE3 per pose (new key every 8), Cauchy, "
+                       "10 LM iterations; numeric Jacobians",
+           "value": float(np.median(lat)), "solves_timed": len(lat), "first_solve_ms": float(first), "kernel": kind, "jacobian": "numeric",
+           "outer_iterations": int(g["outer_iterations"]), "lm_trials": int(g["lm_trials"]), "ingest_ms_per_message_no_solve": ingest_ms,
+           "inside_library_median": {"pack_host": float(np.median([p[0] for p in parts])), "window_solve_call": float(np.median([p[1] for p in parts])),
+                                     "of_which_kernel": float(np.median([p[2] for p in parts]))},
+           "value_note": "repeated loc_node_solve calls on the filled window (each continues from the previous estimates, as consecutive messages would)"}
+    node.close()
+    if not args.no_cpu_baseline:
+        from oracle import oracle as O
+        ora = O.LocalizationOracle(ids, pos, jac_mode=O.JAC_NUMERIC_G2O, **cfg)
+        fill(ora)
+        olat = []
+        for rep in range(4):
+            t0 = time.perf_counter()
+            ora.solve()
+            olat.append((time.perf_counter() - t0) * 1e3)
+        opath = ora.path(200)
+        out["cpu_baseline"] = {"value": float(np.median(olat)), "unit": "ms", "cores": 1, "kind": "port",
+                               "sample": "the same 1 040 messages, then 4 solves of the 500-pose window by oracle/ (g2o restatement with a dense-band Cholesky, numeric Jacobians), one thread",
+                               "max_abs_diff_vs_gpu_m": float(np.abs(gpath[:, 1:4] - opath[:, 1:4]).max())}
+    return out
+
+
 def leg_cfg4(D, args):
     """BASELINE cfg4: Monte-Carlo anchor self-calibration, 10 unknown anchors x 256 timesteps per hypothesis, 1 024 hypotheses in total
     (strong scaling: the ranks share them; at N = 1 one GPU solves all 1 024, and the 128-hypothesis share of an 8-GPU job is timed too)."""
@@ -600,7 +811,7 @@ def leg_cfg4(D, args):
         args2 = argparse.Namespace(**vars(args)); args2.no_cpu_baseline = True
         share = _window_leg(D, args2, tiled(128), anchors, nv - 1, note, work, "hypothesis solves/sec", "solves/s", ALGO_BYTES_CFG4_PER_IT * 10, 128,
                             lambda n: None, 0)
-        res["share_of_8_gpu_job_128_hypotheses"] = {k: share[k] for k in ("value", "ms_per_step", "value_reference_config")}
+        res["share_of_8_gpu_job_128_hypotheses"] = {k: share[k] for k in ("value", "ms_per_step", "value_fast_mode")}
         res["share_of_8_gpu_job_128_hypotheses"]["kernel_ms_avg"] = share["roofline"]["kernel_ms_avg"]
     return res
 
@@ -612,7 +823,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=65536, help="tags per GPU")
     ap.add_argument("--epochs", type=int, default=128, help="epochs per launch (step)")
-    ap.add_argument("--jacobian", default="analytic", choices=["analytic", "numeric"])
+    ap.add_argument("--jacobian", default="numeric", choices=["analytic", "numeric"],
+                    help="numeric = g2o's central differences: the reference's configuration and every library default (the headline); "
+                         "analytic = the opt-in fast mode")
     ap.add_argument("--lpi", type=int, default=0, help="lanes per tag (0 = library default)")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--seed", type=int, default=0)
@@ -621,9 +834,10 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the driver's multi-GPU runs); gloo only to rehearse N > 1 on a one-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cfg3-kernel-times", action="store_true", help="cfg3 leg: HIP-event time of every launch (a synchronize per step)")
     ap.add_argument("--cpu-tags", type=int, default=2048)
     ap.add_argument("--cpu-epochs", type=int, default=96)
-    ap.add_argument("--legs", default="all", help="secondary legs: all, none, or a comma list of cfg2_numeric,cfg3,cfg5,cfg4,cfg1_windows,cfg1_node")
+    ap.add_argument("--legs", default="all", help="secondary legs: all, none, or a comma list of cfg2_analytic,cfg2_numeric,cfg3,cfg5,cfg4,cfg1_windows,cfg1_node,node_uwb_twist,node_uwb_pose_T500")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -685,26 +899,30 @@ def main():
     value = total_updates / elapsed
     achieved_gbs = ALGO_BYTES_PER_UPDATE * updates_per_launch / (kern_ms_avg * 1e-3) / 1e9
 
+    # ---- the reporting collectives, AFTER the timed region (the solve path has none) -----------------------
+    coll = reporting_collectives(D, args, out_pos, out_chi2, out_trials, dist_t, E, total_steps, B)
+
     res = None
+    oracle_sample = None
     if rank == 0:
         trials_mean = float(out_trials[args.warmup * E:].cpu().numpy().mean())
         err_last = torch.from_numpy(np.sqrt(((out_pos[-1].cpu().numpy() - stream["truth_last"].cpu().numpy()) ** 2).sum(axis=0)))
         # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process); they apply to the
         # default launch shape AND to the kernel source they were measured on: a hash of the sources is stored with them
-        traffic, traffic_src, f64_flop, issue_slots, issue_ceiling, stale = None, None, None, None, None, None
+        pm, stale, ceiling = None, None, None
         prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(prof) and (B, E) == (65536, 128) and args.jacobian == "analytic":
+        if os.path.exists(prof) and (B, E) == (65536, 128):
             try:
                 with open(prof) as f:
                     pj = json.load(f)
                 if pj.get("kernel_source_sha256") == kernel_source_hash(SNAPSHOT_KERNEL_SOURCES):
-                    traffic, traffic_src, f64_flop = pj["hbm_bytes_per_launch"], pj["source"], pj.get("f64_flop_per_launch")
-                    issue_slots, issue_ceiling = pj.get("issue_lane_slots_per_launch"), pj.get("measured_issue_ceiling_lane_slots_per_s")
+                    pm, ceiling = pj.get("modes", {}).get(args.jacobian), pj.get("measured_issue_ceiling_lane_slots_per_s")
                 else:
                     stale = ("stale: profiles/hbm_traffic.json was measured on a different snapshot_kernel.hip (source hash mismatch); "
                              "PMC-derived fields are withheld until the counters are re-collected")
             except Exception:
-                traffic = None
+                pm = None
+        numeric = args.jacobian == "numeric"
         res = {
             "metric": "localization updates/sec (8-anchor UWB, batch=65k)",
             "value": value, "unit": "updates/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -714,6 +932,9 @@ def main():
                                    "g2o-style LM with the reference's fixed 10 iterations, outlier gate 1 m",
                        "batch_per_gpu": B, "epochs_per_step": E, "updates_per_step_per_gpu": int(updates_per_launch),
                        "anchors": M, "lm_iterations": 10, "jacobian": args.jacobian,
+                       "jacobian_note": ("g2o's central differences, delta = 1e-9 (EdgeSE3Range has no linearizeOplus, types_edge_se3range.h:45-74): "
+                                         "the reference's configuration and the default of every library entry point") if numeric else
+                                        "the opt-in analytic fast mode (NOT the library default)",
                        "lanes_per_tag": solver.lanes_per_instance, "sharding": f"tags split over {n_gpus} GPU(s), no collective"},
             "lm_iterations_per_s": value * 10,
             "mean_lm_trials_per_update": trials_mean,
@@ -721,30 +942,34 @@ def main():
             "frac_err_gt_0p5m": float((err_last > 0.5).double().mean().item()),
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "frac_of_measured_copy_ceiling": achieved_gbs / HBM_COPY_GBS,
-                         "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                         "traffic": pm["hbm_bytes_per_launch"] if pm else None, "traffic_unit": "bytes per launch",
+                         "traffic_source": pm["source"] if pm else None,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_UPDATE * updates_per_launch,
-                         "kernel": "snapshot_lm_kernel", "kernel_ms_avg": kern_ms_avg, "launches_timed": n_launch,
+                         "kernel": f"snapshot_lm_kernel<.., JAC = {args.jacobian}>", "kernel_ms_avg": kern_ms_avg, "launches_timed": n_launch,
                          "algorithmic_bytes_per_update": ALGO_BYTES_PER_UPDATE,
                          "binding_resource": "valu_issue",
                          "note": "north_star names the HBM roofline, so `bound`/`frac` price the algorithmic bytes against 8 TB/s; "
                                  "at fp64 and the reference's 10 LM iterations the kernel is VALU-issue bound (see valu_issue / "
-                                 "valu_f64 and DESIGN.md), the HBM fraction is small by construction"},
+                                 "valu_f64 in this object and DESIGN.md), the HBM fraction is small by construction"},
         }
         if stale:
             res["roofline"]["stale"] = stale
-        if f64_flop:
-            tf = f64_flop / (kern_ms_avg * 1e-3) / 1e12
-            res["valu_f64"] = {"achieved_tflops": tf, "peak_tflops": F64_VECTOR_PEAK_TFLOPS, "frac": tf / F64_VECTOR_PEAK_TFLOPS,
-                               "note": "f64 add+mul+2*fma+trans lane-ops per launch (PMC, profiles/) / live kernel time; "
-                                       "the kernel is VALU-issue bound at one wave per SIMD, not HBM bound"}
-        if issue_slots and issue_ceiling:
-            rate = issue_slots / (kern_ms_avg * 1e-3)
-            res["valu_issue"] = {"achieved_lane_slots_per_s": rate, "measured_ceiling": issue_ceiling, "frac": rate / issue_ceiling,
-                                 "note": "(VALU + SALU wave-instructions per launch) x 64 lanes (PMC) / live kernel time, against the "
-                                         "measured one-wave-per-SIMD issue ceiling (tools/fp64_probe.hip): what actually bounds this kernel"}
+        if pm and pm.get("f64_flop_per_launch"):
+            tf = pm["f64_flop_per_launch"] / (kern_ms_avg * 1e-3) / 1e12
+            res["roofline"]["valu_f64"] = {"achieved_tflops": tf, "peak_tflops": F64_VECTOR_PEAK_TFLOPS, "frac": tf / F64_VECTOR_PEAK_TFLOPS,
+                                           "note": "f64 add+mul+2*fma+trans lane-ops per launch (PMC, profiles/) / live kernel time"}
+        if pm and pm.get("issue_lane_slots_per_launch") and ceiling:
+            rate = pm["issue_lane_slots_per_launch"] / (kern_ms_avg * 1e-3)
+            res["roofline"]["valu_issue"] = {"achieved_lane_slots_per_s": rate, "measured_ceiling": ceiling, "frac": rate / ceiling,
+                                             "valu_wave_insts_per_launch": pm.get("valu_wave_insts_per_launch"),
+                                             "note": "(VALU + SALU wave-instructions per launch) x 64 lanes (PMC) / live kernel time, against the "
+                                                     "measured one-wave-per-SIMD issue ceiling (tools/fp64_probe.hip): what actually bounds this kernel"}
+        if coll is not None:
+            res["collectives"] = coll
         if not args.no_cpu_baseline and n_gpus == 1:
-            res["cpu_baseline"] = cpu_baseline(ANCHORS_8, dist_t, err_t, stream["init"], min(args.cpu_tags, B),
-                                               min(args.cpu_epochs, E * total_steps), out_pos, M)
+            n_t, n_e = min(args.cpu_tags, B), min(args.cpu_epochs, E * total_steps)
+            res["cpu_baseline"], rp = cpu_baseline(ANCHORS_8, dist_t, err_t, stream["init"], n_t, n_e, out_pos, M, args.jacobian)
+            oracle_sample = (n_e, n_t, rp)
             try:  # a secondary figure: a host that refuses worker processes must not cost the bench its JSON line
                 res["cpu_baseline_all_cores"] = cpu_baseline_all_cores(ANCHORS_8, dist_t, err_t, stream["init"], args.cpu_tags // 2,
                                                                        min(args.cpu_epochs, E * total_steps), M)
@@ -754,12 +979,14 @@ def main():
     del out_pos, out_chi2, out_trials
 
     # ---- secondary legs (every rank takes part: they carry their own barriers) ------------------------------------------------
-    want = [] if args.legs == "none" else (["cfg2_numeric", "cfg3", "cfg5", "cfg4", "cfg1_windows", "cfg1_node"] if args.legs == "all" else args.legs.split(","))
+    other = "analytic" if args.jacobian == "numeric" else "numeric"
+    all_legs = ["cfg2_" + other, "cfg3", "cfg5", "cfg4", "cfg1_windows", "cfg1_node", "node_uwb_twist", "node_uwb_pose_T500"]
+    want = [] if args.legs == "none" else (all_legs if args.legs == "all" else args.legs.split(","))
     legs = {}
     for name in want:
         try:
-            if name == "cfg2_numeric":
-                out = leg_cfg2_numeric(D, args, stream, B, E, M)
+            if name in ("cfg2_numeric", "cfg2_analytic"):
+                out = leg_cfg2_mode(D, args, stream, B, E, M, name[5:], oracle_sample if name[5:] != args.jacobian else None)
             elif name == "cfg3":
                 out = leg_cfg3(D, args)
             elif name == "cfg5":
@@ -770,6 +997,8 @@ def main():
                 out = leg_cfg1_windows(D, args)
             elif name == "cfg1_node":
                 out = leg_cfg1_node(D, args)
+            elif name in ("node_uwb_twist", "node_uwb_pose_T500"):
+                out = leg_node_se3(D, args, name)
             else:
                 out = {"error": "unknown leg"}
         except Exception as exc:  # noqa: BLE001 — a secondary leg must not cost the bench its headline line
@@ -782,13 +1011,14 @@ def main():
     if rank == 0:
         if legs:
             res["legs"] = legs
-        num = legs.get("cfg2_numeric", {})
-        # the same workload in the REFERENCE's configuration (EdgeSE3Range has no linearizeOplus: g2o's numeric Jacobians), at top level
-        res["value_reference_config"] = num.get("value")
-        res["reference_config"] = {"jacobian": "numeric (g2o central differences, delta = 1e-9)", "ms_per_step": num.get("ms_per_step"),
-                                   "roofline_frac": (num.get("roofline") or {}).get("frac"),
-                                   "note": "`value` is the analytic-Jacobian fast mode (opt-in through loc_snapshot_params.jacobian); every library "
-                                           "default is the numeric mode measured here"} if num else None
+        oth = legs.get("cfg2_" + other, {})
+        key = "value_fast_mode" if other == "analytic" else "value_reference_config"
+        res[key] = oth.get("value")
+        res["other_jacobian_mode"] = {"jacobian": other, "value": oth.get("value"), "ms_per_step": oth.get("ms_per_step"),
+                                      "roofline_frac": (oth.get("roofline") or {}).get("frac"),
+                                      "note": "`value` is the numeric-Jacobian mode every library entry point defaults to (the reference's configuration); "
+                                              "this is the opt-in analytic mode (loc_snapshot_params.jacobian)" if other == "analytic" else
+                                              "`value` was run with --jacobian analytic (opt-in fast mode); this is the library default"} if oth else None
         print(json.dumps(res))
     D.close()
 

@@ -23,8 +23,10 @@
 extern "C" {
 #endif
 
-#define LOC_ABI_VERSION 3 /* 2: jacobian mode for every solver, resident window solves, loc_node_add_rl_range;
-                           * 3: numeric (g2o) Jacobians are the default everywhere, loc_shard_*, loc_window_last_kernel_kind */
+#define LOC_ABI_VERSION 4 /* 2: jacobian mode for every solver, resident window solves, loc_node_add_rl_range;
+                           * 3: numeric (g2o) Jacobians are the default everywhere, loc_shard_*, loc_window_last_kernel_kind;
+                           * 4: loc_window_set_option / _last_host_timing, loc_node_flush_tail / _last_kernel_kind, loc_fusion_timing_*;
+                           *    a large loc_window_solve_host drops the resident batch */
 
 typedef enum loc_status {
     LOC_OK = 0,
@@ -255,10 +257,28 @@ enum { LOC_WINDOW_KERNEL_NONE = -1, LOC_WINDOW_KERNEL_GENERAL = 0, LOC_WINDOW_KE
        LOC_WINDOW_KERNEL_WAVE3 = 6 /* translation-only chains of <= 64 poses: one wave per window (wave3_lm_kernel) */,
        LOC_WINDOW_KERNEL_WAVE6 = 7 /* 6-DoF chains of <= 64 poses (no EdgeSE3, one range edge per consecutive pair): wave6_lm_kernel */ };
 int loc_window_last_kernel_kind(const loc_window* w, int32_t* kind);
+/* Kernel-selection switches of ONE handle.  They are read from the environment ONCE, when the handle is created (LOCAMD_CHAIN_MIN_BATCH,
+ * LOCAMD_ARROW3, LOCAMD_TREE, LOCAMD_WAVE3, LOCAMD_WAVE6, LOCAMD_CHAIN3, LOCAMD_NO_ZERO_COPY: A/B runs and tests), never at solve
+ * time; this call changes them afterwards.  name / value:
+ *   "chain_min_batch"  as loc_window_set_chain_threshold (0: never anything but the general kernel; < 0: the default rule)
+ *   "arrow3"           -1 default (windows of more than 64 poses), 0 never, 1 whenever the batch qualifies
+ *   "tree"             -1 default, 0 never, 2 the lane-per-window variant (tree_lm_kernel)
+ *   "wave3" "wave6" "chain3" "zero_copy"   1 (default) / 0
+ *   "topology_cache"   1 (default) / 0: reuse the structural verdict of the previous batch when counts and index tables hash the same
+ * LOC_ERR_INVALID for an unknown name or value. */
+int loc_window_set_option(loc_window* w, const char* name, int64_t value);
+/* Host-side cost of the last loc_window_solve_host call, milliseconds: [0] argument validation, [1] structure analysis (kernel
+ * choice: hash of the index tables, chain / forest / arrowhead tests, host-built schedules), [2] staging + launch + copy back +
+ * synchronise, [3] 1.0 when the structural verdict came from the handle's cache, else 0.0 */
+int loc_window_last_host_timing(const loc_window* w, double* validate_topology_run_cached);
 /* Device-resident operation: upload n instances once (same host layouts as loc_window_solve_host), then run
  * loc_window_solve_resident any number of times — each launch starts from the uploaded estimates, is asynchronous on
  * hip_stream (NULL = the handle's own stream) and leaves poses / result on the device — and fetch them with
- * loc_window_download (synchronises).  loc_window_timing_begin/_end bracket resident launches with HIP events on the
+ * loc_window_download (synchronises).
+ * Mixing with loc_window_solve_host on the same handle: every loc_window_solve_host first waits for the last resident launch (a
+ * handle-owned event; the caller's stream is not kept).  A SMALL host solve (its inputs fit the 4 MiB staging block) leaves the
+ * resident batch intact.  A LARGE one reuses the resident batch's device arrays: it DROPS the resident batch — the next
+ * loc_window_solve_resident / loc_window_download return LOC_ERR_INVALID until loc_window_upload is called again.  loc_window_timing_begin/_end bracket resident launches with HIP events on the
  * stream they run on, like loc_snapshot_timing_*. */
 int loc_window_upload(loc_window* w, int64_t n_instances, const int32_t* counts, const double* poses,
                       const int32_t* r_idx, const double* r_val, const int32_t* p_idx, const double* p_val,
@@ -336,6 +356,13 @@ int32_t loc_node_number_measurements(const loc_node* n);
 /* Where the last solve's time went, milliseconds: [0] packing the window on the host, [1] the window solve call (copy in, launch, copy
  * out, synchronise), [2] of which the kernel (HIP events) — the reference prints the same figure per solve (CPPTimer, localization.cpp:166,191) */
 int loc_node_last_timing(const loc_node* n, double* pack_solve_kernel_ms);
+/* LOC_WINDOW_KERNEL_* of the node's last solve (LOC_WINDOW_KERNEL_NONE before the first) */
+int loc_node_last_kernel_kind(const loc_node* n, int32_t* kind);
+/* Localization::~Localization (localization.cpp:708-717): at destruction the reference appends path->poses[T/2 .. T-1] of the moving
+ * tag to its "optimized" log (every earlier row of that log is a published path[T/2]), so that the log ends with the newest half of the
+ * window.  Returns those rows (oldest first, 8 doubles each, the same poses loc_node_get_path gives at [T/2 .. T-1]) and their number;
+ * LOC_ERR_INVALID when capacity_poses < T - T/2.  The node stays usable. */
+int loc_node_flush_tail(loc_node* n, double* out_rows_by_8, int32_t capacity_poses);
 /* Fleet mode: with deferred on, add_* only mark the node "solve pending"; loc_nodes_solve_batch then solves every
  * pending node of the array in ONE launch per parameter group (returns how many were solved). */
 int loc_node_set_deferred(loc_node* n, int32_t on);
@@ -383,6 +410,9 @@ int loc_fusion_solve_host(loc_fusion* f, int32_t epochs, const float* dist_tiles
 int loc_fusion_solve_host_kmb(loc_fusion* f, int32_t epochs, const float* dist_kmb_host, const float* err_kmb_host,
                               const double* imu_host, double* out_pose_host, double* out_chi2_host, uint8_t* out_trials_host);
 int loc_fusion_last_kernel_ms(loc_fusion* f, double* ms);
+/* per-launch HIP-event pairs on the launch stream, as loc_snapshot_timing_* */
+int loc_fusion_timing_begin(loc_fusion* f, int32_t max_launches);
+int loc_fusion_timing_end(loc_fusion* f, int32_t* n_launches, double* total_ms, double* avg_ms);
 
 #ifdef __cplusplus
 }

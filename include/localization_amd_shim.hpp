@@ -4,6 +4,8 @@
 // one-liners on the caller's side.
 #pragma once
 #include <array>
+#include <cstdio>
+#include <ctime>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -49,7 +51,14 @@ public:
                                        (int32_t)(p.antennaOffset.size() / 3), p.antennaOffset.empty() ? nullptr : p.antennaOffset.data());
         if (rc != LOC_OK) throw std::runtime_error(std::string("localization_amd: ") + loc_last_error());
     }
-    ~Localization() { loc_node_destroy(node_); }
+    // Localization::~Localization (localization.cpp:708-717): with logging on, path->poses[T/2 .. T-1] goes to the optimized log
+    ~Localization() {
+        if (flag_save_file_ && node_) {
+            for (const PoseStampedLike& p : flushTail()) save_file(p, optimized_filename_);
+            std::printf("Results Loged to file: %s\n", optimized_filename_.c_str());
+        }
+        loc_node_destroy(node_);
+    }
     Localization(const Localization&) = delete;
     Localization& operator=(const Localization&) = delete;
 
@@ -77,8 +86,50 @@ public:
     bool addLidarEdge(double stamp, double z, const std::string& frame_id) {
         return handle(loc_node_add_lidar(node_, stamp, z, frame_id.c_str(), &last_));
     }
+    // void addRLRangeEdge(const uwb_reloc::uwbTalkData::ConstPtr&)        localization.cpp:378 (built with -DRELATIVE_LOCALIZATION, CMakeLists.txt:137)
+    // uwbTalkData: time_stamp, rqstrId, rspdrId, d, rqstr_vx / vy / vz
+    bool addRLRangeEdge(double time_stamp, int rqstrId, int rspdrId, double d, const std::array<double, 3>& rqstr_velocity) {
+        return handle(loc_node_add_rl_range(node_, rqstrId, rspdrId, time_stamp, d, rqstr_velocity.data(), &last_));
+    }
     // void solve(); void publish();                                        localization.cpp:164, :195
     bool solve() { return handle(loc_node_solve(node_, &last_)); }
+
+    // void set_file()                                                      localization.cpp:645-706: "<prefix>_realtime<stamp>.txt" and
+    // "<prefix>_optimized<stamp>.txt" with the reference's header lines; from then on every solve that publishes appends the realtime pose
+    // and path[T/2] (publish(), :221-225), and the destructor appends path[T/2 .. T-1].  stamp_suffix empty: "_%Y_%b_%d_%H_%M_%S.txt" of now.
+    void set_file(const std::string& name_prefix, const Params& p, const std::string& stamp_suffix = "") {
+        std::string s = stamp_suffix;
+        if (s.empty()) {
+            char buf[40];
+            const std::time_t now = std::time(nullptr);
+            std::strftime(buf, sizeof buf, "_%Y_%b_%d_%H_%M_%S.txt", std::localtime(&now));
+            s = buf;
+        }
+        realtime_filename_ = name_prefix + "_realtime" + s;
+        optimized_filename_ = name_prefix + "_optimized" + s;
+        for (const std::string& fn : {realtime_filename_, optimized_filename_}) {
+            std::FILE* f = std::fopen(fn.c_str(), "w");
+            if (!f) throw std::runtime_error("localization_amd: cannot open " + fn);
+            if (p.antennaOffset.empty()) {   // set_file(), :645-671
+                std::fprintf(f, "# iteration_max:%d\n# trajectory_length:%d\n# maximum_velocity:%g\n", p.maximum_iteration, p.trajectory_length, p.maximum_velocity);
+            } else {                          // set_file(antennaOffset), :673-706: the files are re-opened with ios::trunc, so this line is all that stays
+                std::fprintf(f, "# antenna offsets: ");
+                for (size_t i = 0; i < p.antennaOffset.size(); ++i) std::fprintf(f, "%g%s", p.antennaOffset[i], i + 1 < p.antennaOffset.size() ? "," : "\n");
+            }
+            std::fclose(f);
+        }
+        flag_save_file_ = true;
+    }
+    const std::string& realtimeFilename() const { return realtime_filename_; }
+    const std::string& optimizedFilename() const { return optimized_filename_; }
+    // path->poses[T/2 .. T-1]: what the destructor logs (loc_node_flush_tail)
+    std::vector<PoseStampedLike> flushTail() const {
+        std::vector<double> buf((size_t)trajectory_length_ * 8 + 8);
+        const int n = loc_node_flush_tail(node_, buf.data(), trajectory_length_);
+        std::vector<PoseStampedLike> out;
+        for (int i = 0; i < n; ++i) out.push_back(to_pose(&buf[(size_t)i * 8]));
+        return out;
+    }
 
     // what publish() would put on the wire after the last solve
     bool published() const { return last_.published != 0; }
@@ -101,8 +152,22 @@ private:
     }
     bool handle(int rc) {
         if (rc < 0) throw std::runtime_error(std::string("localization_amd: ") + loc_last_error());  // reference: map::at throws
+        if (rc == 1 && flag_save_file_ && last_.published) {   // publish(), localization.cpp:221-225
+            save_file(to_pose(last_.realtime), realtime_filename_);
+            save_file(to_pose(last_.optimized), optimized_filename_);
+        }
         return rc == 1;
     }
+    // Localization::save_file, localization.cpp:630-642: "%.9f" stamp, then x y z qx qy qz qw at the stream's default precision (6 digits)
+    static void save_file(const PoseStampedLike& p, const std::string& filename) {
+        std::FILE* f = std::fopen(filename.c_str(), "a");
+        if (!f) return;
+        std::fprintf(f, "%.9f %g %g %g %g %g %g %g\n", p.stamp, p.position[0], p.position[1], p.position[2], p.orientation_xyzw[0],
+                     p.orientation_xyzw[1], p.orientation_xyzw[2], p.orientation_xyzw[3]);
+        std::fclose(f);
+    }
+    bool flag_save_file_ = false;
+    std::string realtime_filename_, optimized_filename_;
     loc_node* node_ = nullptr;
     loc_node_output last_{};
     int trajectory_length_ = 0;

@@ -39,15 +39,15 @@ EXPORTED_SYMBOLS = [
     "loc_snapshot_solve_host_kmb", "loc_host_alloc", "loc_host_free",
     "loc_snapshot_timing_begin", "loc_snapshot_timing_end",
     "loc_window_create", "loc_window_destroy", "loc_window_set_anchors", "loc_window_lds_bytes", "loc_window_solve_host",
-    "loc_window_last_kernel_ms", "loc_window_set_endpoint1_offsets", "loc_window_set_jacobian", "loc_window_set_ordering", "loc_window_set_chain_threshold", "loc_window_last_kernel_kind", "loc_window_upload",
+    "loc_window_last_kernel_ms", "loc_window_set_endpoint1_offsets", "loc_window_set_jacobian", "loc_window_set_ordering", "loc_window_set_chain_threshold", "loc_window_last_kernel_kind", "loc_window_set_option", "loc_window_last_host_timing", "loc_window_upload",
     "loc_window_solve_resident", "loc_window_download", "loc_window_poses_device", "loc_window_result_device",
     "loc_window_timing_begin", "loc_window_timing_end",
     "loc_node_default_config", "loc_node_create", "loc_node_destroy", "loc_node_add_range", "loc_node_add_imu",
     "loc_node_add_pose", "loc_node_add_twist", "loc_node_add_lidar", "loc_node_add_rl_range", "loc_node_solve", "loc_node_get_path",
-    "loc_node_number_measurements", "loc_node_last_timing", "loc_node_set_deferred", "loc_node_solve_pending", "loc_nodes_solve_batch",
+    "loc_node_number_measurements", "loc_node_last_timing", "loc_node_last_kernel_kind", "loc_node_flush_tail", "loc_node_set_deferred", "loc_node_solve_pending", "loc_nodes_solve_batch",
     "loc_nodes_release_batch_cache",
     "loc_fusion_default_params", "loc_fusion_create", "loc_fusion_destroy", "loc_fusion_set_poses", "loc_fusion_get_poses",
-    "loc_fusion_solve_device", "loc_fusion_solve_host", "loc_fusion_solve_host_kmb", "loc_fusion_last_kernel_ms",
+    "loc_fusion_solve_device", "loc_fusion_solve_host", "loc_fusion_solve_host_kmb", "loc_fusion_last_kernel_ms", "loc_fusion_timing_begin", "loc_fusion_timing_end",
 ]
 
 

@@ -28,6 +28,9 @@ struct loc_fusion {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    std::vector<hipEvent_t> ev;   // loc_fusion_timing_*: one pair per launch
+    int ev_used = 0;
+    bool timing = false;
     long long epochs_done = 0;
     // staging for the host path
     float *d_dist = nullptr, *d_err = nullptr;
@@ -63,6 +66,7 @@ int loc_fusion_destroy(loc_fusion* f) {
     (void)hipSetDevice(f->device);
     fusion_free_staging(f);
     for (hipEvent_t ev : f->pipe_ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : f->ev) (void)hipEventDestroy(ev);
     if (f->d_raw_dist) (void)hipFree(f->d_raw_dist);
     if (f->d_raw_err) (void)hipFree(f->d_raw_err);
     if (f->in_stream) (void)hipStreamDestroy(f->in_stream);
@@ -145,9 +149,12 @@ int loc_fusion_solve_device(loc_fusion* f, int32_t epochs, const float* dist, co
     a.jacobian = f->prm.jacobian;
     const long long left = (long long)f->prm.gate_warmup_epochs - f->epochs_done;
     a.gate_from_epoch = left > 0 ? (int)(left > epochs ? epochs : left) : 0;
+    const bool pair = f->timing && (size_t)(f->ev_used + 2) <= f->ev.size();
     LOC_HIP(hipEventRecord(f->ev0, st));
+    if (pair) LOC_HIP(hipEventRecord(f->ev[f->ev_used], st));
     hipError_t e = locamd::launch_fusion(a, f->prm.block_threads, st);
     if (e != hipSuccess) return locamd_fail_hip(e, "launch_fusion");
+    if (pair) { LOC_HIP(hipEventRecord(f->ev[f->ev_used + 1], st)); f->ev_used += 2; }
     LOC_HIP(hipEventRecord(f->ev1, st));
     f->timed = true;
     f->epochs_done += epochs;
@@ -238,6 +245,37 @@ int loc_fusion_last_kernel_ms(loc_fusion* f, double* ms) {
     float t = 0;
     LOC_HIP(hipEventElapsedTime(&t, f->ev0, f->ev1));
     *ms = t;
+    return LOC_OK;
+}
+
+int loc_fusion_timing_begin(loc_fusion* f, int32_t max_launches) {
+    if (!f || max_launches <= 0) return locamd_fail(LOC_ERR_INVALID, "timing_begin");
+    LOC_HIP(hipSetDevice(f->device));
+    while ((int)f->ev.size() < 2 * max_launches) {
+        hipEvent_t ev;
+        LOC_HIP(hipEventCreate(&ev));
+        f->ev.push_back(ev);
+    }
+    f->ev_used = 0;
+    f->timing = true;
+    return LOC_OK;
+}
+int loc_fusion_timing_end(loc_fusion* f, int32_t* n_launches, double* total_ms, double* avg_ms) {
+    if (!f) return locamd_fail(LOC_ERR_INVALID, "timing_end");
+    LOC_HIP(hipSetDevice(f->device));
+    f->timing = false;
+    double tot = 0;
+    const int n = f->ev_used / 2;
+    for (int i = 0; i < n; ++i) {
+        LOC_HIP(hipEventSynchronize(f->ev[2 * i + 1]));
+        float ms = 0;
+        LOC_HIP(hipEventElapsedTime(&ms, f->ev[2 * i], f->ev[2 * i + 1]));
+        tot += ms;
+    }
+    if (n_launches) *n_launches = n;
+    if (total_ms) *total_ms = tot;
+    if (avg_ms) *avg_ms = n ? tot / n : 0.0;
+    f->ev_used = 0;
     return LOC_OK;
 }
 

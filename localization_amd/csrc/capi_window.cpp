@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include <algorithm>
+#include <chrono>
 #include <new>
 #include <string>
 #include <utility>
@@ -64,7 +65,26 @@ struct loc_window {
     int resident_min_anchors = 0;   // anchors the resident batch references (loc_window_set_anchors may not shrink below it)
     bool resident_solved = false;   // a resident solve has run since the upload (loc_window_download has something to fetch)
     int last_kind = -1;             // LOC_WINDOW_KERNEL_* of the last launch
-    hipStream_t last_stream = nullptr;   // stream of the last resident launch (an upload waits for it)
+    hipEvent_t resident_done = nullptr;  // recorded after every resident launch on the stream it ran on: whatever touches the shared
+    bool resident_inflight = false;      // device state waits for THIS (the caller's stream is not kept: it may be destroyed any time)
+    // kernel-selection switches: the environment is read ONCE, here at creation (loc_window_set_option changes them afterwards)
+    struct Opts {
+        long long env_chain_min = 12288;   // LOCAMD_CHAIN_MIN_BATCH, or the default
+        bool env_chain_min_set = false;
+        int arrow3 = -1;                   // LOCAMD_ARROW3: -1 default (windows of more than 64 poses), 0 never, 1 whenever the batch qualifies
+        int tree = -1;                     // LOCAMD_TREE: -1 default, 0 never, 2 the lane-per-window variant
+        bool wave3 = true, wave6 = true, chain3 = true, zero_copy = true, topology_cache = true;
+    } opt;
+    // structural verdict of the last host-path batch, keyed on a hash of (n, counts, index tables): a caller that replays one graph
+    // with new measurements (the node's window between two slides, a Monte-Carlo batch) skips the chain / forest / arrowhead tests
+    struct TopoCache {
+        bool valid = false;
+        unsigned long long key = 0;
+        int64_t n = 0;
+        bool chain = false, single_pairs = false, tree_ok = false, tree_tried = false;
+    } topo_cache;
+    double t_validate_ms = 0, t_topology_ms = 0, t_run_ms = 0;   // loc_window_last_host_timing
+    bool t_cached = false;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_ms = 0.0;
@@ -106,6 +126,7 @@ int loc_window_destroy(loc_window* w) {
     if (w->d_stage) (void)hipFree(w->d_stage);
     if (w->ev0) (void)hipEventDestroy(w->ev0);
     if (w->ev1) (void)hipEventDestroy(w->ev1);
+    if (w->resident_done) (void)hipEventDestroy(w->resident_done);
     if (w->stream) (void)hipStreamDestroy(w->stream);
     delete w;
     return LOC_OK;
@@ -147,19 +168,38 @@ int loc_window_create(loc_window** out, int32_t device, int64_t batch, const loc
         (global_a && (e = hipMalloc((void**)&w->d_workspace, B * locamd::window_workspace_doubles(w->caps) * sizeof(double))) != hipSuccess) ||
         (e = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&w->ev0)) != hipSuccess || (e = hipEventCreate(&w->ev1)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&w->resident_done, hipEventDisableTiming)) != hipSuccess ||
         (n_anchors > 0 && (e = hipMemcpy(w->d_anchors, anchors, (size_t)n_anchors * 3 * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess)) {
         loc_window_destroy(w);
         return locamd_fail_hip(e, "loc_window_create");
     }
     if (batch <= 4 && n_anchors > 0) w->h_anchors.assign(anchors, anchors + (size_t)n_anchors * 3);
+    {   // the A/B switches of the environment, read once
+        loc_window::Opts& o = w->opt;
+        if (const char* v = getenv("LOCAMD_CHAIN_MIN_BATCH")) { o.env_chain_min = atoll(v); o.env_chain_min_set = true; }
+        if (const char* v = getenv("LOCAMD_ARROW3")) o.arrow3 = v[0] == '1' ? 1 : 0;
+        if (const char* v = getenv("LOCAMD_TREE")) o.tree = v[0] == '0' ? 0 : (v[0] == 'l' ? 2 : -1);
+        if (const char* v = getenv("LOCAMD_WAVE3")) o.wave3 = v[0] != '0';
+        if (const char* v = getenv("LOCAMD_WAVE6")) o.wave6 = v[0] != '0';
+        if (const char* v = getenv("LOCAMD_CHAIN3")) o.chain3 = v[0] != '0';
+        if (getenv("LOCAMD_NO_ZERO_COPY")) o.zero_copy = false;
+    }
     *out = w;
+    return LOC_OK;
+}
+
+// whatever is about to touch the device state a resident launch reads or writes waits for that launch first
+static int wait_resident(loc_window* w) {
+    if (!w->resident_inflight) return LOC_OK;
+    LOC_HIP(hipEventSynchronize(w->resident_done));
+    w->resident_inflight = false;
     return LOC_OK;
 }
 
 // the device copy of the anchor table
 static int upload_anchors(loc_window* w, int32_t n_anchors, const double* anchors) {
     LOC_HIP(hipSetDevice(w->device));
-    if (w->last_stream) LOC_HIP(hipStreamSynchronize(w->last_stream));   // a resident launch may still be reading the table
+    if (int rc = wait_resident(w)) return rc;   // a resident launch may still be reading the table
     if (n_anchors > w->anchors_cap) {
         double* p = nullptr;
         LOC_HIP(hipMalloc((void**)&p, (size_t)n_anchors * 3 * sizeof(double)));
@@ -232,10 +272,7 @@ static int validate_instances(const loc_window* w, int64_t n, const int32_t* cou
 // (chain_lm_kernel; chain3_lm_kernel when the batch is translation-only).  Below the threshold a wave per window is faster (the
 // lane-per-window kernels take about as long for 1 000 windows as for 65 536); LOCAMD_CHAIN_MIN_BATCH in the environment moves it
 // (0 = never).
-static long long chain_min_batch() {
-    static const long long v = [] { const char* e = getenv("LOCAMD_CHAIN_MIN_BATCH"); return e ? atoll(e) : 12288LL; }();
-    return v;
-}
+static long long chain_min_batch(const loc_window* w) { return w->opt.env_chain_min; }
 // translation-only (the exact 3-DoF reduction, chain3_kernel.hip / arrow3_kernel.hip): no EdgeSE3, every lever arm zero, every
 // rotation the identity, priors with an identity measurement rotation and no rotation information
 static bool translation_only(const loc_window* w, int64_t n, const int32_t* counts, const double* poses, const double* r_val, const double* p_val) {
@@ -590,37 +627,74 @@ static hipError_t upload_tree_sched(loc_window* w, int which, hipStream_t st) {
 }
 
 static long long tree_min_batch(const loc_window* w) {
-    const long long mn = w->chain_min >= 0 ? w->chain_min : chain_min_batch();
+    const long long mn = w->chain_min >= 0 ? w->chain_min : chain_min_batch(w);
     if (mn <= 0) return 1ll << 62;     // (threshold 0 = "never a batch kernel")
     return mn < 256 ? mn : 256;
 }
 
+// 64-bit hash of a batch's STRUCTURE: n, the counts and the used entries of the index tables (never the measurements)
+static unsigned long long hash_structure(const loc_window* w, int64_t n, const int32_t* counts, const int32_t* r_idx, const int32_t* p_idx, const int32_t* s_idx) {
+    const locamd::WindowCaps& c = w->caps;
+    unsigned long long h = 0x9e3779b97f4a7c15ull ^ (unsigned long long)n ^ (w->has_off1 ? 0x51ull << 56 : 0);
+    auto mix = [&h](const int32_t* p, size_t cnt) {
+        size_t i = 0;
+        for (; i + 2 <= cnt; i += 2) {
+            unsigned long long v;
+            std::memcpy(&v, p + i, 8);
+            h = (h ^ v) * 0xff51afd7ed558ccdull;
+            h ^= h >> 32;
+        }
+        if (i < cnt) { h = (h ^ (unsigned long long)(uint32_t)p[i]) * 0xc4ceb9fe1a85ec53ull; h ^= h >> 29; }
+    };
+    mix(counts, (size_t)n * 4);
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t* cn = counts + i * 4;
+        if (cn[1]) mix(r_idx + (size_t)i * c.nr_max * 2, (size_t)cn[1] * 2);
+        if (cn[2]) mix(p_idx + (size_t)i * c.np_max, (size_t)cn[2]);
+        if (cn[3]) mix(s_idx + (size_t)i * c.ns_max * 4, (size_t)cn[3] * 4);
+    }
+    return h;
+}
+
 // what the batch qualifies for BY ITS STRUCTURE: LOC_WINDOW_KERNEL_GENERAL, _CHAIN (block-tridiagonal, 6-DoF), _CHAIN3, _ARROW3 or _TREE
 // (for _ARROW3 the edge lists are left in w->h_a*)
-// which: the set of host-built tables ARROW3 / TREE fill (0: a loc_window_solve_host call, 1: the resident batch)
+// which: the set of host-built tables ARROW3 / TREE fill (0: a loc_window_solve_host call, 1: the resident batch).
+// Host-path calls (which == 0) keep the structural verdict of the previous batch in w->topo_cache: the same counts and index tables
+// (one 64-bit hash; a collision — 2^-64 per call — would hand a batch to a kernel built for another structure) skip the tests below.
+// What depends on the VALUES (translation_only: identity rotations, zero lever arms; arrow3's packed edge records) is looked at every time.
 static int batch_topology(loc_window* w, int which, int64_t n, const int32_t* counts, const double* poses, const int32_t* r_idx, const double* r_val,
                           const int32_t* p_idx, const double* p_val, const int32_t* s_idx) {
     const locamd::WindowCaps& c = w->caps;
+    loc_window::TopoCache& tc = w->topo_cache;
+    const bool use_cache = which == 0 && w->opt.topology_cache;
+    unsigned long long key = 0;
+    bool hit = false;
+    if (use_cache) {
+        key = hash_structure(w, n, counts, r_idx, p_idx, s_idx);
+        hit = tc.valid && tc.key == key && tc.n == n;
+    }
+    if (which == 0) w->t_cached = hit;
     bool chain = true;
     bool single_pairs = true;   // no EdgeSE3 anywhere and at most one range edge per pair of consecutive poses (wave6_lm_kernel's rank-1 couplings)
-    for (int64_t i = 0; i < n && chain; ++i) {
+    if (hit) { chain = tc.chain; single_pairs = tc.single_pairs; }
+    for (int64_t i = 0; i < n && chain && !hit; ++i) {
         const int32_t* cn = counts + i * 4;
         if (cn[3] != 0) single_pairs = false;
         int last = 0;
         for (int e = 0; e < cn[3]; ++e) {   // EdgeSE3 factors: between consecutive poses, ordered by their later pose (addTwistEdge)
             const int32_t* ix = s_idx + ((size_t)i * c.ns_max + e) * 4;
-            const int key = ix[1] > ix[0] ? ix[1] : ix[0];
-            if (key < last || (ix[0] - ix[1] != 1 && ix[1] - ix[0] != 1)) { chain = false; break; }
-            last = key;
+            const int key2 = ix[1] > ix[0] ? ix[1] : ix[0];
+            if (key2 < last || (ix[0] - ix[1] != 1 && ix[1] - ix[0] != 1)) { chain = false; break; }
+            last = key2;
         }
         last = 0;
         int last_pair = -1;
         for (int e = 0; e < cn[1] && chain; ++e) {
             const int32_t* ix = r_idx + ((size_t)i * c.nr_max + e) * 2;
-            const int key = ix[1] > ix[0] ? ix[1] : ix[0];
-            if (key < last) chain = false;
-            if (ix[1] >= 0) { if (key == last_pair) single_pairs = false; last_pair = key; }
-            last = key;
+            const int key2 = ix[1] > ix[0] ? ix[1] : ix[0];
+            if (key2 < last) chain = false;
+            if (ix[1] >= 0) { if (key2 == last_pair) single_pairs = false; last_pair = key2; }
+            last = key2;
             if (ix[1] >= 0 && ix[0] - ix[1] != 1 && ix[1] - ix[0] != 1) chain = false;
         }
         last = 0;
@@ -630,65 +704,64 @@ static int batch_topology(loc_window* w, int which, int64_t n, const int32_t* co
             last = v;
         }
     }
+    if (use_cache && !hit) { tc.valid = true; tc.key = key; tc.n = n; tc.chain = chain; tc.single_pairs = single_pairs; tc.tree_tried = false; tc.tree_ok = false; }
     if (chain) {
         if (translation_only(w, n, counts, poses, r_val, p_val)) return LOC_WINDOW_KERNEL_CHAIN3;
         return (single_pairs && c.nv_max <= 64 && locamd::window_wave6_lds_bytes(c) <= locamd::kWave6MaxLds) ? LOC_WINDOW_KERNEL_WAVE6 : LOC_WINDOW_KERNEL_CHAIN;
     }
     {
-        // (LOCAMD_ARROW3: 0 = never, 1 = whenever the batch qualifies; default: windows of more than 64 poses — below that the
+        // (option "arrow3": 0 = never, 1 = whenever the batch qualifies; default: windows of more than 64 poses — below that the
         //  wave-per-window kernel keeps everything in LDS and is the better choice)
-        const char* v = getenv("LOCAMD_ARROW3");
-        const bool want = v ? v[0] == '1' : c.nv_max > 64;
+        const bool want = w->opt.arrow3 >= 0 ? w->opt.arrow3 == 1 : c.nv_max > 64;
         if (want && translation_only(w, n, counts, poses, r_val, p_val) && build_arrow_aux(w, which, n, counts, r_idx, r_val, p_idx, p_val)) return LOC_WINDOW_KERNEL_ARROW3;
     }
     {
-        // (LOCAMD_TREE=0: never.  One wave per window, so any batch gains; the host-side comparison of the index tables is only worth
+        // (option "tree" = 0: never.  One wave per window, so any batch gains; the host-side comparison of the index tables is only worth
         //  it from a few hundred windows on — or from the chain threshold when that was lowered, as the tests do)
-        const char* v = getenv("LOCAMD_TREE");
-        if (!(v && v[0] == '0') && n >= tree_min_batch(w) && build_tree_sched(w, which, n, counts, r_idx, p_idx, s_idx)) return LOC_WINDOW_KERNEL_TREE;
+        if (w->opt.tree != 0 && n >= tree_min_batch(w)) {
+            if (hit && tc.tree_tried) {
+                if (tc.tree_ok) return LOC_WINDOW_KERNEL_TREE;   // (aux[0]'s schedule is still the one built for this structure)
+            } else {
+                const bool ok = build_tree_sched(w, which, n, counts, r_idx, p_idx, s_idx);
+                if (use_cache) { tc.tree_tried = true; tc.tree_ok = ok; }
+                if (ok) return LOC_WINDOW_KERNEL_TREE;
+            }
+        }
     }
     return LOC_WINDOW_KERNEL_GENERAL;
 }
-// the kernel a batch of n windows with that structure takes NOW (threshold, ordering override, LOCAMD_CHAIN3=0 for A/B runs)
+// the kernel a batch of n windows with that structure takes NOW (threshold, ordering override, the handle's options)
 static int pick_kernel(const loc_window* w, int64_t n, int topology) {
-    const long long mn = w->chain_min >= 0 ? w->chain_min : chain_min_batch();
+    const long long mn = w->chain_min >= 0 ? w->chain_min : chain_min_batch(w);
+    const bool default_rule = w->chain_min < 0 && !w->opt.env_chain_min_set;
     if (w->has_off1) return LOC_WINDOW_KERNEL_GENERAL;   // (lever arms on endpoint 1: only the general kernel evaluates them)
+    if (mn <= 0 || w->natural_order) return LOC_WINDOW_KERNEL_GENERAL;   // threshold 0 = "never anything but the general kernel" (every structure)
     if (topology == LOC_WINDOW_KERNEL_WAVE6) {
         // a 6-DoF chain batch that also qualifies for wave6_lm_kernel (one wave per window, rank-1 couplings).  Measured on twelve-pose
         // cfg/uwb_imu.yaml windows: 1.15e7 windows/s at 4 096, 16 384 and 65 536 windows against chain_lm_kernel's 1.1e6 / 4.3e6 / 6.9e6 —
         // so by default it takes every batch; an explicit threshold hands batches from that size on to the lane-per-window kernel.
-        // LOCAMD_WAVE6=0: as before (the general kernel below the threshold, chain_lm_kernel from it on), for A/B runs.
-        if (mn <= 0 || w->natural_order) return LOC_WINDOW_KERNEL_GENERAL;
-        const bool default_rule = w->chain_min < 0 && !getenv("LOCAMD_CHAIN_MIN_BATCH");
-        const char* v = getenv("LOCAMD_WAVE6");
-        const bool off = v && v[0] == '0';
+        // option "wave6" = 0: as before (the general kernel below the threshold, chain_lm_kernel from it on), for A/B runs.
+        const bool off = !w->opt.wave6;
         if (n >= mn && (off || !default_rule)) return LOC_WINDOW_KERNEL_CHAIN;
         return off ? LOC_WINDOW_KERNEL_GENERAL : LOC_WINDOW_KERNEL_WAVE6;
     }
-    if (topology == LOC_WINDOW_KERNEL_ARROW3) return w->natural_order ? LOC_WINDOW_KERNEL_GENERAL : LOC_WINDOW_KERNEL_ARROW3;   // (one wave per window: any batch size)
-    if (topology == LOC_WINDOW_KERNEL_TREE) return (w->natural_order || n < tree_min_batch(w)) ? LOC_WINDOW_KERNEL_GENERAL : LOC_WINDOW_KERNEL_TREE;
-    if (topology == LOC_WINDOW_KERNEL_CHAIN3 && mn > 0 && !w->natural_order && w->caps.nv_max <= 64 && locamd::window_wave3_lds_bytes(w->caps) <= 64 * 1024) {
+    if (topology == LOC_WINDOW_KERNEL_ARROW3) return LOC_WINDOW_KERNEL_ARROW3;   // (one workgroup per window: any batch size)
+    if (topology == LOC_WINDOW_KERNEL_TREE) return n < tree_min_batch(w) ? LOC_WINDOW_KERNEL_GENERAL : LOC_WINDOW_KERNEL_TREE;
+    if (topology == LOC_WINDOW_KERNEL_CHAIN3 && w->caps.nv_max <= 64 && locamd::window_wave3_lds_bytes(w->caps) <= 64 * 1024) {
         // translation-only chains of <= 64 poses (the node's single window first of all): one wave per window with 3x3 blocks, rank-1
         // couplings and speculative LM trials.  Measured on ten-pose windows: 0.056 ms for one window, 3.6e7 windows/s (numeric) /
         // 4.0e7 (analytic) from ~8 000 windows on — level with chain3_lm_kernel at 65 536 windows, ahead of it everywhere else — so by
         // default it takes every batch; an explicit threshold (loc_window_set_chain_threshold / LOCAMD_CHAIN_MIN_BATCH) hands batches
-        // from that size on to the lane-per-window kernel.  LOCAMD_WAVE3=0 / LOCAMD_CHAIN3=0: no such kernel (A/B runs, tests).
-        const bool default_rule = w->chain_min < 0 && !getenv("LOCAMD_CHAIN_MIN_BATCH");
-        const char* v = getenv("LOCAMD_WAVE3");
-        const char* v3 = getenv("LOCAMD_CHAIN3");
-        if ((default_rule || n < mn) && !(v && v[0] == '0') && !(v3 && v3[0] == '0')) return LOC_WINDOW_KERNEL_WAVE3;
+        // from that size on to the lane-per-window kernel.  Options "wave3" / "chain3" = 0: no such kernel (A/B runs, tests).
+        if ((default_rule || n < mn) && w->opt.wave3 && w->opt.chain3) return LOC_WINDOW_KERNEL_WAVE3;
     }
-    if (topology == LOC_WINDOW_KERNEL_CHAIN3 && mn > 0 && !w->natural_order && w->chain_min < 0 && !getenv("LOCAMD_CHAIN_MIN_BATCH") && n >= 4096 && n < mn) {
+    if (topology == LOC_WINDOW_KERNEL_CHAIN3 && default_rule && n >= 4096 && n < mn) {
         // the translation-only kernel is worth it from ~4 096 windows on (it takes ~1 ms for any batch up to 16 384, the wave-per-window
         // kernel 4.3e6 windows/s): e.g. one GPU's 8 192-window share of a 65 536-window job split over eight
-        const char* v = getenv("LOCAMD_CHAIN3");
-        if (!(v && v[0] == '0')) return LOC_WINDOW_KERNEL_CHAIN3;
+        if (w->opt.chain3) return LOC_WINDOW_KERNEL_CHAIN3;
     }
-    if (topology == LOC_WINDOW_KERNEL_GENERAL || mn <= 0 || n < mn || w->natural_order) return LOC_WINDOW_KERNEL_GENERAL;
-    if (topology == LOC_WINDOW_KERNEL_CHAIN3) {   // LOCAMD_CHAIN3=0: the 6-DoF kernel on a translation-only batch (A/B runs, tests; read per call)
-        const char* v = getenv("LOCAMD_CHAIN3");
-        if (v && v[0] == '0') return LOC_WINDOW_KERNEL_CHAIN;
-    }
+    if (topology == LOC_WINDOW_KERNEL_GENERAL || n < mn) return LOC_WINDOW_KERNEL_GENERAL;
+    if (topology == LOC_WINDOW_KERNEL_CHAIN3 && !w->opt.chain3) return LOC_WINDOW_KERNEL_CHAIN;   // the 6-DoF kernel on a translation-only batch (A/B runs, tests)
     return topology;
 }
 static hipError_t launch_any(loc_window* w, int which, const locamd::WindowArgs& a, hipStream_t st, int kind) {
@@ -700,9 +773,8 @@ static hipError_t launch_any(loc_window* w, int which, const locamd::WindowArgs&
         x.ws = w->d_arrow_ws; x.nb_max = A.arrow_nb_max; x.jmax = A.arrow_jmax; x.jpmax = A.arrow_jpmax; x.nchunk = (w->caps.nv_max + 63) / 64;
         return locamd::launch_window_arrow3(a, x, st);
     }
-    if (kind == LOC_WINDOW_KERNEL_TREE) {   // (LOCAMD_TREE=lane: the one-lane-per-window variant, for A/B runs)
-        const char* v = getenv("LOCAMD_TREE");
-        if ((v && v[0] == 'l') || A.tsched.max_se3_per_node > 1) {   // (tree_wave_kernel: one EdgeSE3 per node)
+    if (kind == LOC_WINDOW_KERNEL_TREE) {   // (option "tree" = 2: the one-lane-per-window variant, for A/B runs)
+        if (w->opt.tree == 2 || A.tsched.max_se3_per_node > 1) {   // (tree_wave_kernel: one EdgeSE3 per node)
             w->last_kind = LOC_WINDOW_KERNEL_TREE_LANE;
             return locamd::launch_window_tree(a, A.tsched, w->d_tree_ws, st);
         }
@@ -737,17 +809,41 @@ int loc_window_set_chain_threshold(loc_window* w, int64_t min_batch) {
     return LOC_OK;
 }
 
+int loc_window_set_option(loc_window* w, const char* name, int64_t value) {
+    if (!w || !name) return locamd_fail(LOC_ERR_INVALID, "set_option");
+    const std::string k(name);
+    loc_window::Opts& o = w->opt;
+    auto flag = [&](bool& f) { if (value != 0 && value != 1) return locamd_fail(LOC_ERR_INVALID, "set_option: 0 or 1"); f = value == 1; return (int)LOC_OK; };
+    if (k == "chain_min_batch") { w->chain_min = value; return LOC_OK; }
+    if (k == "arrow3") { if (value < -1 || value > 1) return locamd_fail(LOC_ERR_INVALID, "set_option arrow3: -1, 0 or 1"); o.arrow3 = (int)value; w->topo_cache.valid = false; return LOC_OK; }
+    if (k == "tree") { if (value != -1 && value != 0 && value != 2) return locamd_fail(LOC_ERR_INVALID, "set_option tree: -1, 0 or 2"); o.tree = (int)value; w->topo_cache.valid = false; return LOC_OK; }
+    if (k == "wave3") return flag(o.wave3);
+    if (k == "wave6") return flag(o.wave6);
+    if (k == "chain3") return flag(o.chain3);
+    if (k == "zero_copy") return flag(o.zero_copy);
+    if (k == "topology_cache") { w->topo_cache.valid = false; return flag(o.topology_cache); }
+    return locamd_fail(LOC_ERR_INVALID, "set_option: unknown option name");
+}
+
+int loc_window_last_host_timing(const loc_window* w, double* out) {
+    if (!w || !out) return locamd_fail(LOC_ERR_INVALID, "null");
+    out[0] = w->t_validate_ms; out[1] = w->t_topology_ms; out[2] = w->t_run_ms; out[3] = w->t_cached ? 1.0 : 0.0;
+    return LOC_OK;
+}
+
 int loc_window_set_endpoint1_offsets(loc_window* w, int64_t n, const double* off1) {
     if (!w || (off1 && (n <= 0 || n > w->B))) return locamd_fail(LOC_ERR_INVALID, "set_endpoint1_offsets");
+    w->topo_cache.valid = false;
     if (!off1) { w->has_off1 = false; return LOC_OK; }
     if (w->caps.nr_max <= 0) return locamd_fail(LOC_ERR_INVALID, "set_endpoint1_offsets: no range edges in this solver");
     LOC_HIP(hipSetDevice(w->device));
-    if (w->last_stream) LOC_HIP(hipStreamSynchronize(w->last_stream));
-    if (!w->d_roff1) {
-        LOC_HIP(hipMalloc((void**)&w->d_roff1, (size_t)w->B * w->caps.nr_max * 3 * sizeof(double)));
-        LOC_HIP(hipMemset(w->d_roff1, 0, (size_t)w->B * w->caps.nr_max * 3 * sizeof(double)));
-    }
-    LOC_HIP(hipMemcpy(w->d_roff1, off1, (size_t)n * w->caps.nr_max * 3 * sizeof(double), hipMemcpyHostToDevice));
+    if (int rc = wait_resident(w)) return rc;
+    LOC_HIP(hipStreamSynchronize(w->stream));
+    const size_t row = (size_t)w->caps.nr_max * 3 * sizeof(double);
+    if (!w->d_roff1) LOC_HIP(hipMalloc((void**)&w->d_roff1, (size_t)w->B * row));
+    LOC_HIP(hipMemcpy(w->d_roff1, off1, (size_t)n * row, hipMemcpyHostToDevice));
+    // rows [n, B): no lever arm (a call with fewer instances than an earlier one must not leave that one's behind)
+    if (n < w->B) LOC_HIP(hipMemset((char*)w->d_roff1 + (size_t)n * row, 0, (size_t)(w->B - n) * row));
     w->has_off1 = true;
     return LOC_OK;
 }
@@ -767,12 +863,18 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
                           const double* r_val, const int32_t* p_idx, const double* p_val, const int32_t* s_idx,
                           const double* s_val, double* result) {
     if (!result) return locamd_fail(LOC_ERR_INVALID, "window solve arguments");
+    using clk = std::chrono::steady_clock;
+    auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
+    const auto t_begin = clk::now();
     {
         const int rc = validate_instances(w, n, counts, poses, r_idx, r_val, p_idx, p_val, s_idx, s_val);
         if (rc != LOC_OK) return rc;
     }
+    w->t_validate_ms = ms_since(t_begin);
     const locamd::WindowCaps& c = w->caps;
     LOC_HIP(hipSetDevice(w->device));
+    // a resident launch (possibly on a caller's stream) may still be using the workspaces and tables this call shares with it
+    if (int rc = wait_resident(w)) return rc;
     const size_t N = (size_t)n;
     hipStream_t st = w->stream;
     {
@@ -794,13 +896,16 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
             if (c.nr_max) { std::memcpy(h + off[3], r_val, N * c.nr_max * 5 * sizeof(double)); std::memcpy(h + off[6], r_idx, N * c.nr_max * 2 * sizeof(int32_t)); }
             if (c.np_max) { std::memcpy(h + off[4], p_val, N * c.np_max * 18 * sizeof(double)); std::memcpy(h + off[7], p_idx, N * c.np_max * sizeof(int32_t)); }
             if (c.ns_max) { std::memcpy(h + off[5], s_val, N * c.ns_max * 48 * sizeof(double)); std::memcpy(h + off[8], s_idx, N * c.ns_max * 4 * sizeof(int32_t)); }
+            const auto t_topo = clk::now();
             const int kind = pick_kernel(w, n, batch_topology(w, 0, n, counts, poses, r_idx, r_val, p_idx, p_val, s_idx));
+            w->t_topology_ms = ms_since(t_topo);
+            const auto t_run = clk::now();
             // A handful of small windows on wave3_lm_kernel (the node's own solve): the kernel reads its few KB of input once and
             // writes 1 KB of results — it does so straight from / to the page-locked staging block (host-coherent memory, mapped
             // into the device's address space), which saves the two DMA operations around a ~75 us kernel.
             const size_t anchor_bytes = (size_t)w->n_anchors * 3 * sizeof(double);
             const bool zero_copy = (kind == LOC_WINDOW_KERNEL_WAVE3 || kind == LOC_WINDOW_KERNEL_WAVE6) && n <= 4 && w->B <= 4 && w->h_anchors.size() == (size_t)w->n_anchors * 3 &&
-                                   off[9] + anchor_bytes <= kStageBytes && !getenv("LOCAMD_NO_ZERO_COPY");
+                                   off[9] + anchor_bytes <= kStageBytes && w->opt.zero_copy;
             if (zero_copy) {
                 d = h;
                 if (anchor_bytes) std::memcpy(h + off[9], w->h_anchors.data(), anchor_bytes);
@@ -829,6 +934,7 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
             float ms = 0;
             LOC_HIP(hipEventElapsedTime(&ms, w->ev0, w->ev1));
             w->last_ms = ms;
+            w->t_run_ms = ms_since(t_run);
             return LOC_OK;
         }
     }
@@ -836,6 +942,13 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
         const int rc = flush_anchors(w);
         if (rc != LOC_OK) return rc;
     }
+    // The large path stages its batch in the device arrays a resident batch lives in: that batch is gone from here on
+    // (loc_window_solve_resident / loc_window_download return LOC_ERR_INVALID until the next loc_window_upload).
+    w->n_resident = 0; w->resident_solved = false; w->resident_topology = LOC_WINDOW_KERNEL_GENERAL; w->resident_min_anchors = 0;
+    const auto t_topo = clk::now();
+    const int kind = pick_kernel(w, n, batch_topology(w, 0, n, counts, poses, r_idx, r_val, p_idx, p_val, s_idx));
+    w->t_topology_ms = ms_since(t_topo);
+    const auto t_run = clk::now();
     LOC_HIP(hipMemcpyAsync(w->d_counts, counts, N * 4 * sizeof(int32_t), hipMemcpyHostToDevice, st));
     LOC_HIP(hipMemcpyAsync(w->d_poses, poses, N * c.nv_max * 12 * sizeof(double), hipMemcpyHostToDevice, st));
     if (c.nr_max) {
@@ -856,7 +969,6 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
     a.p_val = w->d_pval; a.s_idx = w->d_sidx; a.s_val = w->d_sval; a.anchors = w->d_anchors; a.result = w->d_result;
     a.workspace = w->d_workspace;
     a.n_anchors = w->n_anchors; a.B = (int)n; a.iterations = w->iterations; a.caps = c;
-    const int kind = pick_kernel(w, n, batch_topology(w, 0, n, counts, poses, r_idx, r_val, p_idx, p_val, s_idx));
     if (kind == LOC_WINDOW_KERNEL_ARROW3) LOC_HIP(upload_arrow_aux(w, 0, n, st));
     if (kind == LOC_WINDOW_KERNEL_TREE) LOC_HIP(upload_tree_sched(w, 0, st));
     LOC_HIP(hipEventRecord(w->ev0, st));
@@ -869,6 +981,7 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
     float ms = 0;
     LOC_HIP(hipEventElapsedTime(&ms, w->ev0, w->ev1));
     w->last_ms = ms;
+    w->t_run_ms = ms_since(t_run);
     return LOC_OK;
 }
 
@@ -886,7 +999,9 @@ int loc_window_upload(loc_window* w, int64_t n, const int32_t* counts, const dou
     // a resident launch of the previous batch may still be running on the handle's (or the caller's) stream: it reads what the
     // copies below overwrite
     LOC_HIP(hipStreamSynchronize(w->stream));
-    if (w->last_stream && w->last_stream != w->stream) LOC_HIP(hipStreamSynchronize(w->last_stream));
+    if (int rc = wait_resident(w)) return rc;
+    // (a failing step below must not leave a half-described resident batch behind: nothing is resident until everything is)
+    w->n_resident = 0; w->resident_solved = false; w->resident_topology = LOC_WINDOW_KERNEL_GENERAL; w->resident_min_anchors = 0;
     if (!w->d_poses_in) LOC_HIP(hipMalloc((void**)&w->d_poses_in, (size_t)w->B * c.nv_max * 12 * sizeof(double)));
     LOC_HIP(hipMemcpy(w->d_counts, counts, N * 4 * sizeof(int32_t), hipMemcpyHostToDevice));
     LOC_HIP(hipMemcpy(w->d_poses_in, poses, N * c.nv_max * 12 * sizeof(double), hipMemcpyHostToDevice));
@@ -902,11 +1017,9 @@ int loc_window_upload(loc_window* w, int64_t n, const int32_t* counts, const dou
         LOC_HIP(hipMemcpy(w->d_sidx, s_idx, N * c.ns_max * 4 * sizeof(int32_t), hipMemcpyHostToDevice));
         LOC_HIP(hipMemcpy(w->d_sval, s_val, N * c.ns_max * 48 * sizeof(double), hipMemcpyHostToDevice));
     }
-    w->n_resident = n;
-    w->resident_solved = false;
-    w->resident_topology = batch_topology(w, 1, n, counts, poses, r_idx, r_val, p_idx, p_val, s_idx);
-    if (w->resident_topology == LOC_WINDOW_KERNEL_ARROW3) LOC_HIP(upload_arrow_aux(w, 1, n, w->stream));
-    if (w->resident_topology == LOC_WINDOW_KERNEL_TREE) LOC_HIP(upload_tree_sched(w, 1, w->stream));
+    const int topology = batch_topology(w, 1, n, counts, poses, r_idx, r_val, p_idx, p_val, s_idx);
+    if (topology == LOC_WINDOW_KERNEL_ARROW3) LOC_HIP(upload_arrow_aux(w, 1, n, w->stream));
+    if (topology == LOC_WINDOW_KERNEL_TREE) LOC_HIP(upload_tree_sched(w, 1, w->stream));
     int max_anchor = 0;   // anchors referenced: v1 = -1 - anchor
     for (int64_t i = 0; i < n; ++i)
         for (int e = 0; e < counts[i * 4 + 1]; ++e) {
@@ -914,6 +1027,9 @@ int loc_window_upload(loc_window* w, int64_t n, const int32_t* counts, const dou
             if (v1 < 0 && -v1 > max_anchor) max_anchor = -v1;
         }
     w->resident_min_anchors = max_anchor;
+    w->resident_topology = topology;
+    w->resident_solved = false;
+    w->n_resident = n;
     return LOC_OK;
 }
 
@@ -939,7 +1055,8 @@ int loc_window_solve_resident(loc_window* w, void* hip_stream) {
     hipError_t e = launch_any(w, 1, a, st, pick_kernel(w, w->n_resident, w->resident_topology));
     if (e != hipSuccess) return locamd_fail_hip(e, "launch_window");
     if (timed) { LOC_HIP(hipEventRecord(w->ev[w->ev_used + 1], st)); w->ev_used += 2; }
-    w->last_stream = st;
+    LOC_HIP(hipEventRecord(w->resident_done, st));
+    w->resident_inflight = true;
     w->resident_solved = true;
     return LOC_OK;
 }
@@ -948,7 +1065,7 @@ int loc_window_download(loc_window* w, double* poses, double* result) {
     if (!w || w->n_resident <= 0) return locamd_fail(LOC_ERR_INVALID, "nothing uploaded");
     if (!w->resident_solved) return locamd_fail(LOC_ERR_INVALID, "loc_window_download: no resident solve has run since the upload");
     LOC_HIP(hipSetDevice(w->device));
-    LOC_HIP(hipDeviceSynchronize());
+    if (int rc = wait_resident(w)) return rc;
     const size_t N = (size_t)w->n_resident;
     if (poses) LOC_HIP(hipMemcpy(poses, w->d_poses, N * w->caps.nv_max * 12 * sizeof(double), hipMemcpyDeviceToHost));
     if (result) LOC_HIP(hipMemcpy(result, w->d_result, N * 8 * sizeof(double), hipMemcpyDeviceToHost));

@@ -124,6 +124,7 @@ struct loc_node {
     loc_window_caps caps{16, 0, 0, 0, -1};     // LIMIT of what pack() accepts: nv_max = the most active poses (set in loc_node_create);
                                                // the edge counts have no limit (the reference has none): the handle grows on demand
     loc_window_caps win_caps{0, 0, 0, 0, 0};   // capacities of the cached handle: what the packed graphs needed so far
+    int last_kind = LOC_WINDOW_KERNEL_NONE;                    // LOC_WINDOW_KERNEL_* of the last solve
     double t_pack_ms = 0, t_solve_ms = 0, t_kernel_ms = 0;   // the last solve: host packing, loc_window_solve_host (copies + launch + sync), its kernel
 
     RobotRing* robot(int id) { for (auto& r : robots) if (r.id == id) return &r; return nullptr; }
@@ -363,6 +364,7 @@ int solve_now(loc_node* n, loc_node_output* out) {
         n->t_pack_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
         n->t_solve_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
         (void)loc_window_last_kernel_ms(n->win, &n->t_kernel_ms);
+        { int32_t k = LOC_WINDOW_KERNEL_NONE; (void)loc_window_last_kernel_kind(n->win, &k); n->last_kind = k; }
         for (size_t s = 0; s < P.slot_vid.size(); ++s) {
             Vertex& v = n->vertices.at(P.slot_vid[s]);
             std::memcpy(v.est.R, &P.poses[s * 12], sizeof(double) * 9);
@@ -460,6 +462,12 @@ int32_t loc_node_solve_pending(const loc_node* n) { return n && n->pending ? 1 :
 int loc_node_last_timing(const loc_node* n, double* pack_solve_kernel_ms) {
     if (!n || !pack_solve_kernel_ms) return locamd_fail(LOC_ERR_INVALID, "null");
     pack_solve_kernel_ms[0] = n->t_pack_ms; pack_solve_kernel_ms[1] = n->t_solve_ms; pack_solve_kernel_ms[2] = n->t_kernel_ms;
+    return LOC_OK;
+}
+
+int loc_node_last_kernel_kind(const loc_node* n, int32_t* kind) {
+    if (!n || !kind) return locamd_fail(LOC_ERR_INVALID, "null");
+    *kind = n->last_kind;
     return LOC_OK;
 }
 
@@ -655,6 +663,20 @@ int loc_node_get_path(loc_node* n, int32_t node_id, double* out, int32_t capacit
         pose_out(n, r->slot_vertex(idx), r->header[idx].stamp, out + 8 * i);
     }
     return r->T;
+}
+
+// Localization::~Localization, localization.cpp:708-717: path->poses[T/2 .. T-1] of the moving tag (vertices2path order, robot.cpp:61-72)
+int loc_node_flush_tail(loc_node* n, double* out, int32_t capacity) {
+    if (!n || !out) return locamd_fail(LOC_ERR_INVALID, "null");
+    RobotRing* r = n->robot(n->self_id);
+    if (!r) return locamd_fail(LOC_ERR_UNKNOWN_NODE, "self id not in nodesId");
+    const int T = n->cfg.trajectory_length, first = T / 2;
+    if (capacity < T - first) return locamd_fail(LOC_ERR_INVALID, "tail buffer too small");
+    for (int i = first; i < T; ++i) {
+        const int idx = (r->index + 1 + i) % r->T;
+        pose_out(n, r->slot_vertex(idx), r->header[idx].stamp, out + 8 * (i - first));
+    }
+    return T - first;
 }
 
 }  // extern "C"

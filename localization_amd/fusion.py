@@ -25,6 +25,8 @@ def _bind(L):
     L.loc_fusion_solve_device.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
     L.loc_fusion_solve_host.argtypes = [vp, C.c_int32, fp, fp, dp, dp, dp, C.POINTER(C.c_uint8)]
     L.loc_fusion_last_kernel_ms.argtypes = [vp, dp]
+    L.loc_fusion_timing_begin.argtypes = [vp, C.c_int32]
+    L.loc_fusion_timing_end.argtypes = [vp, C.POINTER(C.c_int32), dp, dp]
     L._fusion_bound = True
 
 
@@ -110,3 +112,11 @@ class FusionSolver:
         ms = C.c_double()
         check(self.L.loc_fusion_last_kernel_ms(self.h, C.byref(ms)))
         return ms.value
+
+    def timing_begin(self, max_launches):
+        check(self.L.loc_fusion_timing_begin(self.h, int(max_launches)))
+
+    def timing_end(self):
+        n = C.c_int32(); tot = C.c_double(); avg = C.c_double()
+        check(self.L.loc_fusion_timing_end(self.h, C.byref(n), C.byref(tot), C.byref(avg)))
+        return n.value, tot.value, avg.value

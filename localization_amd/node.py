@@ -39,6 +39,8 @@ def _bind(L):
     L.loc_node_get_path.argtypes = [vp, C.c_int32, dp, C.c_int32]
     L.loc_node_number_measurements.argtypes = [vp]; L.loc_node_number_measurements.restype = C.c_int32
     L.loc_node_last_timing.argtypes = [vp, C.POINTER(C.c_double)]
+    L.loc_node_last_kernel_kind.argtypes = [vp, C.POINTER(C.c_int32)]
+    L.loc_node_flush_tail.argtypes = [vp, dp, C.c_int32]
     L.loc_node_set_deferred.argtypes = [vp, C.c_int32]
     L.loc_node_solve_pending.argtypes = [vp]; L.loc_node_solve_pending.restype = C.c_int32
     L.loc_nodes_solve_batch.argtypes = [C.POINTER(vp), C.c_int32, po]
@@ -157,6 +159,21 @@ class LocalizationNode:
         t = (C.c_double * 3)()
         check(self.L.loc_node_last_timing(self.h, t))
         return float(t[0]), float(t[1]), float(t[2])
+
+    def last_kernel_kind(self):
+        """name of the kernel the node's last solve ran (loc_node_last_kernel_kind)"""
+        from .window import WindowSolver
+        k = C.c_int32()
+        check(self.L.loc_node_last_kernel_kind(self.h, C.byref(k)))
+        return WindowSolver.KERNEL_KINDS.get(k.value, str(k.value))
+
+    def flush_tail(self):
+        """path[T/2 .. T-1] of the moving tag: what Localization::~Localization appends to the optimized log (localization.cpp:708-717)"""
+        out = np.zeros((max(self.T, 1), 8))
+        n = self.L.loc_node_flush_tail(self.h, _dp(out), out.shape[0])
+        if n < 0:
+            raise _lib.LocalizationAmdError(n, self.L.loc_last_error().decode(errors="replace"))
+        return out[:n]
 
     @property
     def number_measurements(self):

@@ -161,3 +161,15 @@ class WindowSolver:
         ms = C.c_double()
         check(self.L.loc_window_last_kernel_ms(self.h, C.byref(ms)))
         return ms.value
+
+    def set_option(self, name, value):
+        """loc_window_set_option: the kernel-selection switches of this handle ("chain_min_batch", "arrow3", "tree", "wave3", "wave6",
+        "chain3", "zero_copy", "topology_cache")"""
+        self.L.loc_window_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        check(self.L.loc_window_set_option(self.h, str(name).encode(), int(value)))
+
+    def last_host_timing(self):
+        """(validate ms, structure analysis ms, staging + launch + copy back ms, verdict came from the cache) of the last solve()"""
+        t = (C.c_double * 4)()
+        check(self.L.loc_window_last_host_timing(self.h, t))
+        return float(t[0]), float(t[1]), float(t[2]), bool(t[3])

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(built):
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/localization_amd.h but not exported"
     assert sorted(_lib.EXPORTED_SYMBOLS) == names
-    assert la.abi_version() == 3
+    assert la.abi_version() == 4
 
 
 def test_no_cpu_fallback(built):

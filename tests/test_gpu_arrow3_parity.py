@@ -87,23 +87,20 @@ def test_arrow3_kernel_matches_6dof_oracle_and_general_kernel(gpu, T, A, rich, j
     ref = _copy_batch(la, wb)
     mode = O.JAC_ANALYTIC if jac == "analytic" else O.JAC_NUMERIC_G2O
     want = [oracle_solve_instance(wb, i, FIXED, jac_mode=mode) for i in range(B)]
-    os.environ["LOCAMD_ARROW3"] = "0"
-    try:
-        g = la.WindowSolver(FIXED, B, *wb.caps, jacobian=jac)
-        res_g = g.solve(ref).copy()
-        assert g.last_kernel_kind() == "window_lm_kernel"
-        g.close()
-        os.environ["LOCAMD_ARROW3"] = "1"
-        s = la.WindowSolver(FIXED, B, *wb.caps, jacobian=jac)
-        res = s.solve(wb).copy()
-        assert s.last_kernel_kind() == "arrow3_lm_kernel"
-        # resident path: the same bits
-        wb2 = _copy_batch(la, wb); wb2.poses[:] = before
-        s.upload(wb2); s.solve_resident(); s.download(wb2)
-        assert s.last_kernel_kind() == "arrow3_lm_kernel"
-        s.close()
-    finally:
-        del os.environ["LOCAMD_ARROW3"]
+    g = la.WindowSolver(FIXED, B, *wb.caps, jacobian=jac)
+    g.set_option("arrow3", 0)                              # (was LOCAMD_ARROW3=0: never)
+    res_g = g.solve(ref).copy()
+    assert g.last_kernel_kind() == "window_lm_kernel"
+    g.close()
+    s = la.WindowSolver(FIXED, B, *wb.caps, jacobian=jac)
+    s.set_option("arrow3", 1)                              # whenever the batch qualifies (default: windows of more than 64 poses)
+    res = s.solve(wb).copy()
+    assert s.last_kernel_kind() == "arrow3_lm_kernel"
+    # resident path: the same bits
+    wb2 = _copy_batch(la, wb); wb2.poses[:] = before
+    s.upload(wb2); s.solve_resident(); s.download(wb2)
+    assert s.last_kernel_kind() == "arrow3_lm_kernel"
+    s.close()
     tol = 1e-6 if jac == "analytic" else 1e-4
     for i in range(B):
         nv = int(wb.counts[i, 0])

@@ -74,12 +74,10 @@ def test_chain3_kernel_matches_6dof_oracle_and_6dof_kernels(gpu, T, jac, with_z_
     assert general.last_kernel_kind() == "window_lm_kernel"
     general.close()
     chain = la.WindowSolver(ANCH, B, *wb.caps, jacobian=jac, chain_threshold=1)
-    os.environ["LOCAMD_CHAIN3"] = "0"
-    try:
-        res6 = chain.solve(six).copy()
-        assert chain.last_kernel_kind() == "chain_lm_kernel"
-    finally:
-        del os.environ["LOCAMD_CHAIN3"]
+    chain.set_option("chain3", 0)
+    res6 = chain.solve(six).copy()
+    assert chain.last_kernel_kind() == "chain_lm_kernel"
+    chain.set_option("chain3", 1)
     res = chain.solve(wb).copy()
     assert chain.last_kernel_kind() == "chain3_lm_kernel"
     tol = 1e-7 if jac == "analytic" else 3e-5
@@ -165,23 +163,19 @@ def test_lane_per_window_kernels_at_the_batch_size_that_selects_them(gpu, kernel
         src = getattr(small, name)
         getattr(wb, name)[:] = np.resize(src, (B,) + src.shape[1:])
     poses0 = wb.poses.copy()
-    if kernel == "chain_lm_kernel":
-        os.environ["LOCAMD_CHAIN3"] = "0"
-    if kernel == "chain3_lm_kernel":
-        os.environ["LOCAMD_WAVE3"] = "0"
-    try:
-        out = {}
-        for jac in ("analytic", "numeric"):
-            s = la.WindowSolver(anchors, B, *wb.caps, maximum_iteration=10, bw_max=1, jacobian=jac)
-            wb.poses[:] = poses0
-            s.solve(wb)
-            assert s.last_kernel_kind() == kernel
-            s.close()
-            out[jac] = wb.poses[:, :, 9:].copy()
-            assert np.array_equal(out[jac][:n_distinct], out[jac][n_distinct:2 * n_distinct])     # repeated windows, other lanes / waves: same bits
-    finally:
-        os.environ.pop("LOCAMD_CHAIN3", None)
-        os.environ.pop("LOCAMD_WAVE3", None)
+    out = {}
+    for jac in ("analytic", "numeric"):
+        s = la.WindowSolver(anchors, B, *wb.caps, maximum_iteration=10, bw_max=1, jacobian=jac)
+        if kernel == "chain_lm_kernel":
+            s.set_option("chain3", 0)
+        if kernel == "chain3_lm_kernel":
+            s.set_option("wave3", 0)
+        wb.poses[:] = poses0
+        s.solve(wb)
+        assert s.last_kernel_kind() == kernel
+        s.close()
+        out[jac] = wb.poses[:, :, 9:].copy()
+        assert np.array_equal(out[jac][:n_distinct], out[jac][n_distinct:2 * n_distinct])     # repeated windows, other lanes / waves: same bits
     want_num = bw.oracle_time(graphs, anchors, T, 2048)[1]
     want_ana = bw.oracle_time(graphs, anchors, T, 512, analytic=True)[1]
     same = np.abs(out["analytic"][:512] - want_ana).max(axis=(1, 2))

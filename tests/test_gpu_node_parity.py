@@ -446,7 +446,9 @@ int main(int argc, char** argv) {
     p.minimum_optimize_error = 2000.0; p.publish_range = true;
     p.nodesId = {%s};
     p.nodesPos = {%s};
+    {
     localization_amd::Localization loc(p);
+    loc.set_file(argv[2], p, "_shim.txt");   // Localization::set_file: the realtime / optimized logs of the reference
     FILE* f = std::fopen(argv[1], "r");
     if (!f) return 2;
     int responder, antenna; double stamp, distance, err;
@@ -458,6 +460,7 @@ int main(int argc, char** argv) {
     }
     std::fclose(f);
     std::printf("path %%zu\\n", loc.optimizedPath().size());
+    }   // ~Localization: path[T/2 .. T-1] appended to the optimized log (localization.cpp:708-717)
     return 0;
 }
 ''' % (", ".join(str(i) for i in ids), ", ".join(repr(float(v)) for v in pos.ravel())))
@@ -466,11 +469,11 @@ int main(int argc, char** argv) {
     cc = subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"), str(src), "-o", str(exe), "-L", libdir,
                          "-llocalization_amd", f"-Wl,-rpath,{libdir}"], capture_output=True, text=True)
     assert cc.returncode == 0, cc.stderr[-3000:]
-    run = subprocess.run([str(exe), str(data)], capture_output=True, text=True, timeout=120)
+    run = subprocess.run([str(exe), str(data), str(tmp_path / "log")], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0, run.stderr[-2000:]
     lines = run.stdout.strip().splitlines()
-    assert lines[-1] == "path 10"
-    got = np.array([[float(x) for x in ln.split()] for ln in lines[:-1]])
+    assert lines[-1].startswith("Results Loged to file:") and lines[-2] == "path 10"
+    got = np.array([[float(x) for x in ln.split()] for ln in lines[:-2]])
     node = la.LocalizationNode(ids, pos, trajectory_length=10, maximum_velocity=5.0, distance_outlier=1.0, maximum_iteration=10,
                                minimum_optimize_error=2000.0, publish_range=True)
     want = []
@@ -479,10 +482,88 @@ int main(int argc, char** argv) {
                            bag["uwb_distance_err"][i], int(bag["uwb_antenna"][i]), "uwb")
         if o["solved"] and o["published"]:
             want.append([o["realtime"][0], o["realtime"][1], o["realtime"][2], o["realtime"][3], o["chi2"]])
+    tail = node.flush_tail()          # loc_node_flush_tail: path[T/2 .. T-1]
+    assert tail.shape == (5, 8) and np.array_equal(tail, node.path(200)[5:])
     node.close()
     want = np.array(want)
     assert got.shape == want.shape and len(got) > 90
     assert np.array_equal(got, want)
+    # the logs the shim wrote the way Localization::publish / save_file / ~Localization do: header, one row per published solve, and in
+    # the optimized log the newest half of the window at destruction
+    rt = [ln for ln in open(tmp_path / "log_realtime_shim.txt") if not ln.startswith("#")]
+    op = [ln for ln in open(tmp_path / "log_optimized_shim.txt") if not ln.startswith("#")]
+    hdr = [ln for ln in open(tmp_path / "log_optimized_shim.txt") if ln.startswith("#")]
+    assert hdr == ["# iteration_max:10\n", "# trajectory_length:10\n", "# maximum_velocity:5\n"]
+    assert len(rt) == len(want) and len(op) == len(want) + 5
+    rows = np.array([[float(x) for x in ln.split()] for ln in op[-5:]])
+    assert np.allclose(rows[:, 0], tail[:, 0], atol=1e-8) and np.allclose(rows[:, 1:], tail[:, 1:], rtol=2e-6, atol=1e-9)   # (%g: six digits)
+    assert np.allclose(np.array([[float(x) for x in ln.split()] for ln in rt])[:, 1:4], want[:, 1:4], rtol=2e-6, atol=1e-9)
+
+
+def test_shim_adapter_rl_range_edges(gpu, tmp_path):
+    """The sixth callback of the reference's class through the adapter header: Localization::addRLRangeEdge (localization.cpp:378-436,
+    localization.h:122-124) — a compiled C++ program feeds uwbTalkData-shaped messages and prints the self node's pose after
+    every solve; the ctypes harness fed the same messages gives the same bits."""
+    import subprocess
+    import localization_amd as la
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ids = [1, 2, 3, 4]
+    pos = np.array([[2.0, -2.0, 0.5], [2.0, 2.0, 1.5], [-2.0, 0.0, 1.0], [0.2, 0.1, 1.0]])
+    rng = np.random.default_rng(8)
+    truth = pos.copy()
+    vel = rng.normal(0, 0.3, (4, 3)); vel[:, 2] *= 0.2
+    msgs = []
+    for step in range(24):
+        t = 20.0 + 0.05 * (step + 1)
+        truth = truth + 0.05 * vel
+        a, b = step % 4, (step + 1 + step // 4) % 4
+        if a == b: b = (b + 1) % 4
+        msgs.append((t, ids[a], ids[b], float(np.linalg.norm(truth[a] - truth[b]) + rng.normal(0, 0.02)), vel[a] + rng.normal(0, 0.02, 3)))
+    data = tmp_path / "talk.txt"
+    with open(data, "w") as f:
+        for t, a, b, d, v in msgs:
+            f.write(f"{t!r} {a} {b} {d!r} {float(v[0])!r} {float(v[1])!r} {float(v[2])!r}\n")
+    src = tmp_path / "shim_rl.cpp"
+    src.write_text('''
+#include <cstdio>
+#include "localization_amd_shim.hpp"
+int main(int argc, char** argv) {
+    localization_amd::Localization::Params p;
+    p.trajectory_length = 5; p.maximum_velocity = 2.0; p.maximum_iteration = 4; p.minimum_optimize_error = 1e9;
+    p.relative_range_topic = true; p.numeric_jacobian = true;
+    p.nodesId = {1, 2, 3, 4};
+    p.nodesPos = {%s};
+    localization_amd::Localization loc(p);
+    FILE* f = std::fopen(argv[1], "r");
+    if (!f) return 2;
+    double t, d, vx, vy, vz; int a, b;
+    while (std::fscanf(f, "%%lf %%d %%d %%lf %%lf %%lf %%lf", &t, &a, &b, &d, &vx, &vy, &vz) == 7) {
+        loc.addRLRangeEdge(t, a, b, d, {{vx, vy, vz}});
+        loc.solve();
+        const auto q = loc.realtimePose();
+        std::printf("%%.17g %%.17g %%.17g %%.17g\\n", q.position[0], q.position[1], q.position[2], loc.chi2());
+    }
+    std::fclose(f);
+    return 0;
+}
+''' % ", ".join(repr(float(v)) for v in pos.ravel()))
+    exe = tmp_path / "shim_rl"
+    libdir = os.path.join(root, "localization_amd")
+    cc = subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"), str(src), "-o", str(exe), "-L", libdir,
+                         "-llocalization_amd", f"-Wl,-rpath,{libdir}"], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr[-3000:]
+    run = subprocess.run([str(exe), str(data)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stderr[-2000:]
+    got = np.array([[float(x) for x in ln.split()] for ln in run.stdout.strip().splitlines()])
+    node = la.LocalizationNode(ids, pos.ravel(), trajectory_length=5, maximum_velocity=2.0, maximum_iteration=4, minimum_optimize_error=1e9,
+                               has_relative_range=True)
+    want = []
+    for t, a, b, d, v in msgs:
+        node.add_rl_range(a, b, t, d, v)
+        o = node.solve()
+        want.append([o["realtime"][1], o["realtime"][2], o["realtime"][3], o["chi2"]])
+    node.close()
+    assert got.shape == (24, 4) and np.array_equal(got, np.array(want))
 
 
 def test_fleet_batch_equals_one_by_one(gpu, bag):

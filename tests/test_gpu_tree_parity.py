@@ -131,11 +131,9 @@ def test_lane_per_window_tree_kernel_on_the_same_schedule(gpu, jac):
     # without the doubled EdgeSE3 both variants apply: lane-per-window (forced) against lane-per-pose
     plain_lane = _forest_batch(la, np.random.default_rng(5), B, T, 4, True)
     plain_wave = _copy_batch(la, plain_lane)
-    os.environ["LOCAMD_TREE"] = "lane"
-    try:
-        s.solve(plain_lane)
-    finally:
-        del os.environ["LOCAMD_TREE"]
+    s.set_option("tree", 2)                                # the lane-per-window variant (was LOCAMD_TREE=lane)
+    s.solve(plain_lane)
+    s.set_option("tree", -1)
     s.solve(plain_wave)
     assert np.abs(plain_lane.poses - plain_wave.poses).max() < tol
     s.close()

@@ -153,11 +153,9 @@ def test_wave3_selection_rules(gpu):
     def far_pair(wb): wb.r_idx[11, int(wb.counts[11, 1]) - 1] = (4, 1)       # a moving-moving edge that skips poses: not a chain
     for mut in (lever, turned, rot_info, far_pair):
         assert kind(mut) == "window_lm_kernel", mut.__name__
-    os.environ["LOCAMD_WAVE3"] = "0"
-    try:
-        assert kind(lambda wb: None) == "window_lm_kernel"
-    finally:
-        del os.environ["LOCAMD_WAVE3"]
+    s.set_option("wave3", 0)
+    assert kind(lambda wb: None) == "window_lm_kernel"
+    s.set_option("wave3", 1)
     s.L.loc_window_set_chain_threshold(s.h, 0)                                # 0: never anything but the general kernel
     assert kind(lambda wb: None) == "window_lm_kernel"
     s.L.loc_window_set_chain_threshold(s.h, 8)                                # a batch of 16 is then large enough for one lane per window

@@ -157,11 +157,9 @@ def test_wave6_selection_rules(gpu):
     def far_pair(wb): wb.r_idx[11, int(wb.counts[11, 1]) - 1] = (4, 1)        # not a chain
     for mut in (doubled, doubled_in_order, se3, far_pair):
         assert kind(mut) == "window_lm_kernel", mut.__name__
-    os.environ["LOCAMD_WAVE6"] = "0"
-    try:
-        assert kind(lambda wb: None) == "window_lm_kernel"
-    finally:
-        del os.environ["LOCAMD_WAVE6"]
+    s.set_option("wave6", 0)
+    assert kind(lambda wb: None) == "window_lm_kernel"
+    s.set_option("wave6", 1)
     s.L.loc_window_set_chain_threshold(s.h, 0)                                # 0: never anything but the general kernel
     assert kind(lambda wb: None) == "window_lm_kernel"
     s.L.loc_window_set_chain_threshold(s.h, 8)                                # a batch of 16 is then large enough for one lane per window

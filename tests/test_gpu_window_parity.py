@@ -654,3 +654,93 @@ def _without_off1(la, wb):
         getattr(out, name)[:] = getattr(wb, name)
     out.poses[:] = wb._initial if hasattr(wb, "_initial") else wb.poses
     return out
+
+
+def _chain_batch(la, B, T, seed):
+    rng = np.random.default_rng(seed)
+    wb = la.WindowBatch(B, T, 2 * T, 0, 0)
+    for i in range(B):
+        est_t, est_R, off, ranges, smooth, priors, se3 = _random_window(rng, T, False, False, False)
+        for k in range(T):
+            wb.add_pose(i, est_t[k])
+            a = ranges[k]
+            if k > 0:
+                wb.add_range(i, k - 1, k, 0.0, smooth[k - 1][3])
+            wb.add_range(i, k, a[1], a[2], a[3], anchor=True)
+    return wb
+
+
+def test_large_host_solve_drops_the_resident_batch(gpu):
+    """include/localization_amd.h, "Mixing with loc_window_solve_host": a host solve too large for the staging block reuses the device
+    arrays the resident batch lives in, so the resident batch is gone afterwards — loc_window_solve_resident / loc_window_download say
+    LOC_ERR_INVALID until the next upload (before: the resident kernel chosen at upload ran on the other batch's data).  A small host
+    solve in between leaves the resident batch alone."""
+    import localization_amd as la
+    from localization_amd import _lib
+    B, T = 3000, 10                                        # 3000 x (960 + 800 + ...) B > 4 MiB: the large path
+    big = _chain_batch(la, B, T, 5)
+    small = _chain_batch(la, 2, T, 6)
+    solver = la.WindowSolver(ANCH, B, T, 2 * T, 0, 0, maximum_iteration=10, jacobian="analytic", bw_max=1)
+    ref = _chain_batch(la, B, T, 5)
+    solver.solve(ref)                                     # what the batch solves to
+    solver.upload(big)
+    solver.solve_resident()
+    keep = small.poses.copy()
+    solver.solve(small)                                   # small: through the staging block
+    assert solver.last_host_timing()[2] > 0.0
+    assert not np.array_equal(small.poses, keep)
+    out = _chain_batch(la, B, T, 5)
+    solver.solve_resident()                               # the resident batch is still there
+    solver.download(out)
+    assert np.array_equal(out.poses, ref.poses)
+    other = _chain_batch(la, B, T, 7)
+    solver.solve(other)                                   # large: takes over the device arrays
+    for call in (solver.solve_resident, lambda: solver.download(out)):
+        with pytest.raises(la.LocalizationAmdError) as exc:
+            call()
+        assert exc.value.code == _lib.LOC_ERR_INVALID
+    solver.upload(big)                                    # ... until the next upload
+    solver.solve_resident()
+    solver.download(out)
+    assert np.array_equal(out.poses, ref.poses)
+    solver.close()
+
+
+def test_window_options_and_topology_cache(gpu):
+    """loc_window_set_option replaces the environment switches (read once at create); the structural verdict of a host-path batch is
+    cached on a hash of its counts / index tables: the same graph with new measurements skips the analysis, another structure does not;
+    the result is the same with the cache off."""
+    import localization_amd as la
+    B, T = 600, 10
+    a, b = _chain_batch(la, B, T, 1), _chain_batch(la, B, T, 2)
+    solver = la.WindowSolver(ANCH, B, T, 2 * T, 0, 0, maximum_iteration=10, jacobian="analytic", bw_max=1)
+    with pytest.raises(la.LocalizationAmdError):
+        solver.set_option("no_such_switch", 1)
+    with pytest.raises(la.LocalizationAmdError):
+        solver.set_option("wave3", 7)
+    solver.solve(a)
+    assert solver.last_kernel_kind() == "wave3_lm_kernel" and solver.last_host_timing()[3] is False
+    solver.solve(b)                                        # same structure, other measurements: verdict from the cache
+    t = solver.last_host_timing()
+    assert t[3] is True and solver.last_kernel_kind() == "wave3_lm_kernel"
+    cached = b.poses.copy()
+    solver.set_option("topology_cache", 0)
+    b2 = _chain_batch(la, B, T, 2)
+    solver.solve(b2)
+    assert solver.last_host_timing()[3] is False and np.array_equal(b2.poses, cached)
+    solver.set_option("topology_cache", 1)
+    solver.set_option("wave3", 0)                          # A/B switch of the handle (was: LOCAMD_WAVE3=0 read at every solve)
+    b3 = _chain_batch(la, B, T, 2)
+    solver.solve(b3)
+    assert solver.last_kernel_kind() == "window_lm_kernel"
+    assert np.abs(b3.poses - cached).max() < 1e-6
+    solver.set_option("wave3", 1)
+    solver.set_option("chain_min_batch", 0)                # "never anything but the general kernel"
+    solver.solve(b3)
+    assert solver.last_kernel_kind() == "window_lm_kernel"
+    solver.set_option("chain_min_batch", -1)
+    c = _chain_batch(la, B, T, 3)
+    c.r_idx[5, 1, 1] = -1 - 2                               # another structure: instance 5's smoothness edge becomes an anchor range
+    solver.solve(c)
+    assert solver.last_host_timing()[3] is False
+    solver.close()

@@ -140,3 +140,63 @@ def test_bench_refuses_to_run_a_smaller_job_than_asked():
     run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--legs", "none"],
                          capture_output=True, text=True, timeout=120, env=env)
     assert run.returncode != 0 and "refusing to run a smaller job" in run.stderr and run.stdout.strip() == ""
+
+
+class _FakeDist:
+    """what bench.py's Dist offers to reporting_collectives, on host tensors (no device in this container)"""
+
+    def __init__(self, rank, world):
+        self.torch, self.rank, self.world, self.backend, self.dev = torch, rank, world, "gloo", torch.device("cpu")
+
+    def barrier(self):
+        dist.barrier()
+
+
+def _collectives_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import argparse
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    from localization_amd.synthetic import make_snapshot_stream
+    from localization_amd.snapshot import pack_ranges
+    B, E, steps = 48, 4, 3
+    s = make_snapshot_stream(B, E * steps, seed=100 + rank)
+    g = torch.Generator().manual_seed(rank)
+    out_pos = torch.from_numpy(np.ascontiguousarray(s["truth"])) + 0.01 * torch.randn(E * steps, 3, B, generator=g, dtype=torch.float64)
+    out_chi2 = torch.rand(E * steps, B, generator=g, dtype=torch.float64)
+    if rank == 1:
+        out_chi2[-1, 3] = float("inf"); out_pos[-1, 0, 5] = float("nan")
+    out_trials = torch.full((E * steps, B), 10 + rank, dtype=torch.uint8)
+    tiles = torch.from_numpy(pack_ranges(s["dist"]))
+    args = argparse.Namespace(warmup=1)
+    res = bench.reporting_collectives(_FakeDist(rank, world), args, out_pos, out_chi2, out_trials, tiles, E, steps, B)
+    fin = torch.isfinite(out_chi2[E:])
+    mine = [float(out_chi2[E:][fin].sum()), float(out_trials[E:].double().sum()), 1.0 if rank == 1 else 0.0]
+    allm = [torch.zeros(3, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(allm, torch.tensor(mine, dtype=torch.float64))
+    if rank == 0:
+        import json
+        json.dump({"res": res, "sums": torch.stack(allm).sum(0).tolist()}, open(out_path, "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_reporting_collectives_two_ranks_gloo(tmp_path):
+    """SURVEY §8(e)(1)-(2) as bench.py runs them after the timed region for N > 1: the all-reduce(SUM) of the four reporting scalars and
+    the all-gather of one result slab per rank with its checksum — rehearsed with two gloo ranks on host tensors (on a GPU node the same
+    code runs over RCCL on device tensors; unmeasured on hardware)."""
+    import json
+    out = str(tmp_path / "coll.json")
+    mp.start_processes(_collectives_worker, args=(2, _free_port(), out), nprocs=2, join=True, start_method="spawn")
+    j = json.load(open(out))
+    res, sums = j["res"], j["sums"]
+    assert res["ranks"] == 2 and res["backend"].startswith("gloo")
+    assert res["scalars"] == ["sum_chi2", "sum_lm_trials", "n_nonfinite_estimates", "n_gated_ranges_last_epoch"]
+    v = res["all_reduce"]["values"]
+    assert v[0] == pytest.approx(sums[0], rel=1e-12) and v[1] == sums[1] == 48 * 8 * (10 + 11) and v[2] == sums[2] == 1.0
+    assert v[3] >= 0 and res["all_reduce"]["bytes"] == 32
+    assert res["all_gather"]["checksum_ok"] is True and res["all_gather"]["bytes"] == 2 * 4 * 48 * 8 and res["all_gather"]["slab_shape_per_rank"] == [4, 48]
+    assert res["bytes"] == 32 + 3072 and res["ms"] > 0

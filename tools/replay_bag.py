@@ -87,12 +87,10 @@ def main():
             realtime.append(o["realtime"]); optimized.append(o["optimized"])
     # Localization::~Localization (localization.cpp:708-717): at shutdown the second half of the window, path[T/2 .. T-1], is
     # appended to the optimized log (path[T/2] therefore appears twice, as in the reference's file)
-    n_flushed = 0
-    if optimized:
-        path = node.path(cfg.nodes_id[-1])
-        T = int(cfg.trajectory_length)
-        for i in range(T // 2, min(T, len(path))):
-            optimized.append(path[i].copy()); n_flushed += 1
+    # — through the C ABI's loc_node_flush_tail, the call the shim's destructor makes too
+    tail = node.flush_tail()
+    n_flushed = len(tail)
+    optimized.extend(row.copy() for row in tail)
     prefix = a.prefix or os.path.splitext(a.bag)[0]
     os.makedirs(os.path.dirname(os.path.abspath(prefix)), exist_ok=True)
     header = [f"iteration_max:{cfg.maximum_iteration}", f"trajectory_length:{cfg.trajectory_length}", f"maximum_velocity:{cfg.maximum_velocity}"]
