@@ -47,7 +47,11 @@ def kernel_source_hash(names):
 
 
 SNAPSHOT_KERNEL_SOURCES = ("snapshot_kernel.hip", "snapshot_kernel.h", "device_math.h")
-WINDOW_KERNEL_SOURCES = ("window_kernel.hip", "chain3_kernel.hip", "arrow3_kernel.hip", "wave3_kernel.hip", "window_kernel.h", "device_math.h", "numeric_jacobian.h")
+_WIN_COMMON = ("window_kernel.h", "device_math.h", "numeric_jacobian.h")
+# per leg: the sources of the kernel that leg runs (one translation unit per kernel since round 4)
+WINDOW_LEG_SOURCES = {"cfg1_windows": ("wave3_kernel.hip",) + _WIN_COMMON,
+                      "cfg4": ("arrow3_kernel.hip",) + _WIN_COMMON,
+                      "cfg5": ("tree_kernel.hip", "se3_edge_device.h", "window_device.h") + _WIN_COMMON}
 
 
 def window_traffic(leg, world):
@@ -56,10 +60,12 @@ def window_traffic(leg, world):
     path = os.path.join(ROOT, "profiles", "window_traffic.json")
     if world != 1 or not os.path.exists(path):
         return None
-    pj = json.load(open(path))
-    if pj.get("kernel_source_sha256") != kernel_source_hash(WINDOW_KERNEL_SOURCES):
-        return {"stale": "profiles/window_traffic.json was measured on different kernel sources (hash mismatch): traffic withheld"}
-    return pj.get("legs", {}).get(leg)
+    ent = json.load(open(path)).get("legs", {}).get(leg)
+    if not ent or leg not in WINDOW_LEG_SOURCES:
+        return None
+    if ent.get("kernel_source_sha256") != kernel_source_hash(WINDOW_LEG_SOURCES[leg]):
+        return {"stale": "profiles/window_traffic.json was measured on different sources of this leg's kernel (hash mismatch): traffic withheld"}
+    return ent
 
 
 def cpu_baseline(anchors, dist_tiles, err_tiles, init, n_tags, n_epochs, gpu_pos, M, gpu_jacobian="numeric"):
@@ -84,8 +90,10 @@ def cpu_baseline(anchors, dist_tiles, err_tiles, init, n_tags, n_epochs, gpu_pos
         g = gpu_pos[:n_epochs, :, :n_tags].cpu().numpy()
         out["max_abs_diff_vs_gpu_m"] = float(np.abs(g - rp).max())
         out["median_abs_diff_vs_gpu_m"] = float(np.median(np.abs(g - rp).max(axis=1)))
+        out["frac_updates_diff_gt_1e-5_m"] = float((np.abs(g - rp).max(axis=1) > 1e-5).mean())
         out["diff_note"] = (f"GPU headline (jacobian = {gpu_jacobian}) against the oracle (numeric) on the sample: " +
-                            ("the same Jacobian mode on both sides (tests assert <= 1e-5 m)" if gpu_jacobian == "numeric" else
+                            ("the same Jacobian mode on both sides: SURVEY §8(c)'s 1e-5 m holds for all but the fraction reported (updates whose LM accept / reject "
+                             "decision the 1e-7 relative noise of the delta = 1e-9 difference quotient flips; two CPU builds of g2o differ the same way)" if gpu_jacobian == "numeric" else
                              "CROSS-mode, fixed 10 LM iterations, iterates not converged"))
     return out, rp
 
@@ -375,8 +383,6 @@ def leg_cfg3(D, args):
     for jac in ("analytic", "numeric"):   # (the reference's configuration last: its first-step output is what the CPU sample is compared with)
         f = la.FusionSolver(s["anchors"], B, antenna_offset=s["offset"], maximum_iteration=10, distance_outlier=3.0, device=D.local_rank, jacobian=jac)
         f.set_poses(s["init"])
-        kms = []
-
         def step(i):
             d, e, q = fwd if i % 2 == 0 else rev
             f.solve_device(d, e, q, out_pose, out_chi2, None)
@@ -387,16 +393,16 @@ def leg_cfg3(D, args):
         for i in range(1, warmup):
             step(i)
         D.barrier()
+        f.timing_begin(steps)
         t0 = time.perf_counter()
         for i in range(warmup, warmup + steps):
             step(i)
-            if args.cfg3_kernel_times:   # (HIP-event time of every launch: costs a synchronize per step, so it is not the default)
-                torch.cuda.synchronize(); kms.append(f.last_kernel_ms())
         D.barrier()
         elapsed = D.max_over_ranks(time.perf_counter() - t0)
-        kern_ms = D.max_over_ranks(f.last_kernel_ms())   # the last launch's HIP-event time on the slowest rank
+        n_l, _, avg = f.timing_end()
+        kern_ms = D.max_over_ranks(avg)   # HIP events around every timed launch, the slowest rank's average
         f.close()
-        modes[jac] = {"elapsed": elapsed, "kern_ms": kern_ms}
+        modes[jac] = {"elapsed": elapsed, "kern_ms": kern_ms, "launches": n_l}
     num, ana = modes["numeric"], modes["analytic"]
     res = {"workload": "BASELINE cfg3: 8 anchors + IMU rotation prior + antenna lever arm, 6-DoF, g2o-style LM, 10 iterations",
            "metric": "localization updates/sec", "value": upd * steps * D.world / num["elapsed"], "unit": "updates/s", "steps": steps,
@@ -404,10 +410,9 @@ def leg_cfg3(D, args):
            "epochs_per_step": E, "jacobian": "numeric",
            "value_note": "wall time of the timed steps (barrier + synchronize on both sides), numeric Jacobians = the reference's configuration",
            "value_fast_mode": upd * steps * D.world / ana["elapsed"],
-           "fast_mode": {"jacobian": "analytic", "ms_per_step": ana["elapsed"] / steps * 1e3, "kernel_ms_last": ana["kern_ms"],
+           "fast_mode": {"jacobian": "analytic", "ms_per_step": ana["elapsed"] / steps * 1e3, "kernel_ms_avg": ana["kern_ms"],
                          "roofline_frac": ALGO_BYTES_CFG3 * upd / (ana["kern_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
-           "roofline": hbm_roofline("fusion_lm_kernel<JAC = numeric>", ALGO_BYTES_CFG3 * upd, num["kern_ms"], 1,
-                                    "248 B/update; VALU-issue bound; kernel time = HIP events around the last timed launch")}
+           "roofline": hbm_roofline("fusion_lm_kernel<JAC = numeric>", ALGO_BYTES_CFG3 * upd, num["kern_ms"], num["launches"], "248 B/update; VALU-issue bound")}
     if D.rank == 0 and D.world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
         nt, ne = 512, 32
@@ -834,7 +839,6 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the driver's multi-GPU runs); gloo only to rehearse N > 1 on a one-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cfg3-kernel-times", action="store_true", help="cfg3 leg: HIP-event time of every launch (a synchronize per step)")
     ap.add_argument("--cpu-tags", type=int, default=2048)
     ap.add_argument("--cpu-epochs", type=int, default=96)
     ap.add_argument("--legs", default="all", help="secondary legs: all, none, or a comma list of cfg2_analytic,cfg2_numeric,cfg3,cfg5,cfg4,cfg1_windows,cfg1_node,node_uwb_twist,node_uwb_pose_T500")

@@ -32,12 +32,7 @@
 //   * small windows keep everything in LDS, larger ones in a per-instance slice of an HBM workspace (index tables in LDS);
 //   * all LM control flow is uniform over the instance's threads (sums are DPP reductions, combined across the waves in wave
 //     order: every thread holds the same bits).
-#include "window_kernel.h"
-#include "device_math.h"
-#include "numeric_jacobian.h"
-
-#include <float.h>
-#include <math.h>
+#include "window_device.h"
 
 #include <atomic>
 
@@ -53,167 +48,6 @@ constexpr int PREC = 28;   // H_vv[21] b_v[6] (+pad)
 constexpr int SREC = 90;   // H_ii[21] H_jj[21] H_(later,earlier)[36, column-major like the storage] b_i[6] b_j[6]
 constexpr int S_HJJ = 21, S_OFF = 42, S_BI = 78, S_BJ = 84;
 
-// Wave-wide reductions on the VALU (DPP row shifts + row broadcasts, then one readlane): every lane gets the same
-// bits, no LDS crossbar round trips (a __shfl_xor butterfly on doubles costs ~6 dependent ds_bpermute pairs).
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_or_zero(double v, double identity) {
-    const int ilo = __double2loint(identity), ihi = __double2hiint(identity);
-    const int lo = __builtin_amdgcn_update_dpp(ilo, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(ihi, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double read_lane63(double v) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wave_sum(double v) {
-    v += dpp_or_zero<0x111, 0xF>(v, 0.0);  // row_shr:1
-    v += dpp_or_zero<0x112, 0xF>(v, 0.0);  // row_shr:2
-    v += dpp_or_zero<0x114, 0xF>(v, 0.0);  // row_shr:4
-    v += dpp_or_zero<0x118, 0xF>(v, 0.0);  // row_shr:8  -> lane 15 of each row holds the row sum
-    v += dpp_or_zero<0x142, 0xA>(v, 0.0);  // row_bcast:15 into rows 1 and 3
-    v += dpp_or_zero<0x143, 0xC>(v, 0.0);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
-    return read_lane63(v);
-}
-__device__ __forceinline__ double wave_max(double v) {  // for non-negative inputs (identity 0)
-    v = fmax(v, dpp_or_zero<0x111, 0xF>(v, 0.0));
-    v = fmax(v, dpp_or_zero<0x112, 0xF>(v, 0.0));
-    v = fmax(v, dpp_or_zero<0x114, 0xF>(v, 0.0));
-    v = fmax(v, dpp_or_zero<0x118, 0xF>(v, 0.0));
-    v = fmax(v, dpp_or_zero<0x142, 0xA>(v, 0.0));
-    v = fmax(v, dpp_or_zero<0x143, 0xC>(v, 0.0));
-    return read_lane63(v);
-}
-
-// ---- several waves per window (NW > 1: windows of 65 .. 512 poses, whose structure tables fill a CU's LDS so that ONE window
-//      runs per CU — with one wave it used a quarter of one SIMD pair's issue slots and left three SIMDs idle) ------------------
-// SOLO: a section executed by wave 0 alone (the set-up) orders its own memory operations without the workgroup barrier.
-template <bool SOLO>
-__device__ __forceinline__ void sync_() {
-    if (SOLO) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    } else {
-        __syncthreads();
-    }
-}
-// Reductions over the NW waves of a window through `red` (NW doubles of LDS): every thread gets the same bits (the waves'
-// partial results are combined in wave order).  Two barriers each; all threads must call.
-template <int NW>
-__device__ __forceinline__ double block_sum(double v, double* red, int tid) {
-    const double w = wave_sum(v);
-    if (NW == 1) return w;
-    __syncthreads();
-    if ((tid & 63) == 0) red[tid >> 6] = w;
-    __syncthreads();
-    double t = red[0];
-#pragma unroll
-    for (int i = 1; i < NW; ++i) t += red[i];
-    return t;
-}
-template <int NW>
-__device__ __forceinline__ double block_max(double v, double* red, int tid) {  // non-negative inputs
-    const double w = wave_max(v);
-    if (NW == 1) return w;
-    __syncthreads();
-    if ((tid & 63) == 0) red[tid >> 6] = w;
-    __syncthreads();
-    double t = red[0];
-#pragma unroll
-    for (int i = 1; i < NW; ++i) t = fmax(t, red[i]);
-    return t;
-}
-template <int NW>
-__device__ __forceinline__ bool block_any(bool pred, double* red, int tid) {
-    const bool w = __ballot(pred) != 0;
-    if (NW == 1) return w;
-    __syncthreads();
-    if ((tid & 63) == 0) red[tid >> 6] = w ? 1.0 : 0.0;
-    __syncthreads();
-    bool t = false;
-#pragma unroll
-    for (int i = 0; i < NW; ++i) t = t || red[i] != 0.0;
-    return t;
-}
-
-// ---- small SE3 algebra (row-major 3x3) -------------------------------------------------------------------------
-__device__ __forceinline__ void mat_mul(const double* A, const double* B, double* C) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i * 3 + 0] * B[0 * 3 + j] + A[i * 3 + 1] * B[1 * 3 + j] + A[i * 3 + 2] * B[2 * 3 + j];
-}
-__device__ __forceinline__ void mat_tmul(const double* A, const double* B, double* C) {  // A^T B
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[0 * 3 + i] * B[0 * 3 + j] + A[1 * 3 + i] * B[1 * 3 + j] + A[2 * 3 + i] * B[2 * 3 + j];
-}
-__device__ __forceinline__ void mat_vec(const double* A, const double* v, double* o) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) o[i] = A[i * 3 + 0] * v[0] + A[i * 3 + 1] * v[1] + A[i * 3 + 2] * v[2];
-}
-__device__ __forceinline__ void mat_tvec(const double* A, const double* v, double* o) {  // A^T v
-#pragma unroll
-    for (int i = 0; i < 3; ++i) o[i] = A[0 * 3 + i] * v[0] + A[1 * 3 + i] * v[1] + A[2 * 3 + i] * v[2];
-}
-// Eigen::Quaternion(Matrix3) — q = (w, x, y, z).  Scalars, not an array: the optimiser otherwise merges the branches
-// into a computed index and the array lands in scratch memory.
-__device__ __forceinline__ void mat_to_quat(const double* R, double* q) {
-    double qw, qx, qy, qz;
-    double t = R[0] + R[4] + R[8];
-    if (t > 0) {
-        t = sqrt(t + 1.0);
-        qw = 0.5 * t; t = 0.5 / t;
-        qx = (R[7] - R[5]) * t; qy = (R[2] - R[6]) * t; qz = (R[3] - R[1]) * t;
-    } else if (R[0] >= R[4] && R[0] >= R[8]) {  // i = 0, j = 1, k = 2
-        t = sqrt(R[0] - R[4] - R[8] + 1.0);
-        qx = 0.5 * t; t = 0.5 / t;
-        qw = (R[7] - R[5]) * t; qy = (R[3] + R[1]) * t; qz = (R[6] + R[2]) * t;
-    } else if (R[4] > R[0] && R[4] >= R[8]) {   // i = 1, j = 2, k = 0
-        t = sqrt(R[4] - R[8] - R[0] + 1.0);
-        qy = 0.5 * t; t = 0.5 / t;
-        qw = (R[2] - R[6]) * t; qz = (R[7] + R[5]) * t; qx = (R[1] + R[3]) * t;
-    } else {                                      // i = 2, j = 0, k = 1
-        t = sqrt(R[8] - R[0] - R[4] + 1.0);
-        qz = 0.5 * t; t = 0.5 / t;
-        qw = (R[3] - R[1]) * t; qx = (R[2] + R[6]) * t; qy = (R[5] + R[7]) * t;
-    }
-    q[0] = qw; q[1] = qx; q[2] = qy; q[3] = qz;
-}
-__device__ __forceinline__ void quat_mul(const double* a, const double* b, double* o) {
-    o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
-    o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
-    o[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
-    o[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
-}
-// g2o internal::normalize: unit norm, w >= 0; returns the sign applied
-__device__ __forceinline__ double quat_normalize_sign(double* q) {
-    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-    double s = 1.0 / n, sg = 1.0;
-    if (q[0] < 0) { s = -s; sg = -1.0; }
-    q[0] *= s; q[1] *= s; q[2] *= s; q[3] *= s;
-    return sg;
-}
-// Eigen toRotationMatrix (no normalisation)
-__device__ __forceinline__ void quat_to_mat(const double* q, double* R) {
-    const double w = q[0], x = q[1], y = q[2], z = q[3];
-    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
-    const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
-    R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
-    R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
-    R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
-}
-// rows 3..5 x cols 3..5 of a Jacobian: d vec(q (x) (sqrt(1-|v|^2), v)) / dv at 0 = w I + [q_xyz]x
-__device__ __forceinline__ void quat_right_jac(const double* q, double sgn, double* J, int ldj) {
-    const double w = q[0] * sgn, x = q[1] * sgn, y = q[2] * sgn, z = q[3] * sgn;
-    J[3 * ldj + 3] = w;  J[3 * ldj + 4] = -z; J[3 * ldj + 5] = y;
-    J[4 * ldj + 3] = z;  J[4 * ldj + 4] = w;  J[4 * ldj + 5] = -x;
-    J[5 * ldj + 3] = -y; J[5 * ldj + 4] = x;  J[5 * ldj + 5] = w;
-}
-
-typedef unsigned long long u64;
 
 // Stage-A record: out[entry] = in[entry] - sum_k a[k] b[k] for one earlier column K.  dst = index of the block / vector being
 // formed (its source, H or b, lies a fixed distance below), a / b = indices of L_iK (or y_K) and L_JK; ctl bit 0 = the record has
@@ -302,38 +136,6 @@ struct Lds {
 #define LOCAMD_T5_DECL do {} while (0)
 #endif
 
-#pragma clang fp contract(off)
-// one column of the numeric Jacobian of endpoint `which` (0: the pose carrying the lever arm, 1: the other pose)
-template <int D>
-__device__ __forceinline__ double range_jac_numeric(const double* X0, const double* off, const double* X1, const double* q1, int which, double meas,
-                                                    const double* off1 = nullptr) {
-    // (the textbook form of the increment here: these kernels sit at 512 registers, and the short form of numeric_jacobian.h — more
-    //  values shared between the twelve evaluations — costs tree_wave_kernel 112 B more scratch per lane and 10 % of its time)
-    constexpr double delta = 1e-9;
-    constexpr double scalar = 1.0 / (2 * delta);
-    double Rp[9], tp[3], Rm[9], tm[3];
-    double ep, em;
-    if (which == 0) {
-        oplus_axis_plain_reference<D>(X0, X0 + 9, delta, Rp, tp);
-        oplus_axis_plain_reference<D>(X0, X0 + 9, -delta, Rm, tm);
-        ep = range_error_plain(Rp, tp, off, q1, meas);
-        em = range_error_plain(Rm, tm, off, q1, meas);
-    } else if (off1) {   // endpoint 1 carries a lever arm too: its point is (X1 * fromVectorMQT(+-delta e_D)) * o1
-        perturbed_point_plain<D>(X1, X1 + 9, off1, delta, tp);
-        perturbed_point_plain<D>(X1, X1 + 9, off1, -delta, tm);
-        ep = range_error_plain(X0, X0 + 9, off, tp, meas);
-        em = range_error_plain(X0, X0 + 9, off, tm, meas);
-    } else {
-        oplus_axis_plain_reference<D>(X1, X1 + 9, delta, Rp, tp);   // endpoint 1 has no lever arm: its point is its translation
-        oplus_axis_plain_reference<D>(X1, X1 + 9, -delta, Rm, tm);
-        ep = range_error_plain(X0, X0 + 9, off, tp, meas);
-        em = range_error_plain(X0, X0 + 9, off, tm, meas);
-    }
-    double bak = ep;
-    bak -= em;
-    return scalar * bak;
-}
-#pragma clang fp contract(fast)
 
 template <bool SP>
 __device__ __forceinline__ int blk_off(const Lds& L, int i, int K);
@@ -1016,16 +818,6 @@ __device__ __forceinline__ void presum_rhs(const Lds& L, int lane, int J, int Ke
     }
 }
 
-// 1/sqrt(d) for a pivot d > 0: hardware seed (~2^-24) + one third-order step y (1 + e/2 + 3 e^2/8), e = 1 - d y^2: the error
-// term e^3 is far below an ulp; four dependent operations after the seed (the Goldschmidt pair + Newton used elsewhere: eight)
-__device__ __forceinline__ double pivot_rsqrt(double d) {
-    const double y = __builtin_amdgcn_rsq(d);
-    const double t = d * y;
-    const double e = __builtin_fma(-t, y, 1.0);
-    const double pq = __builtin_fma(0.375, e, 0.5);
-    const double ye = y * e;
-    return __builtin_fma(ye, pq, y);
-}
 
 template <int W> __device__ __forceinline__ bool level_is_column_mode(const Lds& L, int l) {
     return W == 1 ? ((L.colmode >> l) & 1ull) != 0 : L.lvl_mode[l] != 0;
@@ -3062,1930 +2854,5 @@ hipError_t launch_window(const WindowArgs& a, hipStream_t stream) {
     }
 }
 
-
-// =====================================================================================================================
-// CHAIN windows, one LANE per window (large batches of the reference's own sliding window: cfg/uwb_only.yaml, uwb_imu.yaml).
-//
-// A window whose binary edges all join CONSECUTIVE poses (the zero-range smoothness edge of Robot::new_vertex) and whose other
-// factors are unary (ranges to anchors with the antenna lever arm, IMU / lidar priors) has a block-TRIDIAGONAL H.  With one wave
-// per window such a system occupies 2 .. 14 lanes and costs ~4 k wave instructions per LM trial whatever is done (see
-// factor_and_solve_small).  Here every lane runs a whole window by itself — the sequential block-tridiagonal Cholesky a CPU
-// would run — and the wave's instruction stream is shared by 64 windows: ~12 k instructions per LM trial per 64 windows.
-// No cross-lane traffic, no LDS, no barriers.  The state of a window lives in an HBM workspace laid out [entry][lane]
-// (every load / store of the wave is one 512-byte line), per pose: H_pp (21), H_p,p-1 (36), b_p (6), G_p (15 + 6 inverse
-// pivots), y_p, x_p and two pose buffers: 120 doubles (W_p = L_p,p-1 is never stored: the back-substitution re-forms W^T x).  The LM loops are flattened into one loop of
-// passes (a pass = one trial; a lane that starts an iteration linearises first), lanes leave when their window is done.
-// The kernel is bound by that workspace traffic (~16 KB per window per trial), not by instruction issue.
-// Conditions (checked on the host, capi_window.cpp: batch_topology): every pose-to-pose edge — range edge or EdgeSE3 (addTwistEdge;
-// the <JAC, true> instantiation) — joins poses p - 1 and p; edges sorted by their later pose, priors sorted by pose (the order the
-// reference adds them in).
-// Elimination order = pose order (no fill), so the rounding differs from the general kernel's in the last bits.
-namespace chainw {
-constexpr int HD = 0, HO = 21, HB = 57, G = 63, Y = 84, X = 90, P = 96, PB = 108, N = 120;
-}
-
-// per window: nv_max poses x N doubles, then the edges as [entry][lane] too (range: v0, v1, measurement, information, lever
-// arm = 7 doubles; prior: v + 18 values = 19; SE3: vi, vj, robust + 48 values = 51)
-__host__ __device__ inline size_t chain_window_doubles(const WindowCaps& c) {
-    return (size_t)c.nv_max * chainw::N + (size_t)c.nr_max * 7 + (size_t)c.np_max * 19 + (size_t)c.ns_max * 51;
-}
-size_t window_chain_workspace_doubles(const WindowCaps& c, long long B) {
-    return (size_t)((B + 63) / 64) * 64 * chain_window_doubles(c);
-}
-
-namespace {
-
-// One EdgeSE3 between the consecutive poses i and j of a chain window: the math of evaluate_edges' SE3 branch, with the record in
-// registers.  Returns chi; rterm = the edge's robust cost; FULL: H_ii, H_jj (lower triangles, 21), the off-diagonal block with the
-// rows of the LATER pose (36, column-major), b_i, b_j.
-template <bool FULL>
-__device__ __forceinline__ double chain_se3_terms(const double* Xi, const double* Xj, const double* val, bool robust, bool j_is_later,
-                                                  double* Hii, double* Hjj, double* Hoff, double* bi_, double* bj_, double& rterm) {
-    double RB[9], tB[3], dt[3] = {Xj[9] - Xi[9], Xj[10] - Xi[10], Xj[11] - Xi[11]};
-    mat_tmul(Xi, Xj, RB);
-    mat_tvec(Xi, dt, tB);
-    double RE[9], tE[3];
-    mat_mul(val, RB, RE);
-    mat_vec(val, tB, tE);
-    tE[0] += val[9]; tE[1] += val[10]; tE[2] += val[11];
-    double qE[4];
-    mat_to_quat(RE, qE);
-    quat_normalize_sign(qE);
-    const double err[6] = {tE[0], tE[1], tE[2], qE[1], qE[2], qE[3]};
-    const double* Om = val + 12;
-    double Oe[6];
-    double chi = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        double r = 0.0;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) r += Om[i * 6 + j] * err[j];
-        Oe[i] = r;
-        chi += err[i] * r;
-    }
-    const double aux = 1.0 + chi;
-    rterm = robust ? fast_log_ge1(aux) : chi;
-    if (FULL) {
-        const double w = robust ? 1.0 / aux : 1.0;
-        double J0[36], J1[36];
-#pragma unroll
-        for (int i = 0; i < 36; ++i) { J0[i] = 0.0; J1[i] = 0.0; }
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) J1[i * 6 + j] = RE[i * 3 + j];
-        quat_right_jac(qE, 1.0, J1, 6);
-        const double S[9] = {0, -tB[2], tB[1], tB[2], 0, -tB[0], -tB[1], tB[0], 0};
-        double RAS[9];
-        mat_mul(val, S, RAS);
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) { J0[i * 6 + j] = -val[i * 3 + j]; J0[i * 6 + 3 + j] = 2.0 * RAS[i * 3 + j]; }
-        double qA[4], qB[4], qAB[4];
-        mat_to_quat(val, qA);
-        mat_to_quat(RB, qB);
-        quat_mul(qA, qB, qAB);
-        const double sg = qAB[0] < 0 ? -1.0 : 1.0;
-        const double nrm = 1.0 / sqrt(qAB[0] * qAB[0] + qAB[1] * qAB[1] + qAB[2] * qAB[2] + qAB[3] * qAB[3]);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            double ek[4] = {0, 0, 0, 0}, r1[4], r2[4];
-            ek[1 + k] = 1.0;
-            quat_mul(qA, ek, r1);
-            quat_mul(r1, qB, r2);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) J0[(3 + i) * 6 + 3 + k] = -sg * nrm * r2[1 + i];
-        }
-#define LOCAMD_J1_LO(c) ((c) < 3 ? 0 : 3)
-#define LOCAMD_J1_HI(c) ((c) < 3 ? 3 : 6)
-#define LOCAMD_J0_HI(c) ((c) < 3 ? 3 : 6)
-        double WJ[36];
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int cc = 0; cc < 6; ++cc) {
-                double s0 = 0.0;
-#pragma unroll
-                for (int j = 0; j < LOCAMD_J0_HI(cc); ++j) s0 += Om[i * 6 + j] * J0[j * 6 + cc];
-                WJ[i * 6 + cc] = w * s0;
-            }
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int cc = 0; cc <= r; ++cc) {
-                double h = 0.0;
-#pragma unroll
-                for (int i = 0; i < LOCAMD_J0_HI(r); ++i) h += J0[i * 6 + r] * WJ[i * 6 + cc];
-                Hii[r * (r + 1) / 2 + cc] = h;
-            }
-        if (j_is_later) {
-#pragma unroll
-            for (int r = 0; r < 6; ++r)
-#pragma unroll
-                for (int cc = 0; cc < 6; ++cc) {
-                    double h = 0.0;
-#pragma unroll
-                    for (int i = LOCAMD_J1_LO(r); i < LOCAMD_J1_HI(r); ++i) h += J1[i * 6 + r] * WJ[i * 6 + cc];
-                    Hoff[6 * cc + r] = h;
-                }
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int cc = 0; cc < 6; ++cc) {
-                double s1 = 0.0;
-#pragma unroll
-                for (int j = LOCAMD_J1_LO(cc); j < LOCAMD_J1_HI(cc); ++j) s1 += Om[i * 6 + j] * J1[j * 6 + cc];
-                WJ[i * 6 + cc] = w * s1;
-            }
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int cc = 0; cc <= r; ++cc) {
-                double h = 0.0;
-#pragma unroll
-                for (int i = LOCAMD_J1_LO(r); i < LOCAMD_J1_HI(r); ++i) h += J1[i * 6 + r] * WJ[i * 6 + cc];
-                Hjj[r * (r + 1) / 2 + cc] = h;
-            }
-        if (!j_is_later) {
-#pragma unroll
-            for (int r = 0; r < 6; ++r)
-#pragma unroll
-                for (int cc = 0; cc < 6; ++cc) {
-                    double h = 0.0;
-#pragma unroll
-                    for (int i = 0; i < LOCAMD_J0_HI(r); ++i) h += J0[i * 6 + r] * WJ[i * 6 + cc];
-                    Hoff[6 * cc + r] = h;
-                }
-        }
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            double bi = 0.0, bj = 0.0;
-#pragma unroll
-            for (int i = 0; i < LOCAMD_J0_HI(r); ++i) bi += J0[i * 6 + r] * (-w * Oe[i]);
-#pragma unroll
-            for (int i = LOCAMD_J1_LO(r); i < LOCAMD_J1_HI(r); ++i) bj += J1[i * 6 + r] * (-w * Oe[i]);
-            bi_[r] = bi;
-            bj_[r] = bj;
-        }
-#undef LOCAMD_J1_LO
-#undef LOCAMD_J1_HI
-#undef LOCAMD_J0_HI
-    }
-    return chi;
-}
-
-// one sweep over the window's edges in pose order: chi sums always; FULL: H and b as well (returns the largest diagonal entry)
-template <bool FULL, int JAC, bool SE3>
-__device__ __forceinline__ void chain_sweep(const WindowArgs& a, double* slab, long long inst, int nv, int nr, int np, int ns, int buf,
-                                            double& robust_chi, double& plain_chi, double& max_diag, unsigned long long& ho_kind, int& shared_edges) {
-    using namespace chainw;
-#define CH(p, f, k) slab[((size_t)(p) * N + (f) + (k)) * 64]
-    const WindowCaps& c = a.caps;
-    (void)inst;
-    // the window's edges, copied into the workspace once per launch ([entry][lane]: one line per load of the wave)
-    const size_t eoff = (size_t)c.nv_max * N, poff = eoff + (size_t)c.nr_max * 7, soff = poff + (size_t)c.np_max * 19;
-#define CE(e, k) slab[(eoff + (size_t)(e) * 7 + (k)) * 64]
-#define CP(e, k) slab[(poff + (size_t)(e) * 19 + (k)) * 64]
-#define CS(e, k) slab[(soff + (size_t)(e) * 51 + (k)) * 64]
-    (void)soff; (void)ns;
-    int es = 0;   // (SE3 edges between consecutive poses — the reference's addTwistEdge —, sorted by their later pose like the ranges)
-    double rsum = 0.0, csum = 0.0, md = 0.0;
-    double Dp[27], Dc[27], O[36], Xp[12], Xc[12];
-#pragma unroll
-    for (int k = 0; k < 27; ++k) { Dp[k] = 0.0; Dc[k] = 0.0; }
-#pragma unroll
-    for (int k = 0; k < 12; ++k) { Xp[k] = 0.0; Xc[k] = 0.0; }
-    // The coupling block H_p,p-1 of a pair of poses joined by ONE range edge (the reference's smoothness edge) is the rank-1
-    // matrix (w J_p) J_{p-1}^T: it is stored as those two vectors (12 doubles instead of 36 — the block is read twice per LM
-    // trial, a quarter of all the bytes a trial moved).  ho_kind: two bits per pose (0 no coupling, 1 rank-1, 2 full block;
-    // poses from 32 on always store the full block).
-    unsigned long long kinds = 0;
-    int nbin = 0, nshared = 0;   // nshared: pose-to-pose edges that share their pair of poses with another edge (result[6]; an EdgeSE3 counts as one edge)
-    int nedges_pair = 0;
-    double fu[6], fv[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { fu[k] = 0.0; fv[k] = 0.0; }
-    int e = 0, q = 0;
-    // (the next edge and the next pose are requested one step ahead: nothing else hides a memory round trip here)
-    double ne[7], nX[12], npv = 0.0;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) ne[k] = nr > 0 ? CE(0, k) : 0.0;
-    if (np > 0) npv = CP(0, 0);
-#pragma unroll
-    for (int k = 0; k < 12; ++k) nX[k] = nv > 0 ? CH(0, P + 12 * buf, k) : 0.0;
-    for (int p = 0; p < nv; ++p) {
-#pragma unroll
-        for (int k = 0; k < 12; ++k) Xc[k] = nX[k];
-        if (p + 1 < nv) {
-#pragma unroll
-            for (int k = 0; k < 12; ++k) nX[k] = CH(p + 1, P + 12 * buf, k);
-        }
-        if (FULL) {
-#pragma unroll
-            for (int k = 0; k < 27; ++k) Dc[k] = 0.0;
-#pragma unroll
-            for (int k = 0; k < 36; ++k) O[k] = 0.0;
-            nbin = 0;
-            nedges_pair = 0;
-        }
-        // range edges whose later pose is p
-        while (e < nr) {
-            const int v0 = (int)ne[0], v1 = (int)ne[1];
-            if ((v1 > v0 ? v1 : v0) != p) break;
-            const double meas = ne[2], info = ne[3];
-            const double off[3] = {ne[4], ne[5], ne[6]};
-            if (e + 1 < nr) {
-#pragma unroll
-                for (int k = 0; k < 7; ++k) ne[k] = CE(e + 1, k);
-            }
-            const bool first_is_cur = v0 == p;   // endpoint 0 (the lever arm) is pose p (else p - 1)
-            double X0[12], X1[12];
-#pragma unroll
-            for (int k = 0; k < 12; ++k) { X0[k] = first_is_cur ? Xc[k] : Xp[k]; X1[k] = first_is_cur ? Xp[k] : Xc[k]; }
-            double p0[3], p1[3];
-            mat_vec(X0, off, p0);
-            p0[0] += X0[9]; p0[1] += X0[10]; p0[2] += X0[11];
-            if (v1 >= 0) { p1[0] = X1[9]; p1[1] = X1[10]; p1[2] = X1[11]; }
-            else { const double* an = a.anchors + (size_t)(-1 - v1) * 3; p1[0] = an[0]; p1[1] = an[1]; p1[2] = an[2]; }
-            double u[3] = {p0[0] - p1[0], p0[1] - p1[1], p0[2] - p1[2]};
-            const double n = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
-            const double err = JAC == 0 ? meas - n : range_error_plain(X0, X0 + 9, off, p1, meas);
-            const double chi = err * (info * err);
-            const double aux = 1.0 + chi;
-            rsum += fast_log_ge1(aux);
-            csum += chi;
-            if (FULL) {
-                double J0[6], J1[3];
-                if (JAC == 0) {
-                    const double inv = n > 0.0 ? 1.0 / n : 0.0;
-                    u[0] *= inv; u[1] *= inv; u[2] *= inv;
-                    double uR[3];
-                    mat_tvec(X0, u, uR);
-                    J0[0] = -uR[0]; J0[1] = -uR[1]; J0[2] = -uR[2];
-                    J0[3] = 2.0 * (uR[1] * off[2] - uR[2] * off[1]);
-                    J0[4] = 2.0 * (uR[2] * off[0] - uR[0] * off[2]);
-                    J0[5] = 2.0 * (uR[0] * off[1] - uR[1] * off[0]);
-                    if (v1 >= 0) mat_tvec(X1, u, J1); else { J1[0] = 0; J1[1] = 0; J1[2] = 0; }
-                } else {
-                    J0[0] = range_jac_numeric<0>(X0, off, X1, p1, 0, meas);
-                    J0[1] = range_jac_numeric<1>(X0, off, X1, p1, 0, meas);
-                    J0[2] = range_jac_numeric<2>(X0, off, X1, p1, 0, meas);
-                    J0[3] = range_jac_numeric<3>(X0, off, X1, p1, 0, meas);
-                    J0[4] = range_jac_numeric<4>(X0, off, X1, p1, 0, meas);
-                    J0[5] = range_jac_numeric<5>(X0, off, X1, p1, 0, meas);
-                    if (v1 >= 0) {
-                        J1[0] = range_jac_numeric<0>(X0, off, X1, p1, 1, meas);
-                        J1[1] = range_jac_numeric<1>(X0, off, X1, p1, 1, meas);
-                        J1[2] = range_jac_numeric<2>(X0, off, X1, p1, 1, meas);
-                    } else { J1[0] = 0; J1[1] = 0; J1[2] = 0; }
-                }
-                const double wr = info / aux, wre = -wr * err;
-                // endpoint 0's block and b: into pose p (Dc) or pose p - 1 (Dp)
-#pragma unroll
-                for (int r = 0; r < 6; ++r) {
-#pragma unroll
-                    for (int cc = 0; cc <= r; ++cc) {
-                        const double h = wr * J0[r] * J0[cc];
-                        Dc[r * (r + 1) / 2 + cc] += first_is_cur ? h : 0.0;
-                        Dp[r * (r + 1) / 2 + cc] += first_is_cur ? 0.0 : h;
-                    }
-                    const double bb = J0[r] * wre;
-                    Dc[21 + r] += first_is_cur ? bb : 0.0;
-                    Dp[21 + r] += first_is_cur ? 0.0 : bb;
-                }
-                if (v1 >= 0) {
-                    // endpoint 1 (translation part only): into the OTHER pose; off-diagonal block rows = pose p, columns = p - 1
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-#pragma unroll
-                        for (int cc = 0; cc <= r; ++cc) {
-                            const double h = wr * J1[r] * J1[cc];
-                            Dc[r * (r + 1) / 2 + cc] += first_is_cur ? 0.0 : h;
-                            Dp[r * (r + 1) / 2 + cc] += first_is_cur ? h : 0.0;
-                        }
-                        const double bb = J1[r] * wre;
-                        Dc[21 + r] += first_is_cur ? 0.0 : bb;
-                        Dp[21 + r] += first_is_cur ? bb : 0.0;
-                    }
-                    // J of pose p (rows) x J of pose p - 1 (columns); J1 has three entries
-                    double jr[6], jc[6];
-#pragma unroll
-                    for (int r = 0; r < 6; ++r) {
-                        jr[r] = first_is_cur ? J0[r] : (r < 3 ? J1[r] : 0.0);
-                        jc[r] = first_is_cur ? (r < 3 ? J1[r] : 0.0) : J0[r];
-                    }
-                    if (nbin == 0 && p < 32) {
-#pragma unroll
-                        for (int r = 0; r < 6; ++r) { fu[r] = wr * jr[r]; fv[r] = jc[r]; }
-                    } else {
-                        if (nbin == 1 && p < 32) {   // a second edge on the pair: expand the first
-#pragma unroll
-                            for (int r = 0; r < 6; ++r)
-#pragma unroll
-                                for (int cc = 0; cc < 6; ++cc) O[6 * cc + r] = fu[r] * fv[cc];
-                        }
-#pragma unroll
-                        for (int r = 0; r < 6; ++r)
-#pragma unroll
-                            for (int cc = 0; cc < 6; ++cc) O[6 * cc + r] += wr * jr[r] * jc[cc];
-                    }
-                    ++nbin;
-                    ++nedges_pair;
-                }
-            }
-            ++e;
-        }
-        if (SE3) {
-            while (es < ns) {
-                const int vi = (int)CS(es, 0), vj = (int)CS(es, 1);
-                if ((vj > vi ? vj : vi) != p) break;
-                const bool robust = CS(es, 2) != 0.0, i_is_cur = vi == p;
-                double val[48], Xi[12], Xj[12];
-#pragma unroll
-                for (int k = 0; k < 48; ++k) val[k] = CS(es, 3 + k);
-#pragma unroll
-                for (int k = 0; k < 12; ++k) { Xi[k] = i_is_cur ? Xc[k] : Xp[k]; Xj[k] = i_is_cur ? Xp[k] : Xc[k]; }
-                double Hii[21], Hjj[21], Hoff[36], bi[6], bj[6], rterm;
-                const double chi = chain_se3_terms<FULL>(Xi, Xj, val, robust, !i_is_cur, Hii, Hjj, Hoff, bi, bj, rterm);
-                rsum += rterm;
-                csum += chi;
-                if (FULL) {
-#pragma unroll
-                    for (int k = 0; k < 21; ++k) {
-                        Dc[k] += i_is_cur ? Hii[k] : Hjj[k];
-                        Dp[k] += i_is_cur ? Hjj[k] : Hii[k];
-                    }
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) {
-                        Dc[21 + k] += i_is_cur ? bi[k] : bj[k];
-                        Dp[21 + k] += i_is_cur ? bj[k] : bi[k];
-                    }
-                    if (nbin == 1 && p < 32) {   // a range edge on the pair is waiting as two vectors: expand it
-#pragma unroll
-                        for (int r = 0; r < 6; ++r)
-#pragma unroll
-                            for (int cc = 0; cc < 6; ++cc) O[6 * cc + r] = fu[r] * fv[cc];
-                    }
-#pragma unroll
-                    for (int k = 0; k < 36; ++k) O[k] += Hoff[k];
-                    nbin += 2;   // (an SE3 coupling is never rank-1: the block is stored in full)
-                    ++nedges_pair;
-                }
-                ++es;
-            }
-        }
-        // unary priors on pose p
-        while (q < np && (int)npv == p) {
-            double Zi[12], Wd[6];
-#pragma unroll
-            for (int k = 0; k < 12; ++k) Zi[k] = CP(q, 1 + k);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) Wd[k] = CP(q, 13 + k);
-            double RE[9], tE[3], qq[4];
-            mat_mul(Zi, Xc, RE);
-            mat_vec(Zi, Xc + 9, tE);
-            tE[0] += Zi[9]; tE[1] += Zi[10]; tE[2] += Zi[11];
-            mat_to_quat(RE, qq);
-            quat_normalize_sign(qq);
-            const double err[6] = {tE[0], tE[1], tE[2], qq[1], qq[2], qq[3]};
-            double chi = 0.0;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) chi += err[i] * (Wd[i] * err[i]);
-            rsum += chi;
-            csum += chi;
-            if (FULL) {
-                double J[36];
-#pragma unroll
-                for (int i = 0; i < 36; ++i) J[i] = 0.0;
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) J[i * 6 + j] = RE[i * 3 + j];
-                quat_right_jac(qq, 1.0, J, 6);
-#pragma unroll
-                for (int r = 0; r < 6; ++r) {
-#pragma unroll
-                    for (int cc = 0; cc <= r; ++cc) {
-                        double h = 0.0;
-                        if ((r < 3) == (cc < 3)) {
-#pragma unroll
-                            for (int i = (r < 3 ? 0 : 3); i < (r < 3 ? 3 : 6); ++i) h += J[i * 6 + r] * Wd[i] * J[i * 6 + cc];
-                        }
-                        Dc[r * (r + 1) / 2 + cc] += h;
-                    }
-                    double bb = 0.0;
-#pragma unroll
-                    for (int i = (r < 3 ? 0 : 3); i < (r < 3 ? 3 : 6); ++i) bb += J[i * 6 + r] * (-Wd[i] * err[i]);
-                    Dc[21 + r] += bb;
-                }
-            }
-            ++q;
-            if (q < np) npv = CP(q, 0);
-        }
-        if (FULL) {
-            if (p > 0) {
-#pragma unroll
-                for (int k = 0; k < 21; ++k) CH(p - 1, HD, k) = Dp[k];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) CH(p - 1, HB, k) = Dp[21 + k];
-#pragma unroll
-                for (int r = 0; r < 6; ++r) md = fmax(md, fabs(Dp[r * (r + 1) / 2 + r]));
-                if (nbin == 1 && p < 32) {
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) { CH(p, HO, k) = fu[k]; CH(p, HO, 6 + k) = fv[k]; }
-                    kinds |= 1ull << (2 * p);
-                } else if (nbin >= 1 || p >= 32) {   // (poses from 32 on are always read as full blocks: zeros when uncoupled)
-#pragma unroll
-                    for (int k = 0; k < 36; ++k) CH(p, HO, k) = O[k];
-                    if (p < 32) kinds |= 2ull << (2 * p);
-                }
-                nshared += nedges_pair >= 2 ? nedges_pair : 0;
-            }
-#pragma unroll
-            for (int k = 0; k < 27; ++k) Dp[k] = Dc[k];
-        }
-#pragma unroll
-        for (int k = 0; k < 12; ++k) Xp[k] = Xc[k];
-    }
-    if (FULL && nv > 0) {
-#pragma unroll
-        for (int k = 0; k < 21; ++k) CH(nv - 1, HD, k) = Dp[k];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) CH(nv - 1, HB, k) = Dp[21 + k];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) md = fmax(md, fabs(Dp[r * (r + 1) / 2 + r]));
-    }
-    robust_chi = rsum; plain_chi = csum; max_diag = md;
-    if (FULL) { ho_kind = kinds; shared_edges = nshared; }
-#undef CE
-#undef CP
-#undef CS
-}
-
-// pose p of the trial state: X (+) dx, read from pose buffer `buf`, written to the other one (accepting a step flips the
-// window's buffer, rejecting it costs nothing); returns the pose's share of g2o's computeScale sum
-__device__ __forceinline__ double chain_apply_step(double* slab, int p, int buf, const double* dx, double lambda) {
-    using namespace chainw;
-    double Xo[12], sc = 0.0;
-#pragma unroll
-    for (int k = 0; k < 12; ++k) Xo[k] = CH(p, P + 12 * buf, k);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) sc += dx[k] * (lambda * dx[k] + CH(p, HB, k));
-    double Rd[9];
-    const double ww = 1.0 - (dx[3] * dx[3] + dx[4] * dx[4] + dx[5] * dx[5]);
-    if (ww < 0) { Rd[0] = 1; Rd[1] = 0; Rd[2] = 0; Rd[3] = 0; Rd[4] = 1; Rd[5] = 0; Rd[6] = 0; Rd[7] = 0; Rd[8] = 1; }
-    else { const double qd[4] = {sqrt(ww), dx[3], dx[4], dx[5]}; quat_to_mat(qd, Rd); }
-    double Rn[9], tn[3];
-    mat_mul(Xo, Rd, Rn);
-    mat_vec(Xo, dx, tn);
-    const int ob = P + 12 * (1 - buf);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) CH(p, ob, k) = Rn[k];
-    CH(p, ob, 9) = Xo[9] + tn[0]; CH(p, ob, 10) = Xo[10] + tn[1]; CH(p, ob, 11) = Xo[11] + tn[2];
-    return sc;
-}
-
-// (H + lambda I) x = b for a block-tridiagonal H: forward sweep (Cholesky + forward substitution), then the back-substitution
-// with the step applied pose by pose as its x comes out.  x is only written when every pivot was positive and finite (g2o
-// leaves its x alone when the factorisation fails, and LM applies that stale x all the same).
-__device__ __forceinline__ bool chain_factor_solve(double* slab, int nv, double lambda, int buf, unsigned long long ho_kind, double& scale_sum) {
-    using namespace chainw;
-    scale_sum = 0.0;
-    // kind of pose p's coupling block (chain_sweep): 0 none, 1 rank-1 (12 doubles), 2 full (36)
-    auto kind_of = [&](int p) { return p < 32 ? (int)((ho_kind >> (2 * p)) & 3ull) : (p > 0 ? 2 : 0); };
-    bool ok = true;
-    double Gp[6][6], igp[6], yp[6];   // the previous pose's factor (strict lower), inverse pivots, y
-#pragma unroll
-    for (int r = 0; r < 6; ++r) { igp[r] = 0.0; yp[r] = 0.0;
-#pragma unroll
-        for (int cc = 0; cc < 6; ++cc) Gp[r][cc] = 0.0; }
-    // (the next pose's H is requested before the current pose is worked on: one wave per SIMD has nobody else to hide the
-    //  memory round trip behind)
-    double nHd[21], nHb[6], nHo[36];
-#pragma unroll
-    for (int k = 0; k < 21; ++k) nHd[k] = nv > 0 ? CH(0, HD, k) : 0.0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) nHb[k] = nv > 0 ? CH(0, HB, k) : 0.0;
-#pragma unroll
-    for (int k = 0; k < 36; ++k) nHo[k] = 0.0;
-    for (int p = 0; p < nv; ++p) {
-        double A[6][6], rhs[6], Ho[36];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-#pragma unroll
-            for (int cc = 0; cc <= r; ++cc) A[r][cc] = nHd[r * (r + 1) / 2 + cc];
-            A[r][r] += lambda;
-            rhs[r] = nHb[r];
-        }
-#pragma unroll
-        for (int k = 0; k < 36; ++k) Ho[k] = nHo[k];
-        const int kd = kind_of(p);
-        if (kd == 1) {   // rank-1: u v^T
-#pragma unroll
-            for (int r = 0; r < 6; ++r)
-#pragma unroll
-                for (int cc = 0; cc < 6; ++cc) Ho[6 * cc + r] = nHo[r] * nHo[6 + cc];
-        }
-        if (p + 1 < nv) {
-#pragma unroll
-            for (int k = 0; k < 21; ++k) nHd[k] = CH(p + 1, HD, k);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) nHb[k] = CH(p + 1, HB, k);
-            const int kn = kind_of(p + 1);
-            if (kn == 1) {
-#pragma unroll
-                for (int k = 0; k < 12; ++k) nHo[k] = CH(p + 1, HO, k);
-            } else if (kn == 2) {
-#pragma unroll
-                for (int k = 0; k < 36; ++k) nHo[k] = CH(p + 1, HO, k);
-            }
-        }
-        if (kd != 0) {
-            // row by row: w = row r of W = H_p,p-1 G_{p-1}^-T; S -= w w^T; rhs_r -= w . y_{p-1}
-            double Wm[36];   // W, entry (r, c) at 6 c + r
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                double w[6];
-#pragma unroll
-                for (int cc = 0; cc < 6; ++cc) w[cc] = Ho[6 * cc + r];
-#pragma unroll
-                for (int cc = 0; cc < 6; ++cc) {
-                    w[cc] *= igp[cc];
-#pragma unroll
-                    for (int c2 = cc + 1; c2 < 6; ++c2) w[c2] = __builtin_fma(-w[cc], Gp[c2][cc], w[c2]);
-                }
-#pragma unroll
-                for (int cc = 0; cc < 6; ++cc) Wm[6 * cc + r] = w[cc];   // (not stored: the back-substitution re-forms W^T x from H_p,p-1 and G)
-                double acc = rhs[r];
-#pragma unroll
-                for (int cc = 0; cc < 6; ++cc) acc = __builtin_fma(-w[cc], yp[cc], acc);
-                rhs[r] = acc;
-            }
-            // S -= W W^T (lower triangle)
-#pragma unroll
-            for (int r = 0; r < 6; ++r)
-#pragma unroll
-                for (int c2 = 0; c2 <= r; ++c2) {
-                    double s2 = A[r][c2];
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) s2 = __builtin_fma(-Wm[6 * k + r], Wm[6 * k + c2], s2);
-                    A[r][c2] = s2;
-                }
-        }
-        double ig[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const double g = pivot_rsqrt(A[j][j]);
-            ig[j] = g;
-#pragma unroll
-            for (int i2 = j + 1; i2 < 6; ++i2) A[i2][j] *= g;
-#pragma unroll
-            for (int i2 = j + 1; i2 < 6; ++i2)
-#pragma unroll
-                for (int cc = j + 1; cc <= i2; ++cc) A[i2][cc] = __builtin_fma(-A[i2][j], A[cc][j], A[i2][cc]);
-        }
-        ok = ok && (((ig[0] + ig[1]) + (ig[2] + ig[3])) + (ig[4] + ig[5]) < DBL_MAX);
-#pragma unroll
-        for (int cc = 0; cc < 6; ++cc) {
-            rhs[cc] *= ig[cc];
-#pragma unroll
-            for (int c2 = cc + 1; c2 < 6; ++c2) rhs[c2] = __builtin_fma(-rhs[cc], A[c2][cc], rhs[c2]);
-        }
-        {
-            int k = 0;
-#pragma unroll
-            for (int cc = 0; cc < 5; ++cc)
-#pragma unroll
-                for (int r = cc + 1; r < 6; ++r) { CH(p, G, k) = A[r][cc]; ++k; }
-        }
-#pragma unroll
-        for (int r = 0; r < 6; ++r) { CH(p, G, 15 + r) = ig[r]; CH(p, Y, r) = rhs[r]; igp[r] = ig[r]; yp[r] = rhs[r]; }
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int cc = 0; cc < 6; ++cc) Gp[r][cc] = cc < r ? A[r][cc] : 0.0;
-    }
-    if (!ok) {
-        for (int p = 0; p < nv; ++p) {
-            double dx[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) dx[k] = CH(p, X, k);
-            scale_sum += chain_apply_step(slab, p, buf, dx, lambda);
-        }
-        return false;
-    }
-    double xn[6];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) xn[r] = 0.0;
-    // x_p = G_p^-T (y_p - W_{p+1}^T x_{p+1}) with W_{p+1}^T x = G_p^-1 (H_{p+1,p}^T x): W itself is never stored (it was a fifth of the
-    // bytes a trial moved)
-    double nG[21], nY[6], nW[36];   // (requested one pose ahead, as in the forward sweep; nW: H_{p+1,p})
-#pragma unroll
-    for (int k = 0; k < 21; ++k) nG[k] = CH(nv - 1, G, k);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) nY[k] = CH(nv - 1, Y, k);
-#pragma unroll
-    for (int k = 0; k < 36; ++k) nW[k] = 0.0;
-    for (int p = nv - 1; p >= 0; --p) {
-        double t[6], Gl[6][6], ig[6], Wn[36];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) { t[r] = nY[r]; ig[r] = nG[15 + r]; }
-        {
-            int k = 0;
-#pragma unroll
-            for (int cc = 0; cc < 5; ++cc)
-#pragma unroll
-                for (int r = cc + 1; r < 6; ++r) { Gl[r][cc] = nG[k]; ++k; }
-        }
-#pragma unroll
-        for (int k = 0; k < 36; ++k) Wn[k] = nW[k];   // W of pose p + 1
-        if (p > 0) {
-#pragma unroll
-            for (int k = 0; k < 21; ++k) nG[k] = CH(p - 1, G, k);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) nY[k] = CH(p - 1, Y, k);
-        }
-        const int kup = p < nv - 1 ? kind_of(p + 1) : 0;   // kind of the block that couples pose p + 1 to this one (held in Wn)
-        {
-            const int kme = kind_of(p);   // (pose p's coupling block is what pose p - 1 needs next)
-            if (kme == 1) {
-#pragma unroll
-                for (int k = 0; k < 12; ++k) nW[k] = CH(p, HO, k);
-            } else if (kme == 2) {
-#pragma unroll
-                for (int k = 0; k < 36; ++k) nW[k] = CH(p, HO, k);
-            }
-        }
-        if (kup != 0) {
-            double v[6];
-            if (kup == 1) {   // (u v^T)^T x = v (u . x)
-                double sx = 0.0;
-#pragma unroll
-                for (int r = 0; r < 6; ++r) sx = __builtin_fma(Wn[r], xn[r], sx);
-#pragma unroll
-                for (int cc = 0; cc < 6; ++cc) v[cc] = Wn[6 + cc] * sx;
-            } else {
-#pragma unroll
-                for (int cc = 0; cc < 6; ++cc) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int r = 0; r < 6; ++r) acc = __builtin_fma(Wn[6 * cc + r], xn[r], acc);
-                    v[cc] = acc;
-                }
-            }
-            // z = G_p^-1 v (forward substitution), t -= z
-#pragma unroll
-            for (int cc = 0; cc < 6; ++cc) {
-                v[cc] *= ig[cc];
-#pragma unroll
-                for (int c2 = cc + 1; c2 < 6; ++c2) v[c2] = __builtin_fma(-v[cc], Gl[c2][cc], v[c2]);
-                t[cc] -= v[cc];
-            }
-        }
-#pragma unroll
-        for (int rr = 5; rr >= 0; --rr) {
-            xn[rr] = t[rr] * ig[rr];
-#pragma unroll
-            for (int q2 = 0; q2 < rr; ++q2) t[q2] = __builtin_fma(-Gl[rr][q2], xn[rr], t[q2]);
-        }
-#pragma unroll
-        for (int r = 0; r < 6; ++r) CH(p, X, r) = xn[r];
-        scale_sum += chain_apply_step(slab, p, buf, xn, lambda);
-    }
-    return true;
-}
-
-template <int JAC, bool SE3>
-__global__ void __launch_bounds__(64, 1) chain_lm_kernel(const WindowArgs a, double* ws) {
-    using namespace chainw;
-    const int lane = threadIdx.x;
-    const long long inst = (long long)blockIdx.x * 64 + lane;
-    const bool live = inst < a.B;
-    const WindowCaps& c = a.caps;
-    double* slab = ws + (size_t)blockIdx.x * 64 * chain_window_doubles(c) + lane;
-    int nv = 0, nr = 0, np = 0, ns = 0;
-    if (live) { nv = a.counts[inst * 4 + 0]; nr = a.counts[inst * 4 + 1]; np = a.counts[inst * 4 + 2]; ns = SE3 ? a.counts[inst * 4 + 3] : 0; }
-    const double* gin = a.poses_in + (size_t)(live ? inst : 0) * c.nv_max * 12;
-    double* gout = a.poses + (size_t)(live ? inst : 0) * c.nv_max * 12;
-    for (int p = 0; p < nv; ++p) {
-#pragma unroll
-        for (int k = 0; k < 12; ++k) CH(p, P, k) = gin[p * 12 + k];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) CH(p, X, k) = 0.0;   // the solver's x of a fresh optimize() call
-    }
-    {
-        const size_t eoff = (size_t)c.nv_max * N, poff = eoff + (size_t)c.nr_max * 7;
-        const int32_t* ridx = a.r_idx + (size_t)(live ? inst : 0) * c.nr_max * 2;
-        const double* rval = a.r_val + (size_t)(live ? inst : 0) * c.nr_max * 5;
-        for (int e = 0; e < nr; ++e) {
-            slab[(eoff + (size_t)e * 7 + 0) * 64] = (double)ridx[2 * e];
-            slab[(eoff + (size_t)e * 7 + 1) * 64] = (double)ridx[2 * e + 1];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) slab[(eoff + (size_t)e * 7 + 2 + k) * 64] = rval[5 * e + k];
-        }
-        const int32_t* pidx = a.p_idx + (size_t)(live ? inst : 0) * c.np_max;
-        const double* pval = a.p_val + (size_t)(live ? inst : 0) * c.np_max * 18;
-        for (int e = 0; e < np; ++e) {
-            slab[(poff + (size_t)e * 19) * 64] = (double)pidx[e];
-#pragma unroll
-            for (int k = 0; k < 18; ++k) slab[(poff + (size_t)e * 19 + 1 + k) * 64] = pval[18 * e + k];
-        }
-        if (SE3) {
-            const size_t soff = poff + (size_t)c.np_max * 19;
-            const int32_t* sidx = a.s_idx + (size_t)(live ? inst : 0) * c.ns_max * 4;
-            const double* sval = a.s_val + (size_t)(live ? inst : 0) * c.ns_max * 48;
-            for (int e = 0; e < ns; ++e) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) slab[(soff + (size_t)e * 51 + k) * 64] = (double)sidx[4 * e + k];
-                for (int k = 0; k < 48; ++k) slab[(soff + (size_t)e * 51 + 3 + k) * 64] = sval[48 * e + k];
-            }
-        }
-    }
-    constexpr double tau = 1e-5, good_lo = 1.0 / 3.0, good_hi = 2.0 / 3.0;
-    constexpr int max_trials = 10;
-    double lambda = 0.0, ni = 2.0, cur_chi = 0.0, last_plain = 0.0;
-    int it = 0, q = 0, trials = 0, terminated = 0, buf = 0, shared_edges = 0;
-    unsigned long long ho_kind = 0;
-    bool need_lin = true;
-    bool done = !live || nv <= 0 || nr + np + ns <= 0 || a.iterations <= 0;
-    while (__ballot(!done)) {
-        if (!done) {
-            if (need_lin) {
-                double plain, md;
-                chain_sweep<true, JAC, SE3>(a, slab, inst, nv, nr, np, ns, buf, cur_chi, plain, md, ho_kind, shared_edges);
-                last_plain = plain;
-                if (it == 0) { lambda = tau * md; ni = 2.0; }
-                q = 0;
-                need_lin = false;
-            }
-            // solve and apply the step (the trial state goes to the other pose buffer)
-            double sc;
-            const bool ok2 = chain_factor_solve(slab, nv, lambda, buf, ho_kind, sc);
-            ++trials;
-            double temp_chi, plain2, md2;
-            unsigned long long unused_kind;
-            int unused_shared;
-            chain_sweep<false, JAC, SE3>(a, slab, inst, nv, nr, np, ns, 1 - buf, temp_chi, plain2, md2, unused_kind, unused_shared);
-            last_plain = plain2;
-            if (!ok2) temp_chi = DBL_MAX;
-            const double scale = sc + 1e-3;
-            const double rho = (cur_chi - temp_chi) / scale;
-            bool iteration_over;
-            if (rho > 0.0 && fabs(temp_chi) <= DBL_MAX) {
-                const double r21 = 2.0 * rho - 1.0;
-                double alpha = 1.0 - r21 * r21 * r21;
-                alpha = fmin(alpha, good_hi);
-                lambda *= fmax(good_lo, alpha);
-                ni = 2.0;
-                cur_chi = temp_chi;
-                buf = 1 - buf;   // the trial state is the state
-                ++q;
-                iteration_over = true;
-            } else {
-                lambda *= ni;
-                ni *= 2.0;      // (pop: the state was never overwritten)
-                ++q;
-                iteration_over = !(rho < 0.0 && q < max_trials);
-            }
-            if (iteration_over) {
-                ++it;
-                need_lin = true;
-                if (q == max_trials || rho == 0.0) { terminated = 1; done = true; }
-                if (it >= a.iterations) done = true;
-            }
-        }
-    }
-    if (live) {
-        for (int p = 0; p < nv; ++p) {
-#pragma unroll
-            for (int k = 0; k < 12; ++k) gout[p * 12 + k] = CH(p, P + 12 * buf, k);
-        }
-        double* res = a.result + (size_t)inst * 8;
-        res[0] = last_plain; res[1] = cur_chi; res[2] = lambda; res[3] = (double)it; res[4] = (double)trials;
-        res[5] = (double)terminated; res[6] = (double)shared_edges; res[7] = nv > 0 ? (double)(nv * 65536 + 2 * nv - 1) : 0.0;
-    }
-#undef CH
-}
-
-}  // namespace
-
-hipError_t launch_window_chain(const WindowArgs& a, double* chain_ws, hipStream_t stream) {
-    if (a.B <= 0 || !chain_ws) return hipErrorInvalidValue;
-    const unsigned blocks = (unsigned)((a.B + 63) / 64);
-    // (the variant with EdgeSE3 factors between consecutive poses is a separate instantiation: the range-only windows keep their
-    //  register budget)
-    if (a.caps.ns_max > 0) {
-        if (a.jacobian) hipLaunchKernelGGL((chain_lm_kernel<1, true>), dim3(blocks), dim3(64), 0, stream, a, chain_ws);
-        else hipLaunchKernelGGL((chain_lm_kernel<0, true>), dim3(blocks), dim3(64), 0, stream, a, chain_ws);
-    } else {
-        if (a.jacobian) hipLaunchKernelGGL((chain_lm_kernel<1, false>), dim3(blocks), dim3(64), 0, stream, a, chain_ws);
-        else hipLaunchKernelGGL((chain_lm_kernel<0, false>), dim3(blocks), dim3(64), 0, stream, a, chain_ws);
-    }
-    return hipGetLastError();
-}
-
-
-// =====================================================================================================================
-// TREE windows of ONE shared topology, one LANE per window (BASELINE config 5: the key-frame star of addPoseEdge,
-// localization.cpp:254-290 — every pose hangs on an older key pose by an EdgeSE3 — plus one anchor range per pose).
-//
-// A window whose pose-to-pose edges form a FOREST factors without fill when the leaves go first; when every window of the
-// batch has the SAME structure (same counts and index tables: the batch is one graph replayed with different measurements),
-// that order and the whole elimination schedule are computed ONCE on the host (capi_window.cpp: build_tree_sched) and every
-// lane of a wave walks it in lock-step on its own window — chain_lm_kernel's scheme with "the previous pose" replaced by
-// "the parent": no per-window ordering / symbolic work, no structure tables in LDS, no divergence, and the state in an
-// [entry][lane] HBM workspace (every load / store of the wave is one 512-byte line) instead of per-instance workspaces read
-// 8 bytes per cache line (window_lm_kernel moves 68 GB per 16 384 config-5 windows that way).
-// Per node: H_nn (21), H_parent,n (36), b (6), G (15 + 6 inverse pivots), y, x, two pose buffers, and a spill slot for the
-// sums a node collects from its children (27) — which stay in REGISTERS as long as consecutive nodes of the schedule share
-// their parent (the host orders the children of a node heavy subtree first, leaves last: for config 5's caterpillar — eight
-// keys in a row, seven leaves each — the spill slot is never touched).
-namespace treew {
-constexpr int HD = 0, HO = 21, HB = 57, G = 63, Y = 84, X = 90, P = 96, ACC = 120, N = 147;
-}
-__host__ __device__ inline size_t tree_window_doubles(const WindowCaps& c) {
-    return (size_t)c.nv_max * treew::N + (size_t)c.nr_max * 5 + (size_t)c.np_max * 18 + (size_t)c.ns_max * 48;
-}
-size_t window_tree_workspace_doubles(const WindowCaps& c, long long B) { return (size_t)((B + 63) / 64) * 64 * tree_window_doubles(c); }
-
-namespace {
-
-#define TH(p, f, k) slab[((size_t)(p) * treew::N + (f) + (k)) * 64]
-// wave-uniform schedule entries as scalars
-__device__ __forceinline__ int sload(const int32_t* p) { return __builtin_amdgcn_readfirstlane(*p); }
-
-// the sums a node collects from its children (27 doubles: 21 + 6): kept in registers while consecutive nodes share their parent
-struct AccCache {
-    double v[27];
-    int owner;                  // position (in the schedule) of the node the registers belong to, -1: none
-    unsigned long long spilled; // nodes (by position) whose sums sit in their ACC slot
-};
-__device__ __forceinline__ void acc_init(AccCache& c) {
-#pragma unroll
-    for (int k = 0; k < 27; ++k) c.v[k] = 0.0;
-    c.owner = -1; c.spilled = 0;
-}
-// make `pos` (pose slot `slot`) the owner of the registers
-__device__ __forceinline__ void acc_switch(AccCache& c, double* slab, const TreeSched& ts, int pos, int slot) {
-    if (c.owner == pos) return;
-    if (c.owner >= 0) {
-        const int os = sload(ts.node + c.owner);
-#pragma unroll
-        for (int k = 0; k < 27; ++k) TH(os, treew::ACC, k) = c.v[k];
-        c.spilled |= 1ull << c.owner;
-    }
-    if ((c.spilled >> pos) & 1ull) {
-#pragma unroll
-        for (int k = 0; k < 27; ++k) c.v[k] = TH(slot, treew::ACC, k);
-        c.spilled &= ~(1ull << pos);
-    } else {
-#pragma unroll
-        for (int k = 0; k < 27; ++k) c.v[k] = 0.0;
-    }
-    c.owner = pos;
-}
-// take the sums collected for node `pos` (zeros if none) and release the registers
-__device__ __forceinline__ void acc_take(AccCache& c, double* slab, int pos, int slot, double* out) {
-    if (c.owner == pos) {
-#pragma unroll
-        for (int k = 0; k < 27; ++k) out[k] = c.v[k];
-        c.owner = -1;
-    } else if ((c.spilled >> pos) & 1ull) {
-#pragma unroll
-        for (int k = 0; k < 27; ++k) out[k] = TH(slot, treew::ACC, k);
-        c.spilled &= ~(1ull << pos);
-    } else {
-#pragma unroll
-        for (int k = 0; k < 27; ++k) out[k] = 0.0;
-    }
-}
-
-// one sweep over the nodes in elimination order: chi sums always; FULL: H, b and the coupling blocks as well
-template <bool FULL, int JAC>
-__device__ __forceinline__ void tree_sweep(const WindowArgs& a, const TreeSched& ts, double* slab, int nv, int buf,
-                                           double& robust_chi, double& plain_chi, double& max_diag, int& shared_edges) {
-    using namespace treew;
-    const WindowCaps& c = a.caps;
-    const size_t eoff = (size_t)c.nv_max * N, poff = eoff + (size_t)c.nr_max * 5, soff = poff + (size_t)c.np_max * 18;
-#define TE(e, k) slab[(eoff + (size_t)(e) * 5 + (k)) * 64]
-#define TP(e, k) slab[(poff + (size_t)(e) * 18 + (k)) * 64]
-#define TS(e, k) slab[(soff + (size_t)(e) * 48 + (k)) * 64]
-    double rsum = 0.0, csum = 0.0, md = 0.0;
-    int nshared = 0;
-    AccCache lacc;
-    acc_init(lacc);
-    int pown = -1;
-    double Xpar[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) Xpar[k] = 0.0;
-    for (int kpos = 0; kpos < nv; ++kpos) {
-        const int n = sload(ts.node + kpos), ppos = sload(ts.par + kpos);
-        const int pn = ppos >= 0 ? sload(ts.node + ppos) : -1;
-        double Xc[12];
-#pragma unroll
-        for (int k = 0; k < 12; ++k) Xc[k] = TH(n, P + 12 * buf, k);
-        if (ppos >= 0 && pown != ppos) {
-#pragma unroll
-            for (int k = 0; k < 12; ++k) Xpar[k] = TH(pn, P + 12 * buf, k);
-            pown = ppos;
-        }
-        double D[27], Dp[27], O[36];   // own block + b; the parent's share; coupling (rows: parent, columns: this node)
-        if (FULL) {
-#pragma unroll
-            for (int k = 0; k < 27; ++k) { D[k] = 0.0; Dp[k] = 0.0; }
-#pragma unroll
-            for (int k = 0; k < 36; ++k) O[k] = 0.0;
-        }
-        int nbin = 0;
-        // range edges attached to this node: to anchors (unary) or to the parent
-        const int r0 = sload(ts.r_off + kpos), r1 = sload(ts.r_off + kpos + 1);
-        for (int ri = r0; ri < r1; ++ri) {
-            const int e = sload(ts.r_list + ri);
-            const int v0 = sload(ts.r_idx + 2 * e), v1 = sload(ts.r_idx + 2 * e + 1);
-            const double meas = TE(ri, 0), info = TE(ri, 1);
-            const double off[3] = {TE(ri, 2), TE(ri, 3), TE(ri, 4)};
-            const bool first_is_cur = v0 == n;   // endpoint 0 (the lever arm) is this node (else the parent)
-            double X0[12], X1[12];
-#pragma unroll
-            for (int k = 0; k < 12; ++k) { X0[k] = first_is_cur ? Xc[k] : Xpar[k]; X1[k] = first_is_cur ? Xpar[k] : Xc[k]; }
-            double p0[3], p1[3];
-            mat_vec(X0, off, p0);
-            p0[0] += X0[9]; p0[1] += X0[10]; p0[2] += X0[11];
-            if (v1 >= 0) { p1[0] = X1[9]; p1[1] = X1[10]; p1[2] = X1[11]; }
-            else { const double* an = a.anchors + (size_t)(-1 - v1) * 3; p1[0] = an[0]; p1[1] = an[1]; p1[2] = an[2]; }
-            double u[3] = {p0[0] - p1[0], p0[1] - p1[1], p0[2] - p1[2]};
-            const double nn = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
-            const double err = JAC == 0 ? meas - nn : range_error_plain(X0, X0 + 9, off, p1, meas);
-            const double chi = err * (info * err);
-            const double aux = 1.0 + chi;
-            rsum += fast_log_ge1(aux);
-            csum += chi;
-            if (FULL) {
-                double J0[6], J1[3];
-                if (JAC == 0) {
-                    const double inv = nn > 0.0 ? 1.0 / nn : 0.0;
-                    u[0] *= inv; u[1] *= inv; u[2] *= inv;
-                    double uR[3];
-                    mat_tvec(X0, u, uR);
-                    J0[0] = -uR[0]; J0[1] = -uR[1]; J0[2] = -uR[2];
-                    J0[3] = 2.0 * (uR[1] * off[2] - uR[2] * off[1]);
-                    J0[4] = 2.0 * (uR[2] * off[0] - uR[0] * off[2]);
-                    J0[5] = 2.0 * (uR[0] * off[1] - uR[1] * off[0]);
-                    if (v1 >= 0) mat_tvec(X1, u, J1); else { J1[0] = 0; J1[1] = 0; J1[2] = 0; }
-                } else {
-                    J0[0] = range_jac_numeric<0>(X0, off, X1, p1, 0, meas);
-                    J0[1] = range_jac_numeric<1>(X0, off, X1, p1, 0, meas);
-                    J0[2] = range_jac_numeric<2>(X0, off, X1, p1, 0, meas);
-                    J0[3] = range_jac_numeric<3>(X0, off, X1, p1, 0, meas);
-                    J0[4] = range_jac_numeric<4>(X0, off, X1, p1, 0, meas);
-                    J0[5] = range_jac_numeric<5>(X0, off, X1, p1, 0, meas);
-                    if (v1 >= 0) {
-                        J1[0] = range_jac_numeric<0>(X0, off, X1, p1, 1, meas);
-                        J1[1] = range_jac_numeric<1>(X0, off, X1, p1, 1, meas);
-                        J1[2] = range_jac_numeric<2>(X0, off, X1, p1, 1, meas);
-                    } else { J1[0] = 0; J1[1] = 0; J1[2] = 0; }
-                }
-                const double wr = info / aux, wre = -wr * err;
-#pragma unroll
-                for (int r = 0; r < 6; ++r) {
-#pragma unroll
-                    for (int cc = 0; cc <= r; ++cc) {
-                        const double h = wr * J0[r] * J0[cc];
-                        D[r * (r + 1) / 2 + cc] += first_is_cur ? h : 0.0;
-                        Dp[r * (r + 1) / 2 + cc] += first_is_cur ? 0.0 : h;
-                    }
-                    const double bb = J0[r] * wre;
-                    D[21 + r] += first_is_cur ? bb : 0.0;
-                    Dp[21 + r] += first_is_cur ? 0.0 : bb;
-                }
-                if (v1 >= 0) {
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-#pragma unroll
-                        for (int cc = 0; cc <= r; ++cc) {
-                            const double h = wr * J1[r] * J1[cc];
-                            D[r * (r + 1) / 2 + cc] += first_is_cur ? 0.0 : h;
-                            Dp[r * (r + 1) / 2 + cc] += first_is_cur ? h : 0.0;
-                        }
-                        const double bb = J1[r] * wre;
-                        D[21 + r] += first_is_cur ? 0.0 : bb;
-                        Dp[21 + r] += first_is_cur ? bb : 0.0;
-                    }
-                    // rows: the parent's J, columns: this node's
-                    double jr[6], jc[6];
-#pragma unroll
-                    for (int r = 0; r < 6; ++r) {
-                        jr[r] = first_is_cur ? (r < 3 ? J1[r] : 0.0) : J0[r];
-                        jc[r] = first_is_cur ? J0[r] : (r < 3 ? J1[r] : 0.0);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 6; ++r)
-#pragma unroll
-                        for (int cc = 0; cc < 6; ++cc) O[6 * cc + r] += wr * jr[r] * jc[cc];
-                    ++nbin;
-                }
-            }
-        }
-        // EdgeSE3 factors between this node and its parent
-        const int s0 = sload(ts.s_off + kpos), s1 = sload(ts.s_off + kpos + 1);
-        for (int si = s0; si < s1; ++si) {
-            const int e = sload(ts.s_list + si);
-            const int vi = sload(ts.s_idx + 4 * e);
-            const bool robust = sload(ts.s_idx + 4 * e + 2) != 0, i_is_cur = vi == n;
-            double val[48], Xi[12], Xj[12];
-#pragma unroll
-            for (int k = 0; k < 48; ++k) val[k] = TS(si, k);
-#pragma unroll
-            for (int k = 0; k < 12; ++k) { Xi[k] = i_is_cur ? Xc[k] : Xpar[k]; Xj[k] = i_is_cur ? Xpar[k] : Xc[k]; }
-            double Hii[21], Hjj[21], Hoff[36], bi[6], bj[6], rterm;
-            // (the "later" pose of the pair = the parent: its rows)
-            const double chi = chain_se3_terms<FULL>(Xi, Xj, val, robust, i_is_cur, Hii, Hjj, Hoff, bi, bj, rterm);
-            rsum += rterm;
-            csum += chi;
-            if (FULL) {
-#pragma unroll
-                for (int k = 0; k < 21; ++k) { D[k] += i_is_cur ? Hii[k] : Hjj[k]; Dp[k] += i_is_cur ? Hjj[k] : Hii[k]; }
-#pragma unroll
-                for (int k = 0; k < 6; ++k) { D[21 + k] += i_is_cur ? bi[k] : bj[k]; Dp[21 + k] += i_is_cur ? bj[k] : bi[k]; }
-#pragma unroll
-                for (int k = 0; k < 36; ++k) O[k] += Hoff[k];
-                ++nbin;
-            }
-        }
-        // unary priors on this node
-        const int q0 = sload(ts.p_off + kpos), q1 = sload(ts.p_off + kpos + 1);
-        for (int qi = q0; qi < q1; ++qi) {
-            double Zi[12], Wd[6];
-#pragma unroll
-            for (int k = 0; k < 12; ++k) Zi[k] = TP(qi, k);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) Wd[k] = TP(qi, 12 + k);
-            double RE[9], tE[3], qq[4];
-            mat_mul(Zi, Xc, RE);
-            mat_vec(Zi, Xc + 9, tE);
-            tE[0] += Zi[9]; tE[1] += Zi[10]; tE[2] += Zi[11];
-            mat_to_quat(RE, qq);
-            quat_normalize_sign(qq);
-            const double err[6] = {tE[0], tE[1], tE[2], qq[1], qq[2], qq[3]};
-            double chi = 0.0;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) chi += err[i] * (Wd[i] * err[i]);
-            rsum += chi;
-            csum += chi;
-            if (FULL) {
-                double J[36];
-#pragma unroll
-                for (int i = 0; i < 36; ++i) J[i] = 0.0;
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) J[i * 6 + j] = RE[i * 3 + j];
-                quat_right_jac(qq, 1.0, J, 6);
-#pragma unroll
-                for (int r = 0; r < 6; ++r) {
-#pragma unroll
-                    for (int cc = 0; cc <= r; ++cc) {
-                        double h = 0.0;
-                        if ((r < 3) == (cc < 3)) {
-#pragma unroll
-                            for (int i = (r < 3 ? 0 : 3); i < (r < 3 ? 3 : 6); ++i) h += J[i * 6 + r] * Wd[i] * J[i * 6 + cc];
-                        }
-                        D[r * (r + 1) / 2 + cc] += h;
-                    }
-                    double bb = 0.0;
-#pragma unroll
-                    for (int i = (r < 3 ? 0 : 3); i < (r < 3 ? 3 : 6); ++i) bb += J[i * 6 + r] * (-Wd[i] * err[i]);
-                    D[21 + r] += bb;
-                }
-            }
-        }
-        if (FULL) {
-            double fromkids[27];
-            acc_take(lacc, slab, kpos, n, fromkids);
-#pragma unroll
-            for (int k = 0; k < 27; ++k) D[k] += fromkids[k];
-#pragma unroll
-            for (int k = 0; k < 21; ++k) TH(n, HD, k) = D[k];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) TH(n, HB, k) = D[21 + k];
-#pragma unroll
-            for (int r = 0; r < 6; ++r) md = fmax(md, fabs(D[r * (r + 1) / 2 + r]));
-            if (ppos >= 0) {
-#pragma unroll
-                for (int k = 0; k < 36; ++k) TH(n, HO, k) = O[k];
-                acc_switch(lacc, slab, ts, ppos, pn);
-#pragma unroll
-                for (int k = 0; k < 27; ++k) lacc.v[k] += Dp[k];
-                nshared += nbin >= 2 ? nbin : 0;
-            }
-        }
-    }
-    robust_chi = rsum; plain_chi = csum; max_diag = md;
-    if (FULL) shared_edges = nshared;
-}
-
-// pose `n` of the trial state: X (+) dx, read from pose buffer `buf`, written to the other one
-__device__ __forceinline__ double tree_apply_step(double* slab, int n, int buf, const double* dx, double lambda) {
-    using namespace treew;
-    double Xo[12], sc = 0.0;
-#pragma unroll
-    for (int k = 0; k < 12; ++k) Xo[k] = TH(n, P + 12 * buf, k);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) sc += dx[k] * (lambda * dx[k] + TH(n, HB, k));
-    double Rd[9];
-    const double ww = 1.0 - (dx[3] * dx[3] + dx[4] * dx[4] + dx[5] * dx[5]);
-    if (ww < 0) { Rd[0] = 1; Rd[1] = 0; Rd[2] = 0; Rd[3] = 0; Rd[4] = 1; Rd[5] = 0; Rd[6] = 0; Rd[7] = 0; Rd[8] = 1; }
-    else { const double qd[4] = {sqrt(ww), dx[3], dx[4], dx[5]}; quat_to_mat(qd, Rd); }
-    double Rn[9], tn[3];
-    mat_mul(Xo, Rd, Rn);
-    mat_vec(Xo, dx, tn);
-    const int ob = P + 12 * (1 - buf);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) TH(n, ob, k) = Rn[k];
-    TH(n, ob, 9) = Xo[9] + tn[0]; TH(n, ob, 10) = Xo[10] + tn[1]; TH(n, ob, 11) = Xo[11] + tn[2];
-    return sc;
-}
-
-// (H + lambda I) x = b over the forest: leaves first (Cholesky + forward substitution, a node's Schur update handed to its
-// parent), then roots first (back-substitution, the step applied node by node).  x is only written when every pivot was positive
-// and finite.
-__device__ __forceinline__ bool tree_factor_solve(const TreeSched& ts, double* slab, int nv, double lambda, int buf, double& scale_sum) {
-    using namespace treew;
-    scale_sum = 0.0;
-    bool ok = true;
-    AccCache acc;
-    acc_init(acc);
-    for (int kpos = 0; kpos < nv; ++kpos) {
-        const int n = sload(ts.node + kpos), ppos = sload(ts.par + kpos);
-        double A[6][6], rhs[6], kids[27];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-#pragma unroll
-            for (int cc = 0; cc <= r; ++cc) A[r][cc] = TH(n, HD, r * (r + 1) / 2 + cc);
-            A[r][r] += lambda;
-            rhs[r] = TH(n, HB, r);
-        }
-        double Ho[36];
-        if (ppos >= 0) {
-#pragma unroll
-            for (int k = 0; k < 36; ++k) Ho[k] = TH(n, HO, k);
-        }
-        acc_take(acc, slab, kpos, n, kids);
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-#pragma unroll
-            for (int cc = 0; cc <= r; ++cc) A[r][cc] -= kids[r * (r + 1) / 2 + cc];
-            rhs[r] -= kids[21 + r];
-        }
-        double ig[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const double g = pivot_rsqrt(A[j][j]);
-            ig[j] = g;
-#pragma unroll
-            for (int i2 = j + 1; i2 < 6; ++i2) A[i2][j] *= g;
-#pragma unroll
-            for (int i2 = j + 1; i2 < 6; ++i2)
-#pragma unroll
-                for (int cc = j + 1; cc <= i2; ++cc) A[i2][cc] = __builtin_fma(-A[i2][j], A[cc][j], A[i2][cc]);
-        }
-        ok = ok && (((ig[0] + ig[1]) + (ig[2] + ig[3])) + (ig[4] + ig[5]) < DBL_MAX);
-#pragma unroll
-        for (int cc = 0; cc < 6; ++cc) {
-            rhs[cc] *= ig[cc];
-#pragma unroll
-            for (int c2 = cc + 1; c2 < 6; ++c2) rhs[c2] = __builtin_fma(-rhs[cc], A[c2][cc], rhs[c2]);
-        }
-        {
-            int k = 0;
-#pragma unroll
-            for (int cc = 0; cc < 5; ++cc)
-#pragma unroll
-                for (int r = cc + 1; r < 6; ++r) { TH(n, G, k) = A[r][cc]; ++k; }
-        }
-#pragma unroll
-        for (int r = 0; r < 6; ++r) { TH(n, G, 15 + r) = ig[r]; TH(n, Y, r) = rhs[r]; }
-        if (ppos >= 0) {
-            // W = H_parent,n G_n^-T (rows: the parent's); its Schur update W W^T, W y goes to the parent
-            double Wm[36];   // entry (r, c) at 6 c + r
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                double w[6];
-#pragma unroll
-                for (int cc = 0; cc < 6; ++cc) w[cc] = Ho[6 * cc + r];
-#pragma unroll
-                for (int cc = 0; cc < 6; ++cc) {
-                    w[cc] *= ig[cc];
-#pragma unroll
-                    for (int c2 = cc + 1; c2 < 6; ++c2) w[c2] = __builtin_fma(-w[cc], A[c2][cc], w[c2]);
-                }
-#pragma unroll
-                for (int cc = 0; cc < 6; ++cc) Wm[6 * cc + r] = w[cc];
-            }
-            acc_switch(acc, slab, ts, ppos, sload(ts.node + ppos));
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-#pragma unroll
-                for (int c2 = 0; c2 <= r; ++c2) {
-                    double s2 = acc.v[r * (r + 1) / 2 + c2];
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) s2 = __builtin_fma(Wm[6 * k + r], Wm[6 * k + c2], s2);
-                    acc.v[r * (r + 1) / 2 + c2] = s2;
-                }
-                double s3 = acc.v[21 + r];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) s3 = __builtin_fma(Wm[6 * k + r], rhs[k], s3);
-                acc.v[21 + r] = s3;
-            }
-        }
-    }
-    if (!ok) {
-        for (int kpos = 0; kpos < nv; ++kpos) {
-            const int n = sload(ts.node + kpos);
-            double dx[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) dx[k] = TH(n, X, k);
-            scale_sum += tree_apply_step(slab, n, buf, dx, lambda);
-        }
-        return false;
-    }
-    // roots first: x_n = G_n^-T (y_n - W_n^T x_parent), W_n^T x = G_n^-1 (H_parent,n^T x)
-    int xown = -1;
-    double xpar[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) xpar[k] = 0.0;
-    for (int kpos = nv - 1; kpos >= 0; --kpos) {
-        const int n = sload(ts.node + kpos), ppos = sload(ts.par + kpos);
-        double t[6], Gl[6][6], ig[6];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) { t[r] = TH(n, Y, r); ig[r] = TH(n, G, 15 + r); }
-        {
-            int k = 0;
-#pragma unroll
-            for (int cc = 0; cc < 5; ++cc)
-#pragma unroll
-                for (int r = cc + 1; r < 6; ++r) { Gl[r][cc] = TH(n, G, k); ++k; }
-        }
-        if (ppos >= 0) {
-            if (xown != ppos) {
-                const int pn = sload(ts.node + ppos);
-#pragma unroll
-                for (int k = 0; k < 6; ++k) xpar[k] = TH(pn, X, k);
-                xown = ppos;
-            }
-            double v[6];
-#pragma unroll
-            for (int cc = 0; cc < 6; ++cc) {
-                double a2 = 0.0;
-#pragma unroll
-                for (int r = 0; r < 6; ++r) a2 = __builtin_fma(TH(n, HO, 6 * cc + r), xpar[r], a2);
-                v[cc] = a2;
-            }
-#pragma unroll
-            for (int cc = 0; cc < 6; ++cc) {
-                v[cc] *= ig[cc];
-#pragma unroll
-                for (int c2 = cc + 1; c2 < 6; ++c2) v[c2] = __builtin_fma(-v[cc], Gl[c2][cc], v[c2]);
-                t[cc] -= v[cc];
-            }
-        }
-        double xn[6];
-#pragma unroll
-        for (int rr = 5; rr >= 0; --rr) {
-            xn[rr] = t[rr] * ig[rr];
-#pragma unroll
-            for (int q2 = 0; q2 < rr; ++q2) t[q2] = __builtin_fma(-Gl[rr][q2], xn[rr], t[q2]);
-        }
-#pragma unroll
-        for (int r = 0; r < 6; ++r) TH(n, X, r) = xn[r];
-        scale_sum += tree_apply_step(slab, n, buf, xn, lambda);
-    }
-    return true;
-}
-
-template <int JAC>
-__global__ void __launch_bounds__(64, 1) tree_lm_kernel(const WindowArgs a, const TreeSched ts, double* ws) {
-    using namespace treew;
-    const int lane = threadIdx.x;
-    const long long inst = (long long)blockIdx.x * 64 + lane;
-    const bool live = inst < a.B;
-    const WindowCaps& c = a.caps;
-    double* slab = ws + (size_t)blockIdx.x * 64 * tree_window_doubles(c) + lane;
-    const int nv = ts.nv, nr = ts.nr, np = ts.np, ns = ts.ns;   // (one topology for the whole batch)
-    const size_t src = (size_t)(live ? inst : 0);               // (lanes past the batch replay window 0: their results are discarded)
-    const double* gin = a.poses_in + src * c.nv_max * 12;
-    double* gout = a.poses + src * c.nv_max * 12;
-    for (int p = 0; p < nv; ++p) {
-#pragma unroll
-        for (int k = 0; k < 12; ++k) TH(p, P, k) = gin[p * 12 + k];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) TH(p, X, k) = 0.0;
-    }
-    {
-        const size_t eoff = (size_t)c.nv_max * N, poff = eoff + (size_t)c.nr_max * 5, soff = poff + (size_t)c.np_max * 18;
-        const double* rval = a.r_val + src * c.nr_max * 5;
-        for (int i = 0; i < nr; ++i) {   // in the order the schedule walks them
-            const int e = sload(ts.r_list + i);
-#pragma unroll
-            for (int k = 0; k < 5; ++k) slab[(eoff + (size_t)i * 5 + k) * 64] = rval[5 * e + k];
-        }
-        const double* pval = a.p_val + src * c.np_max * 18;
-        for (int i = 0; i < np; ++i) {
-            const int e = sload(ts.p_list + i);
-#pragma unroll
-            for (int k = 0; k < 18; ++k) slab[(poff + (size_t)i * 18 + k) * 64] = pval[18 * e + k];
-        }
-        const double* sval = a.s_val + src * c.ns_max * 48;
-        for (int i = 0; i < ns; ++i) {
-            const int e = sload(ts.s_list + i);
-            for (int k = 0; k < 48; ++k) slab[(soff + (size_t)i * 48 + k) * 64] = sval[48 * e + k];
-        }
-    }
-    constexpr double tau = 1e-5, good_lo = 1.0 / 3.0, good_hi = 2.0 / 3.0;
-    constexpr int max_trials = 10;
-    double lambda = 0.0, ni = 2.0, cur_chi = 0.0, last_plain = 0.0;
-    int it = 0, q = 0, trials = 0, terminated = 0, buf = 0, shared_edges = 0;
-    bool need_lin = true;
-    bool done = nv <= 0 || nr + np + ns <= 0 || a.iterations <= 0;
-    while (__ballot(!done)) {
-        if (!done) {
-            if (need_lin) {
-                double plain, md;
-                tree_sweep<true, JAC>(a, ts, slab, nv, buf, cur_chi, plain, md, shared_edges);
-                last_plain = plain;
-                if (it == 0) { lambda = tau * md; ni = 2.0; }
-                q = 0;
-                need_lin = false;
-            }
-            double sc;
-            const bool ok2 = tree_factor_solve(ts, slab, nv, lambda, buf, sc);
-            ++trials;
-            double temp_chi, plain2, md2;
-            int unused_shared;
-            tree_sweep<false, JAC>(a, ts, slab, nv, 1 - buf, temp_chi, plain2, md2, unused_shared);
-            last_plain = plain2;
-            if (!ok2) temp_chi = DBL_MAX;
-            const double scale = sc + 1e-3;
-            const double rho = (cur_chi - temp_chi) / scale;
-            bool iteration_over;
-            if (rho > 0.0 && fabs(temp_chi) <= DBL_MAX) {
-                const double r21 = 2.0 * rho - 1.0;
-                double alpha = 1.0 - r21 * r21 * r21;
-                alpha = fmin(alpha, good_hi);
-                lambda *= fmax(good_lo, alpha);
-                ni = 2.0;
-                cur_chi = temp_chi;
-                buf = 1 - buf;
-                ++q;
-                iteration_over = true;
-            } else {
-                lambda *= ni;
-                ni *= 2.0;
-                ++q;
-                iteration_over = !(rho < 0.0 && q < max_trials);
-            }
-            if (iteration_over) {
-                ++it;
-                need_lin = true;
-                if (q == max_trials || rho == 0.0) { terminated = 1; done = true; }
-                if (it >= a.iterations) done = true;
-            }
-        }
-    }
-    if (live) {
-        for (int p = 0; p < nv; ++p) {
-#pragma unroll
-            for (int k = 0; k < 12; ++k) gout[p * 12 + k] = TH(p, P + 12 * buf, k);
-        }
-        double* res = a.result + (size_t)inst * 8;
-        res[0] = last_plain; res[1] = cur_chi; res[2] = lambda; res[3] = (double)it; res[4] = (double)trials;
-        res[5] = (double)terminated; res[6] = (double)shared_edges; res[7] = nv > 0 ? (double)(ts.depth * 65536 + 2 * nv - ts.nroots) : 0.0;
-    }
-}
-#undef TH
-#undef TE
-#undef TP
-#undef TS
-
-}  // namespace
-
-hipError_t launch_window_tree(const WindowArgs& a, const TreeSched& ts, double* ws, hipStream_t stream) {
-    if (a.B <= 0 || !ws || ts.nv <= 0 || ts.nv > 64) return hipErrorInvalidValue;
-    const unsigned blocks = (unsigned)((a.B + 63) / 64);
-    if (a.jacobian) hipLaunchKernelGGL((tree_lm_kernel<1>), dim3(blocks), dim3(64), 0, stream, a, ts, ws);
-    else hipLaunchKernelGGL((tree_lm_kernel<0>), dim3(blocks), dim3(64), 0, stream, a, ts, ws);
-    return hipGetLastError();
-}
-
-
-// =====================================================================================================================
-// The same batches (forest windows of ONE shared topology, <= 64 poses), one WAVE per window with LANE = POSE and the whole
-// solver state of a pose in that lane's REGISTERS: tree_wave_kernel.
-//
-// tree_lm_kernel above walks a window's 64 nodes one after the other in one lane: a wave's instruction stream is 64 nodes long
-// per sweep whatever the batch, so 16 384 windows are 256 waves — a quarter of the chip's SIMDs, each bound by its own instruction
-// issue (an EdgeSE3 linearisation is ~1 200 instructions).  Here the 64 nodes of a window are the 64 lanes of a wave:
-//   * linearisation and trial scoring: every lane evaluates ITS node's edges (anchor ranges, priors, and the edges to its parent)
-//     at once — one edge's worth of instructions per sweep instead of 64;
-//   * elimination by HEIGHT: all leaves factor their 6x6 block together, then the nodes whose children are done, ... — config 5's
-//     caterpillar is 9 steps (56 leaves at once, then the eight keys) instead of 64; a node hands its Schur update (27 numbers) to
-//     its parent through LDS, the parent sums its children's in list order (fixed order: bit-reproducible); back-substitution the
-//     other way round, x handed down through LDS;
-//   * H_nn, the coupling block with the parent, b, the factor, y, x and both poses of a node (~130 doubles) never leave the lane's
-//     registers: NO workspace in memory at all — a window's poses and measurements are read once per sweep, the poses written once.
-// The schedule (parent, height, children and edge lists per pose slot) is the host's, shared by every window (scalar / cached loads).
-namespace {
-
-struct LaneNode { int par, height, k0, k1, r0, r1, q0, q1, s0, s1; };
-
-// every edge of this lane's node at pose X (the parent's from LDS): chi sums; FULL: own block + b (D), the parent's share (Dp), coupling O
-template <bool FULL, int JAC>
-__device__ __forceinline__ void wave_node_edges(const WindowArgs& a, const TreeSched& ts, long long inst, int lane, const LaneNode& nd,
-                                                const double* Xc, const double* Xpar, double& rsum, double& csum, double* D, double* Dp, double* O, int& nbin) {
-    const WindowCaps& c = a.caps;
-    if (FULL) {
-#pragma unroll
-        for (int k = 0; k < 27; ++k) { D[k] = 0.0; Dp[k] = 0.0; }
-#pragma unroll
-        for (int k = 0; k < 36; ++k) O[k] = 0.0;
-    }
-    nbin = 0;
-    // The EdgeSE3 factor to the parent FIRST (at most one per node here: the host sends batches with more to tree_lm_kernel): it
-    // writes its blocks straight into D / Dp / O — the 78 doubles of H_ii, H_jj and the coupling block next to the Jacobians would
-    // spill, and so would a second inlined copy of the linearisation
-    if (nd.s0 < nd.s1) {
-        const int e = ts.w_slist[nd.s0];
-        const int vi = ts.s_idx[4 * e];
-        const bool robust = ts.s_idx[4 * e + 2] != 0, i_is_cur = vi == lane;
-        const double* val = a.s_val + ((size_t)inst * c.ns_max + e) * 48;   // (read in place)
-        double rterm, chi;
-        if (FULL) {
-            double Hii[21], Hjj[21], bi[6], bj[6];
-            double Xi[12], Xj[12];
-#pragma unroll
-            for (int k = 0; k < 12; ++k) { Xi[k] = i_is_cur ? Xc[k] : Xpar[k]; Xj[k] = i_is_cur ? Xpar[k] : Xc[k]; }
-            chi = chain_se3_terms<FULL>(Xi, Xj, val, robust, i_is_cur, Hii, Hjj, O, bi, bj, rterm);
-#pragma unroll
-            for (int k = 0; k < 21; ++k) { D[k] = i_is_cur ? Hii[k] : Hjj[k]; Dp[k] = i_is_cur ? Hjj[k] : Hii[k]; }
-#pragma unroll
-            for (int k = 0; k < 6; ++k) { D[21 + k] = i_is_cur ? bi[k] : bj[k]; Dp[21 + k] = i_is_cur ? bj[k] : bi[k]; }
-            ++nbin;
-        } else {
-            double Xi[12], Xj[12];
-#pragma unroll
-            for (int k = 0; k < 12; ++k) { Xi[k] = i_is_cur ? Xc[k] : Xpar[k]; Xj[k] = i_is_cur ? Xpar[k] : Xc[k]; }
-            chi = chain_se3_terms<FULL>(Xi, Xj, val, robust, i_is_cur, nullptr, nullptr, nullptr, nullptr, nullptr, rterm);
-        }
-        rsum += rterm;
-        csum += chi;
-    }
-    for (int ri = nd.r0; ri < nd.r1; ++ri) {
-        const int e = ts.w_rlist[ri];
-        const int v0 = ts.r_idx[2 * e], v1 = ts.r_idx[2 * e + 1];
-        const double* val = a.r_val + ((size_t)inst * c.nr_max + e) * 5;
-        const double meas = val[0], info = val[1];
-        const double off[3] = {val[2], val[3], val[4]};
-        const bool first_is_cur = v0 == lane;
-        double X0[12], X1[12];
-#pragma unroll
-        for (int k = 0; k < 12; ++k) { X0[k] = first_is_cur ? Xc[k] : Xpar[k]; X1[k] = first_is_cur ? Xpar[k] : Xc[k]; }
-        double p0[3], p1[3];
-        mat_vec(X0, off, p0);
-        p0[0] += X0[9]; p0[1] += X0[10]; p0[2] += X0[11];
-        if (v1 >= 0) { p1[0] = X1[9]; p1[1] = X1[10]; p1[2] = X1[11]; }
-        else { const double* an = a.anchors + (size_t)(-1 - v1) * 3; p1[0] = an[0]; p1[1] = an[1]; p1[2] = an[2]; }
-        double u[3] = {p0[0] - p1[0], p0[1] - p1[1], p0[2] - p1[2]};
-        const double nn = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
-        const double err = JAC == 0 ? meas - nn : range_error_plain(X0, X0 + 9, off, p1, meas);
-        const double chi = err * (info * err);
-        const double aux = 1.0 + chi;
-        rsum += fast_log_ge1(aux);
-        csum += chi;
-        if (FULL) {
-            double J0[6], J1[3];
-            if (JAC == 0) {
-                const double inv = nn > 0.0 ? 1.0 / nn : 0.0;
-                u[0] *= inv; u[1] *= inv; u[2] *= inv;
-                double uR[3];
-                mat_tvec(X0, u, uR);
-                J0[0] = -uR[0]; J0[1] = -uR[1]; J0[2] = -uR[2];
-                J0[3] = 2.0 * (uR[1] * off[2] - uR[2] * off[1]);
-                J0[4] = 2.0 * (uR[2] * off[0] - uR[0] * off[2]);
-                J0[5] = 2.0 * (uR[0] * off[1] - uR[1] * off[0]);
-                if (v1 >= 0) mat_tvec(X1, u, J1); else { J1[0] = 0; J1[1] = 0; J1[2] = 0; }
-            } else {
-                J0[0] = range_jac_numeric<0>(X0, off, X1, p1, 0, meas);
-                J0[1] = range_jac_numeric<1>(X0, off, X1, p1, 0, meas);
-                J0[2] = range_jac_numeric<2>(X0, off, X1, p1, 0, meas);
-                J0[3] = range_jac_numeric<3>(X0, off, X1, p1, 0, meas);
-                J0[4] = range_jac_numeric<4>(X0, off, X1, p1, 0, meas);
-                J0[5] = range_jac_numeric<5>(X0, off, X1, p1, 0, meas);
-                if (v1 >= 0) {
-                    J1[0] = range_jac_numeric<0>(X0, off, X1, p1, 1, meas);
-                    J1[1] = range_jac_numeric<1>(X0, off, X1, p1, 1, meas);
-                    J1[2] = range_jac_numeric<2>(X0, off, X1, p1, 1, meas);
-                } else { J1[0] = 0; J1[1] = 0; J1[2] = 0; }
-            }
-            const double wr = info / aux, wre = -wr * err;
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-#pragma unroll
-                for (int cc = 0; cc <= r; ++cc) {
-                    const double h = wr * J0[r] * J0[cc];
-                    D[r * (r + 1) / 2 + cc] += first_is_cur ? h : 0.0;
-                    Dp[r * (r + 1) / 2 + cc] += first_is_cur ? 0.0 : h;
-                }
-                const double bb = J0[r] * wre;
-                D[21 + r] += first_is_cur ? bb : 0.0;
-                Dp[21 + r] += first_is_cur ? 0.0 : bb;
-            }
-            if (v1 >= 0) {
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-#pragma unroll
-                    for (int cc = 0; cc <= r; ++cc) {
-                        const double h = wr * J1[r] * J1[cc];
-                        D[r * (r + 1) / 2 + cc] += first_is_cur ? 0.0 : h;
-                        Dp[r * (r + 1) / 2 + cc] += first_is_cur ? h : 0.0;
-                    }
-                    const double bb = J1[r] * wre;
-                    D[21 + r] += first_is_cur ? 0.0 : bb;
-                    Dp[21 + r] += first_is_cur ? bb : 0.0;
-                }
-                double jr[6], jc[6];   // rows: the parent's J, columns: this node's
-#pragma unroll
-                for (int r = 0; r < 6; ++r) {
-                    jr[r] = first_is_cur ? (r < 3 ? J1[r] : 0.0) : J0[r];
-                    jc[r] = first_is_cur ? J0[r] : (r < 3 ? J1[r] : 0.0);
-                }
-#pragma unroll
-                for (int r = 0; r < 6; ++r)
-#pragma unroll
-                    for (int cc = 0; cc < 6; ++cc) O[6 * cc + r] += wr * jr[r] * jc[cc];
-                ++nbin;
-            }
-        }
-    }
-    for (int qi = nd.q0; qi < nd.q1; ++qi) {
-        const int e = ts.w_plist[qi];
-        const double* pv = a.p_val + ((size_t)inst * c.np_max + e) * 18;
-        double Zi[12], Wd[6];
-#pragma unroll
-        for (int k = 0; k < 12; ++k) Zi[k] = pv[k];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) Wd[k] = pv[12 + k];
-        double RE[9], tE[3], qq[4];
-        mat_mul(Zi, Xc, RE);
-        mat_vec(Zi, Xc + 9, tE);
-        tE[0] += Zi[9]; tE[1] += Zi[10]; tE[2] += Zi[11];
-        mat_to_quat(RE, qq);
-        quat_normalize_sign(qq);
-        const double err[6] = {tE[0], tE[1], tE[2], qq[1], qq[2], qq[3]};
-        double chi = 0.0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) chi += err[i] * (Wd[i] * err[i]);
-        rsum += chi;
-        csum += chi;
-        if (FULL) {
-            double J[36];
-#pragma unroll
-            for (int i = 0; i < 36; ++i) J[i] = 0.0;
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) J[i * 6 + j] = RE[i * 3 + j];
-            quat_right_jac(qq, 1.0, J, 6);
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-#pragma unroll
-                for (int cc = 0; cc <= r; ++cc) {
-                    double h = 0.0;
-                    if ((r < 3) == (cc < 3)) {
-#pragma unroll
-                        for (int i = (r < 3 ? 0 : 3); i < (r < 3 ? 3 : 6); ++i) h += J[i * 6 + r] * Wd[i] * J[i * 6 + cc];
-                    }
-                    D[r * (r + 1) / 2 + cc] += h;
-                }
-                double bb = 0.0;
-#pragma unroll
-                for (int i = (r < 3 ? 0 : 3); i < (r < 3 ? 3 : 6); ++i) bb += J[i * 6 + r] * (-Wd[i] * err[i]);
-                D[21 + r] += bb;
-            }
-        }
-    }
-}
-
-template <int JAC>
-__global__ void __launch_bounds__(64, 1) tree_wave_kernel(const WindowArgs a, const TreeSched ts) {
-    __shared__ double dep[64 * 27];   // what a node hands to its parent (Schur update / linearisation share)
-    __shared__ double xp[64 * 12];    // poses, for the children to read their parent's
-    __shared__ double xx[64 * 6];     // x, handed down in the back-substitution
-    const int lane = threadIdx.x;
-    const long long inst = blockIdx.x;
-    const WindowCaps& c = a.caps;
-    const int nv = ts.nv;
-    const bool node = lane < nv;
-    LaneNode nd = {-1, -1, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (node) {
-        nd.par = ts.w_par[lane]; nd.height = ts.w_height[lane];
-        nd.k0 = ts.w_koff[lane]; nd.k1 = ts.w_koff[lane + 1];
-        nd.r0 = ts.w_roff[lane]; nd.r1 = ts.w_roff[lane + 1];
-        nd.q0 = ts.w_poff[lane]; nd.q1 = ts.w_poff[lane + 1];
-        nd.s0 = ts.w_soff[lane]; nd.s1 = ts.w_soff[lane + 1];
-    }
-    const int kleaf = node ? ts.w_kleaf[lane] : 0;
-    const double* gin = a.poses_in + ((size_t)inst * c.nv_max + (node ? lane : 0)) * 12;
-    double* gout = a.poses + ((size_t)inst * c.nv_max + (node ? lane : 0)) * 12;
-    double Xa[12], Xb[12];   // state / trial state
-#pragma unroll
-    for (int k = 0; k < 12; ++k) { Xa[k] = gin[k]; Xb[k] = Xa[k]; }
-    double HD[21], HB[6], HO[36], Gs[15], ig[6], y[6], x[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { x[k] = 0.0; y[k] = 0.0; ig[k] = 0.0; HB[k] = 0.0; }
-#pragma unroll
-    for (int k = 0; k < 21; ++k) HD[k] = 0.0;
-#pragma unroll
-    for (int k = 0; k < 36; ++k) HO[k] = 0.0;
-#pragma unroll
-    for (int k = 0; k < 15; ++k) Gs[k] = 0.0;
-    constexpr double tau = 1e-5, good_lo = 1.0 / 3.0, good_hi = 2.0 / 3.0;
-    constexpr int max_trials = 10;
-    double lambda = 0.0, ni = 2.0, cur_chi = 0.0, last_plain = 0.0;
-    int it = 0, trials = 0, terminated = 0, shared_edges = 0;
-    const bool active = nv > 0 && ts.nr + ts.np + ts.ns > 0 && a.iterations > 0;
-    auto wsync = [] {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    };
-    // pose X of every node -> LDS, the parent's back
-    auto parent_pose = [&](const double* X, double* Xpar) {
-        wsync();
-#pragma unroll
-        for (int k = 0; k < 12; ++k) xp[lane * 12 + k] = X[k];
-        wsync();
-#pragma unroll
-        for (int k = 0; k < 12; ++k) Xpar[k] = nd.par >= 0 ? xp[nd.par * 12 + k] : 0.0;
-    };
-    if (active) {
-        for (; it < a.iterations;) {
-            // ---- linearise at Xa: every lane its node's edges; the parent's shares go up through LDS ------------------------------
-            {
-                double Xpar[12], D[27], Dp[27], rs = 0.0, cs = 0.0;
-                int nbin;
-                parent_pose(Xa, Xpar);
-                if (node) wave_node_edges<true, JAC>(a, ts, inst, lane, nd, Xa, Xpar, rs, cs, D, Dp, HO, nbin);
-                else {
-#pragma unroll
-                    for (int k = 0; k < 27; ++k) { D[k] = 0.0; Dp[k] = 0.0; }
-                    nbin = 0;
-                }
-#pragma unroll
-                for (int k = 0; k < 27; ++k) dep[lane * 27 + k] = Dp[k];
-                wsync();
-                for (int ci = nd.k0; ci < nd.k1; ++ci) {
-                    const int ch = ts.w_klist[ci];
-#pragma unroll
-                    for (int k = 0; k < 27; ++k) D[k] += dep[ch * 27 + k];
-                }
-#pragma unroll
-                for (int k = 0; k < 21; ++k) HD[k] = D[k];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) HB[k] = D[21 + k];
-                double md = 0.0;
-#pragma unroll
-                for (int r = 0; r < 6; ++r) md = fmax(md, fabs(HD[r * (r + 1) / 2 + r]));
-                cur_chi = wave_sum(rs);
-                last_plain = wave_sum(cs);
-                if (it == 0) { lambda = tau * wave_max(node ? md : 0.0); ni = 2.0; shared_edges = (int)wave_sum(node && nbin >= 2 ? (double)nbin : 0.0); }
-                wsync();
-            }
-            int q = 0;
-            double rho = 0.0;
-            do {
-                // ---- (H + lambda I) x = b: leaves first, by height; a node's Schur update goes to its parent through LDS ----------------
-                bool ok = true;
-                for (int h = 0; h < ts.nlev; ++h) {
-                    if (h == 1) {
-                        // every node sums what its LEAF children handed up, all nodes at once (inside the level loop that sum would be
-                        // walked once per level by the whole wave: config 5's keys have seven leaves each); it waits in the node's own
-                        // slot of `dep`, which the node only overwrites when it hands its own update up
-                        if (node && nd.height >= 1) {
-                            double pre[27];
-#pragma unroll
-                            for (int k = 0; k < 27; ++k) pre[k] = 0.0;
-                            for (int ci = nd.k0; ci < nd.k0 + kleaf; ++ci) {
-                                const double* d = dep + ts.w_klist[ci] * 27;
-#pragma unroll
-                                for (int k = 0; k < 27; ++k) pre[k] += d[k];
-                            }
-                            wsync();
-#pragma unroll
-                            for (int k = 0; k < 27; ++k) dep[lane * 27 + k] = pre[k];
-                        } else {
-                            wsync();
-                        }
-                        wsync();
-                    }
-                    if (node && nd.height == h) {
-                        double A[6][6], rhs[6];
-#pragma unroll
-                        for (int r = 0; r < 6; ++r) {
-#pragma unroll
-                            for (int cc = 0; cc <= r; ++cc) A[r][cc] = HD[r * (r + 1) / 2 + cc];
-                            A[r][r] += lambda;
-                            rhs[r] = HB[r];
-                        }
-                        if (h >= 1) {
-                            const double* d = dep + lane * 27;
-#pragma unroll
-                            for (int r = 0; r < 6; ++r) {
-#pragma unroll
-                                for (int cc = 0; cc <= r; ++cc) A[r][cc] -= d[r * (r + 1) / 2 + cc];
-                                rhs[r] -= d[21 + r];
-                            }
-                        }
-                        for (int ci = nd.k0 + kleaf; ci < nd.k1; ++ci) {
-                            const double* d = dep + ts.w_klist[ci] * 27;
-#pragma unroll
-                            for (int r = 0; r < 6; ++r) {
-#pragma unroll
-                                for (int cc = 0; cc <= r; ++cc) A[r][cc] -= d[r * (r + 1) / 2 + cc];
-                                rhs[r] -= d[21 + r];
-                            }
-                        }
-#pragma unroll
-                        for (int j = 0; j < 6; ++j) {
-                            const double g = pivot_rsqrt(A[j][j]);
-                            ig[j] = g;
-#pragma unroll
-                            for (int i2 = j + 1; i2 < 6; ++i2) A[i2][j] *= g;
-#pragma unroll
-                            for (int i2 = j + 1; i2 < 6; ++i2)
-#pragma unroll
-                                for (int cc = j + 1; cc <= i2; ++cc) A[i2][cc] = __builtin_fma(-A[i2][j], A[cc][j], A[i2][cc]);
-                        }
-                        ok = (((ig[0] + ig[1]) + (ig[2] + ig[3])) + (ig[4] + ig[5]) < DBL_MAX);
-#pragma unroll
-                        for (int cc = 0; cc < 6; ++cc) {
-                            rhs[cc] *= ig[cc];
-#pragma unroll
-                            for (int c2 = cc + 1; c2 < 6; ++c2) rhs[c2] = __builtin_fma(-rhs[cc], A[c2][cc], rhs[c2]);
-                        }
-                        {
-                            int k = 0;
-#pragma unroll
-                            for (int cc = 0; cc < 5; ++cc)
-#pragma unroll
-                                for (int r = cc + 1; r < 6; ++r) { Gs[k] = A[r][cc]; ++k; }
-                        }
-#pragma unroll
-                        for (int r = 0; r < 6; ++r) y[r] = rhs[r];
-                        if (nd.par >= 0) {
-                            double Wm[36];   // W = H_parent,n G^-T, entry (r, c) at 6 c + r
-#pragma unroll
-                            for (int r = 0; r < 6; ++r) {
-                                double w[6];
-#pragma unroll
-                                for (int cc = 0; cc < 6; ++cc) w[cc] = HO[6 * cc + r];
-#pragma unroll
-                                for (int cc = 0; cc < 6; ++cc) {
-                                    w[cc] *= ig[cc];
-#pragma unroll
-                                    for (int c2 = cc + 1; c2 < 6; ++c2) w[c2] = __builtin_fma(-w[cc], A[c2][cc], w[c2]);
-                                }
-#pragma unroll
-                                for (int cc = 0; cc < 6; ++cc) Wm[6 * cc + r] = w[cc];
-                            }
-#pragma unroll
-                            for (int r = 0; r < 6; ++r) {
-#pragma unroll
-                                for (int c2 = 0; c2 <= r; ++c2) {
-                                    double s2 = 0.0;
-#pragma unroll
-                                    for (int k = 0; k < 6; ++k) s2 = __builtin_fma(Wm[6 * k + r], Wm[6 * k + c2], s2);
-                                    dep[lane * 27 + r * (r + 1) / 2 + c2] = s2;
-                                }
-                                double s3 = 0.0;
-#pragma unroll
-                                for (int k = 0; k < 6; ++k) s3 = __builtin_fma(Wm[6 * k + r], rhs[k], s3);
-                                dep[lane * 27 + 21 + r] = s3;
-                            }
-                        }
-                    }
-                    wsync();
-                }
-                const bool all_ok = __ballot(node && !ok) == 0;
-                double sc = 0.0;
-                if (all_ok) {
-                    // roots first: x_n = G_n^-T (y_n - G_n^-1 (H_parent,n^T x_parent)), x handed down through LDS
-                    for (int h = ts.nlev - 1; h >= 0; --h) {
-                        if (node && nd.height == h) {
-                            double t[6], Gl[6][6];
-#pragma unroll
-                            for (int r = 0; r < 6; ++r) t[r] = y[r];
-                            {
-                                int k = 0;
-#pragma unroll
-                                for (int cc = 0; cc < 5; ++cc)
-#pragma unroll
-                                    for (int r = cc + 1; r < 6; ++r) { Gl[r][cc] = Gs[k]; ++k; }
-                            }
-                            if (nd.par >= 0) {
-                                double v[6];
-#pragma unroll
-                                for (int cc = 0; cc < 6; ++cc) {
-                                    double a2 = 0.0;
-#pragma unroll
-                                    for (int r = 0; r < 6; ++r) a2 = __builtin_fma(HO[6 * cc + r], xx[nd.par * 6 + r], a2);
-                                    v[cc] = a2;
-                                }
-#pragma unroll
-                                for (int cc = 0; cc < 6; ++cc) {
-                                    v[cc] *= ig[cc];
-#pragma unroll
-                                    for (int c2 = cc + 1; c2 < 6; ++c2) v[c2] = __builtin_fma(-v[cc], Gl[c2][cc], v[c2]);
-                                    t[cc] -= v[cc];
-                                }
-                            }
-#pragma unroll
-                            for (int rr = 5; rr >= 0; --rr) {
-                                x[rr] = t[rr] * ig[rr];
-#pragma unroll
-                                for (int q2 = 0; q2 < rr; ++q2) t[q2] = __builtin_fma(-Gl[rr][q2], x[rr], t[q2]);
-                            }
-#pragma unroll
-                            for (int r = 0; r < 6; ++r) xx[lane * 6 + r] = x[r];
-                        }
-                        wsync();
-                    }
-                }
-                // (a failed factorisation leaves every x as it was: g2o applies the stale x all the same)
-                if (node) {
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) sc += x[k] * (lambda * x[k] + HB[k]);
-                    double Rd[9];
-                    const double ww = 1.0 - (x[3] * x[3] + x[4] * x[4] + x[5] * x[5]);
-                    if (ww < 0) { Rd[0] = 1; Rd[1] = 0; Rd[2] = 0; Rd[3] = 0; Rd[4] = 1; Rd[5] = 0; Rd[6] = 0; Rd[7] = 0; Rd[8] = 1; }
-                    else { const double qd[4] = {sqrt(ww), x[3], x[4], x[5]}; quat_to_mat(qd, Rd); }
-                    double tn[3];
-                    mat_mul(Xa, Rd, Xb);
-                    mat_vec(Xa, x, tn);
-                    Xb[9] = Xa[9] + tn[0]; Xb[10] = Xa[10] + tn[1]; Xb[11] = Xa[11] + tn[2];
-                }
-                const double scale = wave_sum(sc) + 1e-3;
-                ++trials;
-                // ---- score the trial state -------------------------------------------------------------------------------------------------
-                double temp_chi;
-                {
-                    double Xpar[12], rs = 0.0, cs = 0.0, D[1], Dp[1], O[1];
-                    int nbin;
-                    parent_pose(Xb, Xpar);
-                    if (node) wave_node_edges<false, JAC>(a, ts, inst, lane, nd, Xb, Xpar, rs, cs, D, Dp, O, nbin);
-                    temp_chi = wave_sum(rs);
-                    last_plain = wave_sum(cs);
-                }
-                if (!all_ok) temp_chi = DBL_MAX;
-                rho = (cur_chi - temp_chi) / scale;
-                if (rho > 0.0 && fabs(temp_chi) <= DBL_MAX) {
-                    const double r21 = 2.0 * rho - 1.0;
-                    double alpha = 1.0 - r21 * r21 * r21;
-                    alpha = fmin(alpha, good_hi);
-                    lambda *= fmax(good_lo, alpha);
-                    ni = 2.0;
-                    cur_chi = temp_chi;
-#pragma unroll
-                    for (int k = 0; k < 12; ++k) Xa[k] = Xb[k];   // the trial state is the state
-                } else {
-                    lambda *= ni;
-                    ni *= 2.0;
-                }
-                ++q;
-            } while (rho < 0.0 && q < max_trials);
-            ++it;
-            if (q == max_trials || rho == 0.0) { terminated = 1; break; }
-        }
-    }
-    if (node) {
-#pragma unroll
-        for (int k = 0; k < 12; ++k) gout[k] = Xa[k];
-    }
-    if (lane == 0) {
-        double* res = a.result + (size_t)inst * 8;
-        res[0] = last_plain; res[1] = cur_chi; res[2] = lambda; res[3] = (double)it; res[4] = (double)trials;
-        res[5] = (double)terminated; res[6] = (double)shared_edges; res[7] = nv > 0 ? (double)(ts.nlev * 65536 + 2 * nv - ts.nroots) : 0.0;
-    }
-}
-
-}  // namespace
-
-hipError_t launch_window_tree_wave(const WindowArgs& a, const TreeSched& ts, hipStream_t stream) {
-    if (a.B <= 0 || ts.nv <= 0 || ts.nv > 64 || ts.nlev <= 0) return hipErrorInvalidValue;
-    if (a.jacobian) hipLaunchKernelGGL((tree_wave_kernel<1>), dim3((unsigned)a.B), dim3(64), 0, stream, a, ts);
-    else hipLaunchKernelGGL((tree_wave_kernel<0>), dim3((unsigned)a.B), dim3(64), 0, stream, a, ts);
-    return hipGetLastError();
-}
 
 }  // namespace locamd

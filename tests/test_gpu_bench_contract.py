@@ -25,7 +25,9 @@ def test_headline_is_the_reference_configuration(gpu):
     assert j["config"]["jacobian"] == "numeric" and j["dtype"] == "f64" and j["n_gpus"] == 1
     assert j["roofline"]["bound"] == "hbm" and j["roofline"]["kernel"].endswith("numeric>") and 0 < j["roofline"]["frac"] < 1
     cb = j["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["max_abs_diff_vs_gpu_m"] <= 1e-5     # numeric vs numeric
+    # numeric vs numeric: 1e-5 m per update, up to the rare update whose LM accept / reject decision the 1e-7 noise of the difference quotient flips
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["median_abs_diff_vs_gpu_m"] < 1e-7 and cb["max_abs_diff_vs_gpu_m"] < 1e-4
+    assert cb["frac_updates_diff_gt_1e-5_m"] <= 1e-3
     leg = j["legs"]["cfg2_analytic"]
     assert leg["jacobian"] == "analytic" and j["value_fast_mode"] == leg["value"] and leg["max_abs_diff_vs_cpu_baseline_m"] < 1e-3
     assert j["collectives"]["ranks"] == 1

@@ -496,8 +496,8 @@ int main(int argc, char** argv) {
     assert hdr == ["# iteration_max:10\n", "# trajectory_length:10\n", "# maximum_velocity:5\n"]
     assert len(rt) == len(want) and len(op) == len(want) + 5
     rows = np.array([[float(x) for x in ln.split()] for ln in op[-5:]])
-    assert np.allclose(rows[:, 0], tail[:, 0], atol=1e-8) and np.allclose(rows[:, 1:], tail[:, 1:], rtol=2e-6, atol=1e-9)   # (%g: six digits)
-    assert np.allclose(np.array([[float(x) for x in ln.split()] for ln in rt])[:, 1:4], want[:, 1:4], rtol=2e-6, atol=1e-9)
+    assert np.allclose(rows[:, 0], tail[:, 0], atol=1e-8) and np.allclose(rows[:, 1:], tail[:, 1:], rtol=1e-5, atol=1e-9)   # (%g: six significant digits)
+    assert np.allclose(np.array([[float(x) for x in ln.split()] for ln in rt])[:, 1:4], want[:, 1:4], rtol=1e-5, atol=1e-9)
 
 
 def test_shim_adapter_rl_range_edges(gpu, tmp_path):

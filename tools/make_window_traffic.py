@@ -29,8 +29,12 @@ for arg in sys.argv[1:]:
                  "calibration": {"file": "profiles/r03_fetch_calibration.json", "read_factor": calib_read, "write_factor": 1.0,
                                  "note": "FETCH_SIZE x read_factor = bytes of the 128-B lines fetched (measured 0.5000 counted / moved for 16-B and 8-B per lane "
                                          "coalesced streams, 64 B counted per line for scattered 8-B reads); WRITE_SIZE exact for full lines, 32-B sectors for scattered stores"},
+                 "kernel_source_sha256": bench.kernel_source_hash(bench.WINDOW_LEG_SOURCES[leg]), "kernel_sources": list(bench.WINDOW_LEG_SOURCES[leg]),
                  "source": os.path.relpath(os.path.abspath(path), ROOT) + ": rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE, separate passes, per launch of the "
                            "leg's single-GPU batch; factors from profiles/r03_fetch_calibration.json"}
-out = {"kernel_source_sha256": bench.kernel_source_hash(bench.WINDOW_KERNEL_SOURCES), "kernel_sources": list(bench.WINDOW_KERNEL_SOURCES), "legs": legs}
+path = os.path.join(ROOT, "profiles", "window_traffic.json")
+old = json.load(open(path)).get("legs", {}) if os.path.exists(path) else {}
+old.update(legs)   # (legs not named on the command line keep their entries: each carries the hash of its own kernel's sources)
+out = {"legs": old}
 json.dump(out, open(os.path.join(ROOT, "profiles", "window_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
