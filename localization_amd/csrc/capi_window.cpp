@@ -591,6 +591,18 @@ static bool build_tree_sched(loc_window* w, int which, int64_t n, const int32_t*
     }
     by_slot(kids_lf, false); by_slot(re, true); by_slot(pe, true); by_slot(se, true);
     for (int v = 0; v < nv; ++v) t.push_back(nleafkids[(size_t)v]);
+    // the inner nodes, parents first (tree_wave_kernel sums over children with lane = entry, one inner node after the other)
+    int nu = 0;
+    for (int h = hmax; h >= 1; --h)
+        for (int v = 0; v < nv; ++v) if (height[(size_t)v] == h) { t.push_back(v); ++nu; }
+    A.tsched.nu = nu;
+    {   // a pose's position in the children list just emitted (by_slot(kids_lf)): parents in slot order, a parent's leaf children first
+        std::vector<int> kpos((size_t)nv, -1);
+        int at = 0;
+        for (int v = 0; v < nv; ++v) for (int ch : kids_lf[(size_t)v]) kpos[(size_t)ch] = at++;
+        for (int v = 0; v < nv; ++v) if (kpos[(size_t)v] < 0) kpos[(size_t)v] = at++;   // roots
+        for (int v = 0; v < nv; ++v) t.push_back(kpos[(size_t)v]);
+    }
     A.tsched.nlev = hmax + 1;
     A.tsched.max_se3_per_node = 0;
     for (int k = 0; k < nv; ++k) if ((int)se[(size_t)k].size() > A.tsched.max_se3_per_node) A.tsched.max_se3_per_node = (int)se[(size_t)k].size();
@@ -622,7 +634,9 @@ static hipError_t upload_tree_sched(loc_window* w, int which, hipStream_t st) {
     ts.w_roff = p; p += nv + 1; ts.w_rlist = p; p += nr;
     ts.w_poff = p; p += nv + 1; ts.w_plist = p; p += np;
     ts.w_soff = p; p += nv + 1; ts.w_slist = p; p += ns;
-    ts.w_kleaf = p;
+    ts.w_kleaf = p; p += nv;
+    ts.w_ulist = p; p += ts.nu;
+    ts.w_kpos = p;
     return hipSuccess;
 }
 

@@ -9,9 +9,14 @@ namespace {
 // One EdgeSE3 between the consecutive poses i and j of a chain window: the math of evaluate_edges' SE3 branch, with the record in
 // registers.  Returns chi; rterm = the edge's robust cost; FULL: H_ii, H_jj (lower triangles, 21), the off-diagonal block with the
 // rows of the LATER pose (36, column-major), b_i, b_j.
-template <bool FULL>
-__device__ __forceinline__ double chain_se3_terms(const double* Xi, const double* Xj, const double* val, bool robust, bool j_is_later,
+// VS: stride of the record's entries in doubles (1: a plain array; 64: one lane's column of an [entry][lane] LDS block — the inverse
+// measurement is copied to registers, the information matrix is read where it is used).
+template <bool FULL, int VS = 1>
+__device__ __forceinline__ double chain_se3_terms(const double* Xi, const double* Xj, const double* val_, bool robust, bool j_is_later,
                                                   double* Hii, double* Hjj, double* Hoff, double* bi_, double* bj_, double& rterm) {
+    double val[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) val[k] = val_[VS * k];
     double RB[9], tB[3], dt[3] = {Xj[9] - Xi[9], Xj[10] - Xi[10], Xj[11] - Xi[11]};
     mat_tmul(Xi, Xj, RB);
     mat_tvec(Xi, dt, tB);
@@ -23,14 +28,15 @@ __device__ __forceinline__ double chain_se3_terms(const double* Xi, const double
     mat_to_quat(RE, qE);
     quat_normalize_sign(qE);
     const double err[6] = {tE[0], tE[1], tE[2], qE[1], qE[2], qE[3]};
-    const double* Om = val + 12;
+    const double* Om_ = val_ + VS * 12;
+#define Om(k) Om_[VS * (k)]
     double Oe[6];
     double chi = 0.0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         double r = 0.0;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) r += Om[i * 6 + j] * err[j];
+        for (int j = 0; j < 6; ++j) r += Om(i * 6 + j) * err[j];
         Oe[i] = r;
         chi += err[i] * r;
     }
@@ -78,7 +84,7 @@ __device__ __forceinline__ double chain_se3_terms(const double* Xi, const double
             for (int cc = 0; cc < 6; ++cc) {
                 double s0 = 0.0;
 #pragma unroll
-                for (int j = 0; j < LOCAMD_J0_HI(cc); ++j) s0 += Om[i * 6 + j] * J0[j * 6 + cc];
+                for (int j = 0; j < LOCAMD_J0_HI(cc); ++j) s0 += Om(i * 6 + j) * J0[j * 6 + cc];
                 WJ[i * 6 + cc] = w * s0;
             }
 #pragma unroll
@@ -107,7 +113,7 @@ __device__ __forceinline__ double chain_se3_terms(const double* Xi, const double
             for (int cc = 0; cc < 6; ++cc) {
                 double s1 = 0.0;
 #pragma unroll
-                for (int j = LOCAMD_J1_LO(cc); j < LOCAMD_J1_HI(cc); ++j) s1 += Om[i * 6 + j] * J1[j * 6 + cc];
+                for (int j = LOCAMD_J1_LO(cc); j < LOCAMD_J1_HI(cc); ++j) s1 += Om(i * 6 + j) * J1[j * 6 + cc];
                 WJ[i * 6 + cc] = w * s1;
             }
 #pragma unroll
@@ -144,6 +150,7 @@ __device__ __forceinline__ double chain_se3_terms(const double* Xi, const double
 #undef LOCAMD_J1_HI
 #undef LOCAMD_J0_HI
     }
+#undef Om
     return chi;
 }
 

@@ -596,534 +596,4 @@ hipError_t launch_window_tree(const WindowArgs& a, const TreeSched& ts, double* 
     return hipGetLastError();
 }
 
-
-// =====================================================================================================================
-// The same batches (forest windows of ONE shared topology, <= 64 poses), one WAVE per window with LANE = POSE and the whole
-// solver state of a pose in that lane's REGISTERS: tree_wave_kernel.
-//
-// tree_lm_kernel above walks a window's 64 nodes one after the other in one lane: a wave's instruction stream is 64 nodes long
-// per sweep whatever the batch, so 16 384 windows are 256 waves — a quarter of the chip's SIMDs, each bound by its own instruction
-// issue (an EdgeSE3 linearisation is ~1 200 instructions).  Here the 64 nodes of a window are the 64 lanes of a wave:
-//   * linearisation and trial scoring: every lane evaluates ITS node's edges (anchor ranges, priors, and the edges to its parent)
-//     at once — one edge's worth of instructions per sweep instead of 64;
-//   * elimination by HEIGHT: all leaves factor their 6x6 block together, then the nodes whose children are done, ... — config 5's
-//     caterpillar is 9 steps (56 leaves at once, then the eight keys) instead of 64; a node hands its Schur update (27 numbers) to
-//     its parent through LDS, the parent sums its children's in list order (fixed order: bit-reproducible); back-substitution the
-//     other way round, x handed down through LDS;
-//   * H_nn, the coupling block with the parent, b, the factor, y, x and both poses of a node (~130 doubles) never leave the lane's
-//     registers: NO workspace in memory at all — a window's poses and measurements are read once per sweep, the poses written once.
-// The schedule (parent, height, children and edge lists per pose slot) is the host's, shared by every window (scalar / cached loads).
-namespace {
-
-struct LaneNode { int par, height, k0, k1, r0, r1, q0, q1, s0, s1; };
-
-// -DLOCAMD_TREE_TIMING: cycle stamps per phase, reported INSTEAD of result[0 .. 7] (tools/dev/probe_tree.py; never benchmarked)
-#ifdef LOCAMD_TREE_TIMING
-#define TW_T0() unsigned long long tw_tc = __builtin_readcyclecounter(), tw_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long tw_start = tw_tc
-#define TW_T(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); tw_ph[k] += n_ - tw_tc; tw_tc = n_; } while (0)
-#else
-#define TW_T0() do {} while (0)
-#define TW_T(k) do {} while (0)
-#endif
-
-// every edge of this lane's node at pose X (the parent's from LDS): chi sums; FULL: own block + b (D), the parent's share (Dp), coupling O
-template <bool FULL, int JAC>
-__device__ __forceinline__ void wave_node_edges(const WindowArgs& a, const TreeSched& ts, long long inst, int lane, const LaneNode& nd,
-                                                const double* Xc, const double* Xpar, double& rsum, double& csum, double* D, double* Dp, double* O, int& nbin) {
-    const WindowCaps& c = a.caps;
-    if (FULL) {
-#pragma unroll
-        for (int k = 0; k < 27; ++k) { D[k] = 0.0; Dp[k] = 0.0; }
-#pragma unroll
-        for (int k = 0; k < 36; ++k) O[k] = 0.0;
-    }
-    nbin = 0;
-    // The EdgeSE3 factor to the parent FIRST (at most one per node here: the host sends batches with more to tree_lm_kernel): it
-    // writes its blocks straight into D / Dp / O — the 78 doubles of H_ii, H_jj and the coupling block next to the Jacobians would
-    // spill, and so would a second inlined copy of the linearisation
-    if (nd.s0 < nd.s1) {
-        const int e = ts.w_slist[nd.s0];
-        const int vi = ts.s_idx[4 * e];
-        const bool robust = ts.s_idx[4 * e + 2] != 0, i_is_cur = vi == lane;
-        const double* val = a.s_val + ((size_t)inst * c.ns_max + e) * 48;   // (read in place)
-        double rterm, chi;
-        if (FULL) {
-            double Hii[21], Hjj[21], bi[6], bj[6];
-            double Xi[12], Xj[12];
-#pragma unroll
-            for (int k = 0; k < 12; ++k) { Xi[k] = i_is_cur ? Xc[k] : Xpar[k]; Xj[k] = i_is_cur ? Xpar[k] : Xc[k]; }
-            chi = chain_se3_terms<FULL>(Xi, Xj, val, robust, i_is_cur, Hii, Hjj, O, bi, bj, rterm);
-#pragma unroll
-            for (int k = 0; k < 21; ++k) { D[k] = i_is_cur ? Hii[k] : Hjj[k]; Dp[k] = i_is_cur ? Hjj[k] : Hii[k]; }
-#pragma unroll
-            for (int k = 0; k < 6; ++k) { D[21 + k] = i_is_cur ? bi[k] : bj[k]; Dp[21 + k] = i_is_cur ? bj[k] : bi[k]; }
-            ++nbin;
-        } else {
-            double Xi[12], Xj[12];
-#pragma unroll
-            for (int k = 0; k < 12; ++k) { Xi[k] = i_is_cur ? Xc[k] : Xpar[k]; Xj[k] = i_is_cur ? Xpar[k] : Xc[k]; }
-            chi = chain_se3_terms<FULL>(Xi, Xj, val, robust, i_is_cur, nullptr, nullptr, nullptr, nullptr, nullptr, rterm);
-        }
-        rsum += rterm;
-        csum += chi;
-    }
-    for (int ri = nd.r0; ri < nd.r1; ++ri) {
-        const int e = ts.w_rlist[ri];
-        const int v0 = ts.r_idx[2 * e], v1 = ts.r_idx[2 * e + 1];
-        const double* val = a.r_val + ((size_t)inst * c.nr_max + e) * 5;
-        const double meas = val[0], info = val[1];
-        const double off[3] = {val[2], val[3], val[4]};
-        const bool first_is_cur = v0 == lane;
-        double X0[12], X1[12];
-#pragma unroll
-        for (int k = 0; k < 12; ++k) { X0[k] = first_is_cur ? Xc[k] : Xpar[k]; X1[k] = first_is_cur ? Xpar[k] : Xc[k]; }
-        double p0[3], p1[3];
-        mat_vec(X0, off, p0);
-        p0[0] += X0[9]; p0[1] += X0[10]; p0[2] += X0[11];
-        if (v1 >= 0) { p1[0] = X1[9]; p1[1] = X1[10]; p1[2] = X1[11]; }
-        else { const double* an = a.anchors + (size_t)(-1 - v1) * 3; p1[0] = an[0]; p1[1] = an[1]; p1[2] = an[2]; }
-        double u[3] = {p0[0] - p1[0], p0[1] - p1[1], p0[2] - p1[2]};
-        const double nn = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
-        const double err = JAC == 0 ? meas - nn : range_error_plain(X0, X0 + 9, off, p1, meas);
-        const double chi = err * (info * err);
-        const double aux = 1.0 + chi;
-        rsum += fast_log_ge1(aux);
-        csum += chi;
-        if (FULL) {
-            double J0[6], J1[3];
-            if (JAC == 0) {
-                const double inv = nn > 0.0 ? 1.0 / nn : 0.0;
-                u[0] *= inv; u[1] *= inv; u[2] *= inv;
-                double uR[3];
-                mat_tvec(X0, u, uR);
-                J0[0] = -uR[0]; J0[1] = -uR[1]; J0[2] = -uR[2];
-                J0[3] = 2.0 * (uR[1] * off[2] - uR[2] * off[1]);
-                J0[4] = 2.0 * (uR[2] * off[0] - uR[0] * off[2]);
-                J0[5] = 2.0 * (uR[0] * off[1] - uR[1] * off[0]);
-                if (v1 >= 0) mat_tvec(X1, u, J1); else { J1[0] = 0; J1[1] = 0; J1[2] = 0; }
-            } else {
-                J0[0] = range_jac_numeric<0>(X0, off, X1, p1, 0, meas);
-                J0[1] = range_jac_numeric<1>(X0, off, X1, p1, 0, meas);
-                J0[2] = range_jac_numeric<2>(X0, off, X1, p1, 0, meas);
-                J0[3] = range_jac_numeric<3>(X0, off, X1, p1, 0, meas);
-                J0[4] = range_jac_numeric<4>(X0, off, X1, p1, 0, meas);
-                J0[5] = range_jac_numeric<5>(X0, off, X1, p1, 0, meas);
-                if (v1 >= 0) {
-                    J1[0] = range_jac_numeric<0>(X0, off, X1, p1, 1, meas);
-                    J1[1] = range_jac_numeric<1>(X0, off, X1, p1, 1, meas);
-                    J1[2] = range_jac_numeric<2>(X0, off, X1, p1, 1, meas);
-                } else { J1[0] = 0; J1[1] = 0; J1[2] = 0; }
-            }
-            const double wr = info / aux, wre = -wr * err;
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-#pragma unroll
-                for (int cc = 0; cc <= r; ++cc) {
-                    const double h = wr * J0[r] * J0[cc];
-                    D[r * (r + 1) / 2 + cc] += first_is_cur ? h : 0.0;
-                    Dp[r * (r + 1) / 2 + cc] += first_is_cur ? 0.0 : h;
-                }
-                const double bb = J0[r] * wre;
-                D[21 + r] += first_is_cur ? bb : 0.0;
-                Dp[21 + r] += first_is_cur ? 0.0 : bb;
-            }
-            if (v1 >= 0) {
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-#pragma unroll
-                    for (int cc = 0; cc <= r; ++cc) {
-                        const double h = wr * J1[r] * J1[cc];
-                        D[r * (r + 1) / 2 + cc] += first_is_cur ? 0.0 : h;
-                        Dp[r * (r + 1) / 2 + cc] += first_is_cur ? h : 0.0;
-                    }
-                    const double bb = J1[r] * wre;
-                    D[21 + r] += first_is_cur ? 0.0 : bb;
-                    Dp[21 + r] += first_is_cur ? bb : 0.0;
-                }
-                double jr[6], jc[6];   // rows: the parent's J, columns: this node's
-#pragma unroll
-                for (int r = 0; r < 6; ++r) {
-                    jr[r] = first_is_cur ? (r < 3 ? J1[r] : 0.0) : J0[r];
-                    jc[r] = first_is_cur ? J0[r] : (r < 3 ? J1[r] : 0.0);
-                }
-#pragma unroll
-                for (int r = 0; r < 6; ++r)
-#pragma unroll
-                    for (int cc = 0; cc < 6; ++cc) O[6 * cc + r] += wr * jr[r] * jc[cc];
-                ++nbin;
-            }
-        }
-    }
-    for (int qi = nd.q0; qi < nd.q1; ++qi) {
-        const int e = ts.w_plist[qi];
-        const double* pv = a.p_val + ((size_t)inst * c.np_max + e) * 18;
-        double Zi[12], Wd[6];
-#pragma unroll
-        for (int k = 0; k < 12; ++k) Zi[k] = pv[k];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) Wd[k] = pv[12 + k];
-        double RE[9], tE[3], qq[4];
-        mat_mul(Zi, Xc, RE);
-        mat_vec(Zi, Xc + 9, tE);
-        tE[0] += Zi[9]; tE[1] += Zi[10]; tE[2] += Zi[11];
-        mat_to_quat(RE, qq);
-        quat_normalize_sign(qq);
-        const double err[6] = {tE[0], tE[1], tE[2], qq[1], qq[2], qq[3]};
-        double chi = 0.0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) chi += err[i] * (Wd[i] * err[i]);
-        rsum += chi;
-        csum += chi;
-        if (FULL) {
-            double J[36];
-#pragma unroll
-            for (int i = 0; i < 36; ++i) J[i] = 0.0;
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) J[i * 6 + j] = RE[i * 3 + j];
-            quat_right_jac(qq, 1.0, J, 6);
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-#pragma unroll
-                for (int cc = 0; cc <= r; ++cc) {
-                    double h = 0.0;
-                    if ((r < 3) == (cc < 3)) {
-#pragma unroll
-                        for (int i = (r < 3 ? 0 : 3); i < (r < 3 ? 3 : 6); ++i) h += J[i * 6 + r] * Wd[i] * J[i * 6 + cc];
-                    }
-                    D[r * (r + 1) / 2 + cc] += h;
-                }
-                double bb = 0.0;
-#pragma unroll
-                for (int i = (r < 3 ? 0 : 3); i < (r < 3 ? 3 : 6); ++i) bb += J[i * 6 + r] * (-Wd[i] * err[i]);
-                D[21 + r] += bb;
-            }
-        }
-    }
-}
-
-template <int JAC>
-__global__ void __launch_bounds__(64, 1) tree_wave_kernel(const WindowArgs a, const TreeSched ts) {
-    __shared__ double dep[64 * 27];   // what a node hands to its parent (Schur update / linearisation share)
-    __shared__ double xp[64 * 12];    // poses, for the children to read their parent's
-    __shared__ double xx[64 * 6];     // x, handed down in the back-substitution
-    const int lane = threadIdx.x;
-    const long long inst = blockIdx.x;
-    const WindowCaps& c = a.caps;
-    const int nv = ts.nv;
-    const bool node = lane < nv;
-    LaneNode nd = {-1, -1, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (node) {
-        nd.par = ts.w_par[lane]; nd.height = ts.w_height[lane];
-        nd.k0 = ts.w_koff[lane]; nd.k1 = ts.w_koff[lane + 1];
-        nd.r0 = ts.w_roff[lane]; nd.r1 = ts.w_roff[lane + 1];
-        nd.q0 = ts.w_poff[lane]; nd.q1 = ts.w_poff[lane + 1];
-        nd.s0 = ts.w_soff[lane]; nd.s1 = ts.w_soff[lane + 1];
-    }
-    const int kleaf = node ? ts.w_kleaf[lane] : 0;
-    const double* gin = a.poses_in + ((size_t)inst * c.nv_max + (node ? lane : 0)) * 12;
-    double* gout = a.poses + ((size_t)inst * c.nv_max + (node ? lane : 0)) * 12;
-    double Xa[12], Xb[12];   // state / trial state
-#pragma unroll
-    for (int k = 0; k < 12; ++k) { Xa[k] = gin[k]; Xb[k] = Xa[k]; }
-    double HD[21], HB[6], HO[36], Gs[15], ig[6], y[6], x[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { x[k] = 0.0; y[k] = 0.0; ig[k] = 0.0; HB[k] = 0.0; }
-#pragma unroll
-    for (int k = 0; k < 21; ++k) HD[k] = 0.0;
-#pragma unroll
-    for (int k = 0; k < 36; ++k) HO[k] = 0.0;
-#pragma unroll
-    for (int k = 0; k < 15; ++k) Gs[k] = 0.0;
-    constexpr double tau = 1e-5, good_lo = 1.0 / 3.0, good_hi = 2.0 / 3.0;
-    constexpr int max_trials = 10;
-    double lambda = 0.0, ni = 2.0, cur_chi = 0.0, last_plain = 0.0;
-    int it = 0, trials = 0, terminated = 0, shared_edges = 0;
-    const bool active = nv > 0 && ts.nr + ts.np + ts.ns > 0 && a.iterations > 0;
-    auto wsync = [] {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    };
-    // pose X of every node -> LDS, the parent's back
-    auto parent_pose = [&](const double* X, double* Xpar) {
-        wsync();
-#pragma unroll
-        for (int k = 0; k < 12; ++k) xp[lane * 12 + k] = X[k];
-        wsync();
-#pragma unroll
-        for (int k = 0; k < 12; ++k) Xpar[k] = nd.par >= 0 ? xp[nd.par * 12 + k] : 0.0;
-    };
-    TW_T0();
-    if (active) {
-        for (; it < a.iterations;) {
-            TW_T(7);
-            // ---- linearise at Xa: every lane its node's edges; the parent's shares go up through LDS ------------------------------
-            {
-                double Xpar[12], D[27], Dp[27], rs = 0.0, cs = 0.0;
-                int nbin;
-                parent_pose(Xa, Xpar);
-                if (node) wave_node_edges<true, JAC>(a, ts, inst, lane, nd, Xa, Xpar, rs, cs, D, Dp, HO, nbin);
-                else {
-#pragma unroll
-                    for (int k = 0; k < 27; ++k) { D[k] = 0.0; Dp[k] = 0.0; }
-                    nbin = 0;
-                }
-#pragma unroll
-                for (int k = 0; k < 27; ++k) dep[lane * 27 + k] = Dp[k];
-                wsync();
-                for (int ci = nd.k0; ci < nd.k1; ++ci) {
-                    const int ch = ts.w_klist[ci];
-#pragma unroll
-                    for (int k = 0; k < 27; ++k) D[k] += dep[ch * 27 + k];
-                }
-#pragma unroll
-                for (int k = 0; k < 21; ++k) HD[k] = D[k];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) HB[k] = D[21 + k];
-                double md = 0.0;
-#pragma unroll
-                for (int r = 0; r < 6; ++r) md = fmax(md, fabs(HD[r * (r + 1) / 2 + r]));
-                cur_chi = wave_sum(rs);
-                last_plain = wave_sum(cs);
-                if (it == 0) { lambda = tau * wave_max(node ? md : 0.0); ni = 2.0; shared_edges = (int)wave_sum(node && nbin >= 2 ? (double)nbin : 0.0); }
-                wsync();
-            }
-            TW_T(0);
-            int q = 0;
-            double rho = 0.0;
-            do {
-                // ---- (H + lambda I) x = b: leaves first, by height; a node's Schur update goes to its parent through LDS ----------------
-                bool ok = true;
-                for (int h = 0; h < ts.nlev; ++h) {
-                    if (h == 1) {
-                        // every node sums what its LEAF children handed up, all nodes at once (inside the level loop that sum would be
-                        // walked once per level by the whole wave: config 5's keys have seven leaves each); it waits in the node's own
-                        // slot of `dep`, which the node only overwrites when it hands its own update up
-                        if (node && nd.height >= 1) {
-                            double pre[27];
-#pragma unroll
-                            for (int k = 0; k < 27; ++k) pre[k] = 0.0;
-                            for (int ci = nd.k0; ci < nd.k0 + kleaf; ++ci) {
-                                const double* d = dep + ts.w_klist[ci] * 27;
-#pragma unroll
-                                for (int k = 0; k < 27; ++k) pre[k] += d[k];
-                            }
-                            wsync();
-#pragma unroll
-                            for (int k = 0; k < 27; ++k) dep[lane * 27 + k] = pre[k];
-                        } else {
-                            wsync();
-                        }
-                        wsync();
-                        TW_T(2);
-                    }
-                    if (node && nd.height == h) {
-                        double A[6][6], rhs[6];
-#pragma unroll
-                        for (int r = 0; r < 6; ++r) {
-#pragma unroll
-                            for (int cc = 0; cc <= r; ++cc) A[r][cc] = HD[r * (r + 1) / 2 + cc];
-                            A[r][r] += lambda;
-                            rhs[r] = HB[r];
-                        }
-                        if (h >= 1) {
-                            const double* d = dep + lane * 27;
-#pragma unroll
-                            for (int r = 0; r < 6; ++r) {
-#pragma unroll
-                                for (int cc = 0; cc <= r; ++cc) A[r][cc] -= d[r * (r + 1) / 2 + cc];
-                                rhs[r] -= d[21 + r];
-                            }
-                        }
-                        for (int ci = nd.k0 + kleaf; ci < nd.k1; ++ci) {
-                            const double* d = dep + ts.w_klist[ci] * 27;
-#pragma unroll
-                            for (int r = 0; r < 6; ++r) {
-#pragma unroll
-                                for (int cc = 0; cc <= r; ++cc) A[r][cc] -= d[r * (r + 1) / 2 + cc];
-                                rhs[r] -= d[21 + r];
-                            }
-                        }
-#pragma unroll
-                        for (int j = 0; j < 6; ++j) {
-                            const double g = pivot_rsqrt(A[j][j]);
-                            ig[j] = g;
-#pragma unroll
-                            for (int i2 = j + 1; i2 < 6; ++i2) A[i2][j] *= g;
-#pragma unroll
-                            for (int i2 = j + 1; i2 < 6; ++i2)
-#pragma unroll
-                                for (int cc = j + 1; cc <= i2; ++cc) A[i2][cc] = __builtin_fma(-A[i2][j], A[cc][j], A[i2][cc]);
-                        }
-                        ok = (((ig[0] + ig[1]) + (ig[2] + ig[3])) + (ig[4] + ig[5]) < DBL_MAX);
-#pragma unroll
-                        for (int cc = 0; cc < 6; ++cc) {
-                            rhs[cc] *= ig[cc];
-#pragma unroll
-                            for (int c2 = cc + 1; c2 < 6; ++c2) rhs[c2] = __builtin_fma(-rhs[cc], A[c2][cc], rhs[c2]);
-                        }
-                        {
-                            int k = 0;
-#pragma unroll
-                            for (int cc = 0; cc < 5; ++cc)
-#pragma unroll
-                                for (int r = cc + 1; r < 6; ++r) { Gs[k] = A[r][cc]; ++k; }
-                        }
-#pragma unroll
-                        for (int r = 0; r < 6; ++r) y[r] = rhs[r];
-                        if (nd.par >= 0) {
-                            double Wm[36];   // W = H_parent,n G^-T, entry (r, c) at 6 c + r
-#pragma unroll
-                            for (int r = 0; r < 6; ++r) {
-                                double w[6];
-#pragma unroll
-                                for (int cc = 0; cc < 6; ++cc) w[cc] = HO[6 * cc + r];
-#pragma unroll
-                                for (int cc = 0; cc < 6; ++cc) {
-                                    w[cc] *= ig[cc];
-#pragma unroll
-                                    for (int c2 = cc + 1; c2 < 6; ++c2) w[c2] = __builtin_fma(-w[cc], A[c2][cc], w[c2]);
-                                }
-#pragma unroll
-                                for (int cc = 0; cc < 6; ++cc) Wm[6 * cc + r] = w[cc];
-                            }
-#pragma unroll
-                            for (int r = 0; r < 6; ++r) {
-#pragma unroll
-                                for (int c2 = 0; c2 <= r; ++c2) {
-                                    double s2 = 0.0;
-#pragma unroll
-                                    for (int k = 0; k < 6; ++k) s2 = __builtin_fma(Wm[6 * k + r], Wm[6 * k + c2], s2);
-                                    dep[lane * 27 + r * (r + 1) / 2 + c2] = s2;
-                                }
-                                double s3 = 0.0;
-#pragma unroll
-                                for (int k = 0; k < 6; ++k) s3 = __builtin_fma(Wm[6 * k + r], rhs[k], s3);
-                                dep[lane * 27 + 21 + r] = s3;
-                            }
-                        }
-                    }
-                    wsync();
-                    TW_T(h == 0 ? 1 : 3);
-                }
-                const bool all_ok = __ballot(node && !ok) == 0;
-                double sc = 0.0;
-                if (all_ok) {
-                    // roots first: x_n = G_n^-T (y_n - G_n^-1 (H_parent,n^T x_parent)), x handed down through LDS
-                    for (int h = ts.nlev - 1; h >= 0; --h) {
-                        if (node && nd.height == h) {
-                            double t[6], Gl[6][6];
-#pragma unroll
-                            for (int r = 0; r < 6; ++r) t[r] = y[r];
-                            {
-                                int k = 0;
-#pragma unroll
-                                for (int cc = 0; cc < 5; ++cc)
-#pragma unroll
-                                    for (int r = cc + 1; r < 6; ++r) { Gl[r][cc] = Gs[k]; ++k; }
-                            }
-                            if (nd.par >= 0) {
-                                double v[6];
-#pragma unroll
-                                for (int cc = 0; cc < 6; ++cc) {
-                                    double a2 = 0.0;
-#pragma unroll
-                                    for (int r = 0; r < 6; ++r) a2 = __builtin_fma(HO[6 * cc + r], xx[nd.par * 6 + r], a2);
-                                    v[cc] = a2;
-                                }
-#pragma unroll
-                                for (int cc = 0; cc < 6; ++cc) {
-                                    v[cc] *= ig[cc];
-#pragma unroll
-                                    for (int c2 = cc + 1; c2 < 6; ++c2) v[c2] = __builtin_fma(-v[cc], Gl[c2][cc], v[c2]);
-                                    t[cc] -= v[cc];
-                                }
-                            }
-#pragma unroll
-                            for (int rr = 5; rr >= 0; --rr) {
-                                x[rr] = t[rr] * ig[rr];
-#pragma unroll
-                                for (int q2 = 0; q2 < rr; ++q2) t[q2] = __builtin_fma(-Gl[rr][q2], x[rr], t[q2]);
-                            }
-#pragma unroll
-                            for (int r = 0; r < 6; ++r) xx[lane * 6 + r] = x[r];
-                        }
-                        wsync();
-                    }
-                }
-                TW_T(4);
-                // (a failed factorisation leaves every x as it was: g2o applies the stale x all the same)
-                if (node) {
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) sc += x[k] * (lambda * x[k] + HB[k]);
-                    double Rd[9];
-                    const double ww = 1.0 - (x[3] * x[3] + x[4] * x[4] + x[5] * x[5]);
-                    if (ww < 0) { Rd[0] = 1; Rd[1] = 0; Rd[2] = 0; Rd[3] = 0; Rd[4] = 1; Rd[5] = 0; Rd[6] = 0; Rd[7] = 0; Rd[8] = 1; }
-                    else { const double qd[4] = {sqrt(ww), x[3], x[4], x[5]}; quat_to_mat(qd, Rd); }
-                    double tn[3];
-                    mat_mul(Xa, Rd, Xb);
-                    mat_vec(Xa, x, tn);
-                    Xb[9] = Xa[9] + tn[0]; Xb[10] = Xa[10] + tn[1]; Xb[11] = Xa[11] + tn[2];
-                }
-                const double scale = wave_sum(sc) + 1e-3;
-                ++trials;
-                TW_T(5);
-                // ---- score the trial state -------------------------------------------------------------------------------------------------
-                double temp_chi;
-                {
-                    double Xpar[12], rs = 0.0, cs = 0.0, D[1], Dp[1], O[1];
-                    int nbin;
-                    parent_pose(Xb, Xpar);
-                    if (node) wave_node_edges<false, JAC>(a, ts, inst, lane, nd, Xb, Xpar, rs, cs, D, Dp, O, nbin);
-                    temp_chi = wave_sum(rs);
-                    last_plain = wave_sum(cs);
-                }
-                TW_T(6);
-                if (!all_ok) temp_chi = DBL_MAX;
-                rho = (cur_chi - temp_chi) / scale;
-                if (rho > 0.0 && fabs(temp_chi) <= DBL_MAX) {
-                    const double r21 = 2.0 * rho - 1.0;
-                    double alpha = 1.0 - r21 * r21 * r21;
-                    alpha = fmin(alpha, good_hi);
-                    lambda *= fmax(good_lo, alpha);
-                    ni = 2.0;
-                    cur_chi = temp_chi;
-#pragma unroll
-                    for (int k = 0; k < 12; ++k) Xa[k] = Xb[k];   // the trial state is the state
-                } else {
-                    lambda *= ni;
-                    ni *= 2.0;
-                }
-                ++q;
-            } while (rho < 0.0 && q < max_trials);
-            ++it;
-            if (q == max_trials || rho == 0.0) { terminated = 1; break; }
-        }
-    }
-    if (node) {
-#pragma unroll
-        for (int k = 0; k < 12; ++k) gout[k] = Xa[k];
-    }
-    if (lane == 0) {
-        double* res = a.result + (size_t)inst * 8;
-        res[0] = last_plain; res[1] = cur_chi; res[2] = lambda; res[3] = (double)it; res[4] = (double)trials;
-        res[5] = (double)terminated; res[6] = (double)shared_edges; res[7] = nv > 0 ? (double)(ts.nlev * 65536 + 2 * nv - ts.nroots) : 0.0;
-#ifdef LOCAMD_TREE_TIMING
-        for (int k = 0; k < 7; ++k) res[k] = (double)tw_ph[k];
-        res[7] = (double)(__builtin_readcyclecounter() - tw_start) + 1e12 * trials;
-#endif
-    }
-}
-
-}  // namespace
-
-hipError_t launch_window_tree_wave(const WindowArgs& a, const TreeSched& ts, hipStream_t stream) {
-    if (a.B <= 0 || ts.nv <= 0 || ts.nv > 64 || ts.nlev <= 0) return hipErrorInvalidValue;
-    if (a.jacobian) hipLaunchKernelGGL((tree_wave_kernel<1>), dim3((unsigned)a.B), dim3(64), 0, stream, a, ts);
-    else hipLaunchKernelGGL((tree_wave_kernel<0>), dim3((unsigned)a.B), dim3(64), 0, stream, a, ts);
-    return hipGetLastError();
-}
-
 }  // namespace locamd

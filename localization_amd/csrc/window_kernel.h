@@ -83,7 +83,7 @@ size_t window_arrow3_workspace_doubles(const WindowCaps& c, int nb_max);
 size_t window_arrow3_lds_bytes(const WindowCaps& c, int nb_max);
 hipError_t launch_window_arrow3(const WindowArgs& a, const ArrowAux& x, hipStream_t stream);
 
-// forest windows of ONE shared topology, one lane per window (window_kernel.hip: tree_lm_kernel): the elimination schedule the
+// forest windows of ONE shared topology, one lane per window (tree_kernel.hip: tree_lm_kernel) or one wave per window (tree_wave_kernel.hip): the elimination schedule the
 // host builds once per upload (capi_window.cpp: build_tree_sched); all pointers are device arrays shared by the whole batch
 struct TreeSched {
     const int32_t* node;    // [nv]   pose slot of the k-th node in elimination order (children before their parent)
@@ -98,7 +98,10 @@ struct TreeSched {
     // the leaves, children (w_klist[w_koff[v] .. w_koff[v+1])), and the edges of the pose (unary ones, and those to its parent)
     const int32_t *w_par, *w_height, *w_koff, *w_klist, *w_roff, *w_rlist, *w_poff, *w_plist, *w_soff, *w_slist;
     const int32_t* w_kleaf;   // [nv] how many of a pose's children are leaves (they come first in w_klist)
-    int nv, nr, np, ns, depth, nroots, nlev, max_se3_per_node;
+    const int32_t* w_ulist;   // [nu] the inner nodes (height >= 1) by pose slot, PARENTS FIRST (decreasing height)
+    const int32_t* w_kpos;    // [nv] a pose's position in w_klist (= the LDS column its hand-over to the parent uses: a node's children are
+                              //      consecutive columns); roots: nv - nroots, nv - nroots + 1, ...
+    int nv, nr, np, ns, depth, nroots, nlev, max_se3_per_node, nu;
 };
 size_t window_tree_workspace_doubles(const WindowCaps& c, long long B);
 hipError_t launch_window_tree(const WindowArgs& a, const TreeSched& ts, double* ws, hipStream_t stream);

@@ -20,6 +20,8 @@ n, tot, avg = s.timing_end()
 s.download(wb)
 r = wb.result.mean(axis=0)
 trials = int(r[7] // 1e12); total = r[7] - 1e12 * trials
-names = ["linearise", "factor leaves", "leaf-child sums", "factor upper levels", "back-subst", "apply step", "trial scoring"]
+names = ["linearise: edges", "factor leaves", "leaf-child sums", "factor upper levels", "back-subst", "apply step + loop", "trial scoring", "linearise: hand-over + child sums"]
+r = list(r[:8]); r.append(0.0)
+r[7] = np.floor(wb.result[:, 6] / 1e9).mean(); r[6] = (wb.result[:, 6] % 1e9).mean()
 print(f"B={B} {jac} kind {s.last_kernel_kind()} kernel {avg:.3f} ms; cycles per window {total:.0f}; LM trials {trials}")
-for k in range(7): print(f"  {names[k]:20s} {r[k]:10.0f} cycles  {100*r[k]/total:5.1f} %")
+for k in range(8): print(f"  {names[k]:20s} {r[k]:10.0f} cycles  {100*r[k]/total:5.1f} %")
