@@ -285,14 +285,16 @@ __device__ __forceinline__ void arrow_edges(const WindowArgs& a, const ArrowCtx&
         const int r = ch * 64 + lane;
         const bool valid = r < rows, is_chain = r < n;
         const int ob = r - n;   // border index of a border row
-        double tp[3] = {0.0, 0.0, 0.0}, tq[3] = {0.0, 0.0, 0.0};   // own translation, the previous chain row's
+        // own translation, the previous chain row's — SCALARS assigned without a loop: a small array filled in a `for k` loop is not promoted
+        // to registers before InstCombine first runs (the loop is unrolled later), and a select between its elements and a loaded value
+        // then becomes a load through a selected pointer, which keeps the array in scratch memory for good
+        double tp0 = 0.0, tp1 = 0.0, tp2 = 0.0, tq0 = 0.0, tq1 = 0.0, tq2 = 0.0;
         if (valid) {
             if (is_chain) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { tp[k] = T[3 * r + k]; tq[k] = r > 0 ? T[3 * (r - 1) + k] : 0.0; }
+                tp0 = T[3 * r]; tp1 = T[3 * r + 1]; tp2 = T[3 * r + 2];
+                if (r > 0) { tq0 = T[3 * r - 3]; tq1 = T[3 * r - 2]; tq2 = T[3 * r - 1]; }
             } else {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) tp[k] = TB[3 * ob + k];
+                tp0 = TB[3 * ob]; tp1 = TB[3 * ob + 1]; tp2 = TB[3 * ob + 2];
             }
         }
         double hd[6] = {0, 0, 0, 0, 0, 0}, hb[3] = {0, 0, 0}, cu[3] = {0, 0, 0}, cv[3] = {0, 0, 0}, cp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -306,79 +308,6 @@ __device__ __forceinline__ void arrow_edges(const WindowArgs& a, const ArrowCtx&
         for (int q = 0; q < PF; ++q)
 #pragma unroll
             for (int k = 0; k < 3; ++k) rq[q][k] = q < c.jmax ? rec[(size_t)q * 64 * 3 + k] : -1.0;
-        auto slot = [&](const double code_d, const double meas, const double info) __attribute__((always_inline)) {
-            if (!valid || code_d < 0.0) return;
-            const int code = (int)code_d;
-            const bool own0 = code & 1;
-            const int kind = (code >> 1) & 3, idx = code >> 3;
-            double po[3];
-            if (kind == 0) { const double* an = a.anchors + (size_t)idx * 3; po[0] = an[0]; po[1] = an[1]; po[2] = an[2]; }
-            else if (kind == 1) { po[0] = tq[0]; po[1] = tq[1]; po[2] = tq[2]; }
-            else { const double* tb = TB + 3 * idx; po[0] = tb[0]; po[1] = tb[1]; po[2] = tb[2]; }
-            const EdgeTerms t = own0 ? range_terms<FULL, JAC>(tp, po, kind != 0, meas, info) : range_terms<FULL, JAC>(po, tp, true, meas, info);
-            rsum += t.rho;
-            csum += t.chi;
-            if (FULL) {
-                double Jo[3], Jx[3];   // own / other endpoint
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { Jo[k] = own0 ? t.J0[k] : t.J1[k]; Jx[k] = own0 ? t.J1[k] : t.J0[k]; }
-#pragma unroll
-                for (int rr = 0; rr < 3; ++rr) {
-#pragma unroll
-                    for (int cc = 0; cc <= rr; ++cc) hd[rr * (rr + 1) / 2 + cc] += t.wr * Jo[rr] * Jo[cc];
-                    hb[rr] += Jo[rr] * t.wre;
-                }
-                if (kind == 2) {
-                    double* cs = c.CS + (size_t)idx * 9 * c.npad + r;
-                    const bool again = (mask >> idx) & 1u;
-                    double blk[9], own9[9];
-#pragma unroll
-                    for (int i = 0; i < 3; ++i)
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) blk[3 * i + k] = t.wr * Jx[i] * Jo[k];   // row = the OTHER (border) pose's component, column = own component
-#pragma unroll
-                    for (int rr = 0; rr < 3; ++rr) {
-#pragma unroll
-                        for (int cc = 0; cc <= rr; ++cc) own9[rr * (rr + 1) / 2 + cc] = t.wr * Jx[rr] * Jx[cc];
-                        own9[6 + rr] = Jx[rr] * t.wre;
-                    }
-                    if (is_chain) {
-                        double* bb = c.BB + ((size_t)r * D + 3 * idx) * 3;
-                        if (again) {
-#pragma unroll
-                            for (int k = 0; k < 9; ++k) bb[k] += blk[k];
-                        } else {
-#pragma unroll
-                            for (int k = 0; k < 9; ++k) bb[k] = blk[k];
-                        }
-                    } else {   // block (own border pose ob, other border pose idx < ob) of C: rows = own components, columns = the other's
-#pragma unroll
-                        for (int i = 0; i < 3; ++i)
-#pragma unroll
-                            for (int k = 0; k < 3; ++k) c.C0[tri(3 * ob + k, 3 * idx + i)] += blk[3 * i + k];
-                    }
-                    if (again) {
-#pragma unroll
-                        for (int k = 0; k < 9; ++k) cs[k * c.npad] += own9[k];
-                        ndup += 1;
-                        dup |= 1u << idx;
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 9; ++k) cs[k * c.npad] = own9[k];
-                    }
-                    mask |= 1u << idx;
-                } else if (kind == 1) {   // the edge to the previous chain row (one per pair: checked on the host)
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) { cu[k] = t.wr * Jo[k]; cv[k] = Jx[k]; }
-#pragma unroll
-                    for (int rr = 0; rr < 3; ++rr) {
-#pragma unroll
-                        for (int cc = 0; cc <= rr; ++cc) cp[rr * (rr + 1) / 2 + cc] = t.wr * Jx[rr] * Jx[cc];
-                        cp[6 + rr] = Jx[rr] * t.wre;
-                    }
-                }
-            }
-                };
         for (int j0 = 0; j0 < c.jmax; j0 += PF) {
 #pragma unroll
             for (int q = 0; q < PF; ++q) {
@@ -389,7 +318,85 @@ __device__ __forceinline__ void arrow_edges(const WindowArgs& a, const ArrowCtx&
                     const double* rn = rec + (size_t)(j + PF) * 64 * 3;
                     rq[q][0] = rn[0]; rq[q][1] = rn[1]; rq[q][2] = rn[2];
                 }
-                slot(code_d, meas, info);
+                // (the slot's work is written out here, not in a lambda: inside a lambda the row's register arrays are reached through the
+                //  closure pointer, InstCombine folds `kind == 1 ? tq[k] : tb[k]` into a load through a selected — flat — pointer before the
+                //  lambda is inlined, and tq then lives in scratch memory)
+                if (valid && code_d >= 0.0) {
+                    const int code = (int)code_d;
+                    const bool own0 = code & 1;
+                    const int kind = (code >> 1) & 3, idx = code >> 3;
+                    // The other endpoint by VALUE, never through a pointer chosen among the anchor table (global), the previous row's translation
+                    // (registers) and the border's (LDS): such a pointer is a flat one, the register array behind it is pinned in scratch memory and
+                    // every edge pays a flat load.  The border's translation is read unconditionally (LDS, index 0 when unused).
+                    const double* tb = TB + 3 * (kind == 2 ? idx : 0);
+                    double po0 = kind == 1 ? tq0 : tb[0], po1 = kind == 1 ? tq1 : tb[1], po2 = kind == 1 ? tq2 : tb[2];
+                    if (kind == 0) { const double* an = a.anchors + (size_t)idx * 3; po0 = an[0]; po1 = an[1]; po2 = an[2]; }
+                    const double e0[3] = {own0 ? tp0 : po0, own0 ? tp1 : po1, own0 ? tp2 : po2};
+                    const double e1[3] = {own0 ? po0 : tp0, own0 ? po1 : tp1, own0 ? po2 : tp2};
+                    const EdgeTerms t = range_terms<FULL, JAC>(e0, e1, own0 ? kind != 0 : true, meas, info);
+                    rsum += t.rho;
+                    csum += t.chi;
+                    if (FULL) {
+                        double Jo[3], Jx[3];   // own / other endpoint
+        #pragma unroll
+                        for (int k = 0; k < 3; ++k) { Jo[k] = own0 ? t.J0[k] : t.J1[k]; Jx[k] = own0 ? t.J1[k] : t.J0[k]; }
+        #pragma unroll
+                        for (int rr = 0; rr < 3; ++rr) {
+        #pragma unroll
+                            for (int cc = 0; cc <= rr; ++cc) hd[rr * (rr + 1) / 2 + cc] += t.wr * Jo[rr] * Jo[cc];
+                            hb[rr] += Jo[rr] * t.wre;
+                        }
+                        if (kind == 2) {
+                            double* cs = c.CS + (size_t)idx * 9 * c.npad + r;
+                            const bool again = (mask >> idx) & 1u;
+                            double blk[9], own9[9];
+        #pragma unroll
+                            for (int i = 0; i < 3; ++i)
+        #pragma unroll
+                                for (int k = 0; k < 3; ++k) blk[3 * i + k] = t.wr * Jx[i] * Jo[k];   // row = the OTHER (border) pose's component, column = own component
+        #pragma unroll
+                            for (int rr = 0; rr < 3; ++rr) {
+        #pragma unroll
+                                for (int cc = 0; cc <= rr; ++cc) own9[rr * (rr + 1) / 2 + cc] = t.wr * Jx[rr] * Jx[cc];
+                                own9[6 + rr] = Jx[rr] * t.wre;
+                            }
+                            if (is_chain) {
+                                double* bb = c.BB + ((size_t)r * D + 3 * idx) * 3;
+                                if (again) {
+        #pragma unroll
+                                    for (int k = 0; k < 9; ++k) bb[k] += blk[k];
+                                } else {
+        #pragma unroll
+                                    for (int k = 0; k < 9; ++k) bb[k] = blk[k];
+                                }
+                            } else {   // block (own border pose ob, other border pose idx < ob) of C: rows = own components, columns = the other's
+        #pragma unroll
+                                for (int i = 0; i < 3; ++i)
+        #pragma unroll
+                                    for (int k = 0; k < 3; ++k) c.C0[tri(3 * ob + k, 3 * idx + i)] += blk[3 * i + k];
+                            }
+                            if (again) {
+        #pragma unroll
+                                for (int k = 0; k < 9; ++k) cs[k * c.npad] += own9[k];
+                                ndup += 1;
+                                dup |= 1u << idx;
+                            } else {
+        #pragma unroll
+                                for (int k = 0; k < 9; ++k) cs[k * c.npad] = own9[k];
+                            }
+                            mask |= 1u << idx;
+                        } else if (kind == 1) {   // the edge to the previous chain row (one per pair: checked on the host)
+        #pragma unroll
+                            for (int k = 0; k < 3; ++k) { cu[k] = t.wr * Jo[k]; cv[k] = Jx[k]; }
+        #pragma unroll
+                            for (int rr = 0; rr < 3; ++rr) {
+        #pragma unroll
+                                for (int cc = 0; cc <= rr; ++cc) cp[rr * (rr + 1) / 2 + cc] = t.wr * Jx[rr] * Jx[cc];
+                                cp[6 + rr] = Jx[rr] * t.wre;
+                            }
+                        }
+                    }
+                }
             }
         }
         const double* prec = c.prec + ((size_t)ch * c.jpmax * 64 + lane) * 7;
@@ -399,7 +406,7 @@ __device__ __forceinline__ void arrow_edges(const WindowArgs& a, const ArrowCtx&
             double chi = 0.0;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const double er = tp[k] + pr[1 + k], wd = pr[4 + k];
+                const double er = (k == 0 ? tp0 : k == 1 ? tp1 : tp2) + pr[1 + k], wd = pr[4 + k];
                 chi += er * (wd * er);
                 if (FULL) { hd[k * (k + 1) / 2 + k] += wd; hb[k] += -wd * er; }
             }

@@ -847,8 +847,7 @@ int loc_window_last_host_timing(const loc_window* w, double* out) {
 
 int loc_window_set_endpoint1_offsets(loc_window* w, int64_t n, const double* off1) {
     if (!w || (off1 && (n <= 0 || n > w->B))) return locamd_fail(LOC_ERR_INVALID, "set_endpoint1_offsets");
-    w->topo_cache.valid = false;
-    if (!off1) { w->has_off1 = false; return LOC_OK; }
+    if (!off1) { w->has_off1 = false; return LOC_OK; }   // (has_off1 is part of the structure hash: no cache entry survives a change of it)
     if (w->caps.nr_max <= 0) return locamd_fail(LOC_ERR_INVALID, "set_endpoint1_offsets: no range edges in this solver");
     LOC_HIP(hipSetDevice(w->device));
     if (int rc = wait_resident(w)) return rc;
