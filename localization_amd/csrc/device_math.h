@@ -91,6 +91,38 @@ __device__ __forceinline__ double sqrt_ieee_near(double x, double s0, double h0)
     return __builtin_fma(d, h, s);
 }
 
+// The central root of an edge WITHOUT the +-0 / +inf pass-through, and c = 2 h^3 for sqrt_ieee_near_c: what the fast path of the numeric
+// Jacobians needs (its arguments are >= 1e-5 and < 1e300; callers that may see 0 or inf select afterwards, in the branch that only they take).
+__device__ __forceinline__ double sqrt_ieee_unscaled_raw(double x, double& h_out, double& c_out) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double s = x * y;
+    double h = y * 0.5;
+    const double r = __builtin_fma(-h, s, 0.5);
+    s = __builtin_fma(s, r, s);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-s, s, x);
+    s = __builtin_fma(d, h, s);
+    d = __builtin_fma(-s, s, x);
+    s = __builtin_fma(d, h, s);
+    h_out = h;
+    c_out = (h * h) * (h + h);
+    return s;
+}
+// sqrt_ieee_near with the reciprocal root carried along to FIRST order in the residual instead of by a Newton step: with D = x - s0^2 (exact),
+// 0.5 / sqrt(x) = h0 (1 - 2 h0^2 D + O(e0^2)), so h = h0 - c D, c = 2 h0^3 (once per edge): one instruction instead of two.  h is then off
+// by h0's own error (~5e-15: one Goldschmidt step from the hardware seed) instead of one rounding (1e-16); the last correction
+// s <- s1 + (x - s1^2) h moves s1 by at most an ulp, so the result before the final rounding is off by <= 5e-15 ulp and the rounding
+// goes wrong only for a root within that of a rounding boundary: probability ~1e-14 per evaluation (the Newton form: ~2e-16) — nothing
+// in the 2^28 probed arguments (tools/sqrt_probe.hip), about one perturbed norm in 1e4 benchmark launches, where it moves one Jacobian
+// entry by the 3e-7 relative that the difference quotient's own noise is.  5 instructions.
+__device__ __forceinline__ double sqrt_ieee_near_c(double x, double s0, double h0, double c) {
+    const double D = __builtin_fma(-s0, s0, x);
+    const double s = __builtin_fma(D, h0, s0);
+    const double h = __builtin_fma(-c, D, h0);
+    const double d = __builtin_fma(-s, s, x);
+    return __builtin_fma(d, h, s);
+}
+
 // n = sqrt(x) to 4.1e-15 relative (the Goldschmidt step without the residual correction; profiles/r01_math_probe.txt) and
 // inv = 1/sqrt(x) to 4.2e-15:
 // the range norm of the analytic kernels, where 1e-14 m is five orders below anything the estimate resolves; two

@@ -96,6 +96,7 @@ __device__ __forceinline__ Sys6 evaluate6(const Pose& X, const double (&ax)[M8],
     const double p0y = R[3] * ox + R[4] * oy + R[5] * oz + X.t[1];
     const double p0z = R[6] * ox + R[7] * oy + R[8] * oz + X.t[2];
     const double o2x = 2.0 * ox, o2y = 2.0 * oy, o2z = 2.0 * oz;
+    const bool near_ok = ox * ox + oy * oy + oz * oz <= 1.0;   // (wave-uniform: the lever arm is a launch parameter)
     double P0[3], Pp[6][3], Pm[6][3];
     if (JAC == 1) {
         constexpr double delta = 1e-9;
@@ -134,19 +135,23 @@ __device__ __forceinline__ Sys6 evaluate6(const Pose& X, const double (&ax)[M8],
             J[3] = ry * o2z - rz * o2y; J[4] = rz * o2x - rx * o2z; J[5] = rx * o2y - ry * o2x;  // 2 (uR x o)
         } else {
             const double x0 = sq_to_plain(P0, ax[j], ay[j], az[j]);
-            double h0;
-            const double n0 = sqrt_ieee_unscaled_h(x0, h0);
-            e = dj - n0;
-            if (x0 >= 1e-5 && x0 < 1e300) {   // the twelve perturbed norms from the central one: the same correctly rounded numbers
+            double h0, c0;
+            double n0 = sqrt_ieee_unscaled_raw(x0, h0, c0);   // (+-0 / inf pass-through only in the slow branch: the fast one cannot see them)
+            // the twelve perturbed norms from the central one (device_math.h: sqrt_ieee_near_c): the same correctly rounded numbers as long as the
+            // perturbed antenna point stays within ~2e-9 m of the central one — translations move it by 1e-9, rotations by 2e-9 |lever arm|,
+            // so lever arms of more than a metre take the full square roots, as in wave6_kernel.hip
+            if (x0 >= 1e-5 && x0 < 1e300 && near_ok) {
 #pragma unroll
                 for (int dd = 0; dd < 6; ++dd)
-                    J[dd] = central_difference_plain(dj, sqrt_ieee_near(sq_to_plain(Pp[dd], ax[j], ay[j], az[j]), n0, h0),
-                                                     sqrt_ieee_near(sq_to_plain(Pm[dd], ax[j], ay[j], az[j]), n0, h0));
-            } else {   // an antenna within millimetres of an anchor (or an estimate that has run away)
+                    J[dd] = central_difference_plain(dj, sqrt_ieee_near_c(sq_to_plain(Pp[dd], ax[j], ay[j], az[j]), n0, h0, c0),
+                                                     sqrt_ieee_near_c(sq_to_plain(Pm[dd], ax[j], ay[j], az[j]), n0, h0, c0));
+            } else {   // an antenna within millimetres of an anchor (or an estimate that has run away), or a long lever arm
+                n0 = (x0 == 0.0 || x0 == __builtin_inf()) ? x0 : n0;
 #pragma unroll
                 for (int dd = 0; dd < 6; ++dd)
                     J[dd] = central_difference_plain(dj, norm_to_plain(Pp[dd], ax[j], ay[j], az[j]), norm_to_plain(Pm[dd], ax[j], ay[j], az[j]));
             }
+            e = dj - n0;
         }
         const double we = wj * e;
         const double chi = e * we;

@@ -112,17 +112,18 @@ __device__ __forceinline__ System evaluate(const double px, const double py, con
             constexpr double delta = 1e-9;
             constexpr double scalar = 1.0 / (2 * delta);
             const double x0 = range_sq_plain(dx, dy, dz);
-            double h0;
-            n = sqrt_ieee_unscaled_h(x0, h0);
+            double h0, c0;
+            n = sqrt_ieee_unscaled_raw(x0, h0, c0);   // (no +-0 / inf pass-through here: only the slow branch below can see such an argument)
             const double xp = (px + delta) - ax[j], xm = (px - delta) - ax[j];
             const double yp = (py + delta) - ay[j], ym = (py - delta) - ay[j];
             const double zp = (pz + delta) - az[j], zm = (pz - delta) - az[j];
             if (x0 >= 1e-5 && x0 < 1e300) {
-                // the six perturbed norms from the central one (device_math.h: sqrt_ieee_near — the same correctly rounded numbers)
-                jx = scalar * ((d[j] - sqrt_ieee_near(range_sq_plain(xp, dy, dz), n, h0)) - (d[j] - sqrt_ieee_near(range_sq_plain(xm, dy, dz), n, h0)));
-                jy = scalar * ((d[j] - sqrt_ieee_near(range_sq_plain(dx, yp, dz), n, h0)) - (d[j] - sqrt_ieee_near(range_sq_plain(dx, ym, dz), n, h0)));
-                jz = scalar * ((d[j] - sqrt_ieee_near(range_sq_plain(dx, dy, zp), n, h0)) - (d[j] - sqrt_ieee_near(range_sq_plain(dx, dy, zm), n, h0)));
+                // the six perturbed norms from the central one (device_math.h: sqrt_ieee_near_c — the same correctly rounded numbers)
+                jx = scalar * ((d[j] - sqrt_ieee_near_c(range_sq_plain(xp, dy, dz), n, h0, c0)) - (d[j] - sqrt_ieee_near_c(range_sq_plain(xm, dy, dz), n, h0, c0)));
+                jy = scalar * ((d[j] - sqrt_ieee_near_c(range_sq_plain(dx, yp, dz), n, h0, c0)) - (d[j] - sqrt_ieee_near_c(range_sq_plain(dx, ym, dz), n, h0, c0)));
+                jz = scalar * ((d[j] - sqrt_ieee_near_c(range_sq_plain(dx, dy, zp), n, h0, c0)) - (d[j] - sqrt_ieee_near_c(range_sq_plain(dx, dy, zm), n, h0, c0)));
             } else {   // a tag within millimetres of an anchor (or an estimate that has run away)
+                n = (x0 == 0.0 || x0 == __builtin_inf()) ? x0 : n;
                 jx = scalar * ((d[j] - range_norm_plain(xp, dy, dz)) - (d[j] - range_norm_plain(xm, dy, dz)));
                 jy = scalar * ((d[j] - range_norm_plain(dx, yp, dz)) - (d[j] - range_norm_plain(dx, ym, dz)));
                 jz = scalar * ((d[j] - range_norm_plain(dx, dy, zp)) - (d[j] - range_norm_plain(dx, dy, zm)));

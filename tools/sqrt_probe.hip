@@ -1,6 +1,6 @@
 // Is device_math.h's sqrt_ieee_unscaled bit-identical to the compiler's IEEE f64 sqrt on everything the numeric-Jacobian paths feed it?
 //   hipcc --offload-arch=gfx950 -O3 -I localization_amd/csrc tools/sqrt_probe.hip -o tools/sqrt_probe.bin && tools/sqrt_probe.bin
-// and is sqrt_ieee_near bit-identical to it on the perturbed arguments of g2o's central differences?
+// and are sqrt_ieee_near / sqrt_ieee_near_c bit-identical to it on the perturbed arguments of g2o's central differences?
 // Arguments: 2^26 values log-uniform over [1e-220, 1e220], 2^26 squared distances (dx^2 + dy^2 + dz^2 of ranges 1e-6 .. 1e3 m), and the specials.
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -37,16 +37,17 @@ __global__ void probe_near(unsigned long long* mismatches, double lo_log10, unsi
         for (int k = 0; k < 3; ++k) { a[k] = ((double)(rng(s) >> 11) * (2.0 / 9007199254740992.0) - 1.0) * 20.0; p[k] = a[k] + dir[k] * range; }
         const double dx = p[0] - a[0], dy = p[1] - a[1], dz = p[2] - a[2];
         const double x0 = dx * dx + dy * dy + dz * dz;
-        double h0;
+        double h0, h0r, c0;
         const double s0 = sqrt_ieee_unscaled_h(x0, h0);
-        if (__double_as_longlong(s0) != __double_as_longlong(sqrt(x0))) ++bad;
+        const double s0r = sqrt_ieee_unscaled_raw(x0, h0r, c0);
+        if (__double_as_longlong(s0) != __double_as_longlong(sqrt(x0)) || __double_as_longlong(s0r) != __double_as_longlong(s0)) ++bad;
         for (int ax = 0; ax < 3; ++ax)
             for (int sg = 0; sg < 2; ++sg) {
                 double q[3] = {dx, dy, dz};
                 q[ax] = (sg ? (p[ax] - 1e-9) : (p[ax] + 1e-9)) - a[ax];
                 const double x = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
-                const double want = sqrt(x), got = sqrt_ieee_near(x, s0, h0);
-                if (__double_as_longlong(want) != __double_as_longlong(got)) ++bad;
+                const double want = sqrt(x), got = sqrt_ieee_near(x, s0, h0), got_c = sqrt_ieee_near_c(x, s0r, h0r, c0);
+                if (__double_as_longlong(want) != __double_as_longlong(got) || __double_as_longlong(want) != __double_as_longlong(got_c)) ++bad;
             }
     }
     atomicAdd(mismatches, bad);
