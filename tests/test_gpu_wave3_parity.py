@@ -44,6 +44,7 @@ def test_wave3_kernel_matches_6dof_oracle_and_general_kernel(gpu, T, jac, with_z
     assert s.last_kernel_kind() == "wave3_lm_kernel"
     tol = 1e-7 if jac == "analytic" else 3e-5
     same_it = 0
+    escaped = 0
     for i in range(B):
         nv = int(wb.counts[i, 0])
         if nv == 0 or wb.counts[i, 1] + wb.counts[i, 2] == 0:
@@ -56,11 +57,18 @@ def test_wave3_kernel_matches_6dof_oracle_and_general_kernel(gpu, T, jac, with_z
         dg = np.abs(ref.poses[i, :nv] - poses).max()
         # (numeric mode, 64 poses: the difference quotient's 5e8 turns last-bit differences of the summation order into 1e-4 m on an
         #  unconverged window — the general kernel is then as far from the oracle as this one)
-        assert d < tol or (jac == "numeric" and d < max(2 * dg, tol) and d < 1e-3), (i, d, dg)
+        # numeric mode: 3e-5 m, up to the few windows whose LM accept / reject sequence the 1e-7 noise of the difference quotient flips —
+        # there the general kernel sits as far from the oracle as this one (d < 2 dg), and such windows are COUNTED and bounded below
+        if not d < tol:
+            assert jac == "numeric" and d < max(2 * dg, tol) and d < 1e-3, (i, d, dg)
+            escaped += 1
         assert abs(res[i, 0] - chi) <= (1e-6 if jac == "analytic" else (1e-4 if T < 64 else 1e-3)) * max(1.0, abs(chi)), (i, res[i, 0], chi)
         assert res[i, 7] == nv * 65536 + 2 * nv - 1
         same_it += res[i, 3] == st.outer_iterations
     assert same_it >= 0.9 * B or T == 1   # (a lone well-observed pose converges early: g2o's Terminate is then a rounding-edge event)
+    # none beyond the tolerance in analytic mode and on windows of up to 40 poses; measured on the 64-pose numeric case: 2 of 24 (unconverged
+    # 64-pose windows: the difference quotient's 5e8 turns last-bit differences of the summation order into 1e-4 m)
+    assert escaped <= (B // 8 if (jac == "numeric" and T >= 64) else 0), escaped
     assert np.abs(wb.poses - ref.poses).max() < (tol if jac == "analytic" or T < 64 else 2e-3)   # (both within 1e-3 of the oracle)
     assert np.array_equal(res[:, 6], res_general[:, 6])     # edges sharing their pair with another
     if T > 1:   # (a lone well-observed pose converges early: its remaining accept / reject decisions are taken on rounding-level chi differences)
