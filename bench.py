@@ -51,7 +51,7 @@ _WIN_COMMON = ("window_kernel.h", "device_math.h", "numeric_jacobian.h")
 # per leg: the sources of the kernel that leg runs (one translation unit per kernel since round 4)
 WINDOW_LEG_SOURCES = {"cfg1_windows": ("wave3_kernel.hip",) + _WIN_COMMON,
                       "cfg4": ("arrow3_kernel.hip",) + _WIN_COMMON,
-                      "cfg5": ("tree_kernel.hip", "se3_edge_device.h", "window_device.h") + _WIN_COMMON}
+                      "cfg5": ("tree_wave_kernel.hip", "se3_edge_device.h", "window_device.h") + _WIN_COMMON}
 
 
 def window_traffic(leg, world):
