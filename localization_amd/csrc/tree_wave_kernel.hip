@@ -357,28 +357,38 @@ __global__ void __launch_bounds__(64, 1) tree_wave_kernel(const WindowArgs a, co
         wsync();
     };
     // For every inner node: the sum over its children (LEAVES_ONLY: its leaf children, which come first) of what they put into their `dep`
-    // columns, left in the node's own column.  LANE = (node, ENTRY): lanes 0 .. 26 one entry each of one inner node, lanes 32 .. 58 of the
-    // next — two nodes per round, parents first (a node's own column is overwritten only after its parent has read it: the parent's
-    // reads are issued earlier, in the same or an earlier round).  A node's children are consecutive columns: eight reads with
-    // immediate offsets in flight per lane, summed in list order (fixed order: bit-reproducible).
+    // columns, left in the node's own column.  EIGHT inner nodes per round (parents first), eight lanes per node, each lane four of the
+    // 21 + 6 entries: one ds_bpermute for the node's packed word, then up to 32 independent LDS reads in flight per lane (a node's children
+    // are consecutive columns: immediate offsets), summed in list order (fixed order: bit-reproducible).  A node's own column is
+    // overwritten only after its parent has read it: within a round every read is issued before the first write, and parents come in
+    // the same or an earlier round.
     auto sum_children = [&](const bool leaves_only) __attribute__((always_inline)) {
-        const int half = lane >> 5, e = lane & 31;
-        const double* row = &DEP(e < 27 ? e : 0, 0);
-        for (int r = 0; 2 * r < ts.nu; ++r) {
-            const int ui = 2 * r + half;
+        const int slot = lane >> 3, sub = lane & 7;
+        for (int r0 = 0; r0 < ts.nu; r0 += 8) {
+            const int ui = r0 + slot;
             const int pk = __builtin_amdgcn_ds_bpermute(4 * (ui < 64 ? ui : 63), t_upack);
-            const bool mine = e < 27 && ui < ts.nu;
+            const bool mine = ui < ts.nu;
             const int k0 = pk & 255, cnt = mine ? (leaves_only ? (pk >> 16) & 255 : (pk >> 8) & 255) : 0, own = (pk >> 24) & 255;
-            const double* src = row + k0;
-            double s = 0.0;
-            for (int c0 = 0; __any(c0 < cnt); c0 += 8, src += 8) {
-                double v[8];
+            double s[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int c0 = 0; __any(c0 < cnt); c0 += 8) {
+                double v[4][8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = src[j];
+                for (int i = 0; i < 4; ++i) {
+                    const int e = sub + 8 * i;
+                    const double* src = &DEP(e < 27 ? e : 0, k0 + c0);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) s += c0 + j < cnt ? v[j] : 0.0;
+                    for (int j = 0; j < 8; ++j) v[i][j] = src[j];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) s[i] += c0 + j < cnt ? v[i][j] : 0.0;
             }
-            if (mine) DEP(e, own) = s;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = sub + 8 * i;
+                if (mine && e < 27) DEP(e, own) = s[i];
+            }
         }
     };
     TW_T0();
