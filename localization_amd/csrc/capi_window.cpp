@@ -9,7 +9,9 @@
 #include <algorithm>
 #include <chrono>
 #include <new>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -95,6 +97,20 @@ struct loc_window {
     char *h_stage = nullptr, *d_stage = nullptr;
 };
 static constexpr size_t kStageBytes = 4u << 20;
+
+// The host passes over a batch (validation, structure hash, chain / translation-only scans) are O(instances x edges) and run in front of a
+// kernel of a millisecond or two: batches of >= 4 096 instances are split over up to eight threads (f(lo, hi) on disjoint instance ranges).
+template <class F>
+static void parallel_chunks(int64_t n, F&& f) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nt = n >= 4096 ? (int)std::min<unsigned>(8u, hw ? hw : 1u) : 1;
+    if (nt <= 1) { f((int64_t)0, n, 0); return; }
+    const int64_t per = (n + nt - 1) / nt;
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back([&f, t, per, n] { f(std::min(n, t * per), std::min(n, (t + 1) * per), t); });
+    f((int64_t)0, std::min(n, per), 0);
+    for (auto& x : th) x.join();
+}
 
 extern "C" {
 
@@ -241,29 +257,36 @@ static int validate_instances(const loc_window* w, int64_t n, const int32_t* cou
     const locamd::WindowCaps& c = w->caps;
     if ((c.nr_max && (!r_idx || !r_val)) || (c.np_max && (!p_idx || !p_val)) || (c.ns_max && (!s_idx || !s_val)))
         return locamd_fail(LOC_ERR_INVALID, "missing edge arrays");
-    for (int64_t i = 0; i < n; ++i) {
-        const int32_t* cn = counts + i * 4;
-        if (cn[0] < 0 || cn[0] > c.nv_max || cn[1] < 0 || cn[1] > c.nr_max || cn[2] < 0 || cn[2] > c.np_max || cn[3] < 0 || cn[3] > c.ns_max)
-            return locamd_fail(LOC_ERR_INVALID, "counts exceed capacities");
-        for (int e = 0; e < cn[1]; ++e) {
-            const int32_t* ix = r_idx + ((size_t)i * c.nr_max + e) * 2;
-            if (ix[0] < 0 || ix[0] >= cn[0] || ix[1] >= cn[0] || ix[1] < -w->n_anchors || ix[0] == ix[1])
-                return locamd_fail(LOC_ERR_INVALID, "range edge vertex index");
-            if (ix[1] >= 0 && (ix[0] - ix[1] > c.bw_max || ix[1] - ix[0] > c.bw_max))
-                return locamd_fail(LOC_ERR_INVALID, "range edge couples poses further apart than bw_max");
+    // (the error message is set on the calling thread: the workers only report WHICH check failed first in their range)
+    static const char* const kWhat[] = {nullptr, "counts exceed capacities", "range edge vertex index", "range edge couples poses further apart than bw_max",
+                                        "prior edge vertex index", "SE3 edge vertex index", "SE3 edge couples poses further apart than bw_max"};
+    std::atomic<int> first_bad{0};
+    parallel_chunks(n, [&](int64_t lo, int64_t hi, int) {
+        auto check = [&](int64_t i) -> int {
+            const int32_t* cn = counts + i * 4;
+            if (cn[0] < 0 || cn[0] > c.nv_max || cn[1] < 0 || cn[1] > c.nr_max || cn[2] < 0 || cn[2] > c.np_max || cn[3] < 0 || cn[3] > c.ns_max) return 1;
+            for (int e = 0; e < cn[1]; ++e) {
+                const int32_t* ix = r_idx + ((size_t)i * c.nr_max + e) * 2;
+                if (ix[0] < 0 || ix[0] >= cn[0] || ix[1] >= cn[0] || ix[1] < -w->n_anchors || ix[0] == ix[1]) return 2;
+                if (ix[1] >= 0 && (ix[0] - ix[1] > c.bw_max || ix[1] - ix[0] > c.bw_max)) return 3;
+            }
+            for (int e = 0; e < cn[2]; ++e) {
+                const int32_t v = p_idx[(size_t)i * c.np_max + e];
+                if (v < 0 || v >= cn[0]) return 4;
+            }
+            for (int e = 0; e < cn[3]; ++e) {
+                const int32_t* ix = s_idx + ((size_t)i * c.ns_max + e) * 4;
+                if (ix[0] < 0 || ix[0] >= cn[0] || ix[1] < 0 || ix[1] >= cn[0] || ix[0] == ix[1]) return 5;
+                if (ix[0] - ix[1] > c.bw_max || ix[1] - ix[0] > c.bw_max) return 6;
+            }
+            return 0;
+        };
+        for (int64_t i = lo; i < hi && first_bad.load(std::memory_order_relaxed) == 0; ++i) {
+            const int bad = check(i);
+            if (bad) { int zero = 0; first_bad.compare_exchange_strong(zero, bad); return; }
         }
-        for (int e = 0; e < cn[2]; ++e) {
-            const int32_t v = p_idx[(size_t)i * c.np_max + e];
-            if (v < 0 || v >= cn[0]) return locamd_fail(LOC_ERR_INVALID, "prior edge vertex index");
-        }
-        for (int e = 0; e < cn[3]; ++e) {
-            const int32_t* ix = s_idx + ((size_t)i * c.ns_max + e) * 4;
-            if (ix[0] < 0 || ix[0] >= cn[0] || ix[1] < 0 || ix[1] >= cn[0] || ix[0] == ix[1])
-                return locamd_fail(LOC_ERR_INVALID, "SE3 edge vertex index");
-            if (ix[0] - ix[1] > c.bw_max || ix[1] - ix[0] > c.bw_max)
-                return locamd_fail(LOC_ERR_INVALID, "SE3 edge couples poses further apart than bw_max");
-        }
-    }
+    });
+    if (const int bad = first_bad.load()) return locamd_fail(LOC_ERR_INVALID, kWhat[bad]);
     return LOC_OK;
 }
 
@@ -279,21 +302,27 @@ static bool translation_only(const loc_window* w, int64_t n, const int32_t* coun
     const locamd::WindowCaps& c = w->caps;
     static const double I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     if (w->n_anchors > 500000) return false;   // (the packed endpoint word of chain3 holds 2^19 anchors)
-    for (int64_t i = 0; i < n; ++i) {
-        const int32_t* cn = counts + i * 4;
-        if (cn[3] != 0 || cn[0] > 1048575) return false;
-        for (int e = 0; e < cn[1]; ++e) {
-            const double* v = r_val + ((size_t)i * c.nr_max + e) * 5;
-            if (v[2] != 0.0 || v[3] != 0.0 || v[4] != 0.0) return false;
-        }
-        for (int p = 0; p < cn[0]; ++p)
-            if (std::memcmp(poses + ((size_t)i * c.nv_max + p) * 12, I9, sizeof(I9)) != 0) return false;
-        for (int e = 0; e < cn[2]; ++e) {
-            const double* v = p_val + ((size_t)i * c.np_max + e) * 18;
-            if (std::memcmp(v, I9, sizeof(I9)) != 0 || v[15] != 0.0 || v[16] != 0.0 || v[17] != 0.0) return false;
-        }
-    }
-    return true;
+    std::atomic<bool> all{true};
+    parallel_chunks(n, [&](int64_t lo, int64_t hi, int) {
+        auto one = [&](int64_t i) {
+            const int32_t* cn = counts + i * 4;
+            if (cn[3] != 0 || cn[0] > 1048575) return false;
+            for (int e = 0; e < cn[1]; ++e) {
+                const double* v = r_val + ((size_t)i * c.nr_max + e) * 5;
+                if (v[2] != 0.0 || v[3] != 0.0 || v[4] != 0.0) return false;
+            }
+            for (int p = 0; p < cn[0]; ++p)
+                if (std::memcmp(poses + ((size_t)i * c.nv_max + p) * 12, I9, sizeof(I9)) != 0) return false;
+            for (int e = 0; e < cn[2]; ++e) {
+                const double* v = p_val + ((size_t)i * c.np_max + e) * 18;
+                if (std::memcmp(v, I9, sizeof(I9)) != 0 || v[15] != 0.0 || v[16] != 0.0 || v[17] != 0.0) return false;
+            }
+            return true;
+        };
+        for (int64_t i = lo; i < hi && all.load(std::memory_order_relaxed); ++i)
+            if (!one(i)) { all.store(false); return; }
+    });
+    return all.load();
 }
 
 // CHAIN + BORDER ("arrowhead": BASELINE config 4, anchor self-calibration — a tag trajectory whose poses range to a few nodes that
@@ -649,24 +678,30 @@ static long long tree_min_batch(const loc_window* w) {
 // 64-bit hash of a batch's STRUCTURE: n, the counts and the used entries of the index tables (never the measurements)
 static unsigned long long hash_structure(const loc_window* w, int64_t n, const int32_t* counts, const int32_t* r_idx, const int32_t* p_idx, const int32_t* s_idx) {
     const locamd::WindowCaps& c = w->caps;
-    unsigned long long h = 0x9e3779b97f4a7c15ull ^ (unsigned long long)n ^ (w->has_off1 ? 0x51ull << 56 : 0);
-    auto mix = [&h](const int32_t* p, size_t cnt) {
-        size_t i = 0;
-        for (; i + 2 <= cnt; i += 2) {
-            unsigned long long v;
-            std::memcpy(&v, p + i, 8);
-            h = (h ^ v) * 0xff51afd7ed558ccdull;
-            h ^= h >> 32;
+    unsigned long long part[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // one hash per thread's instance range, combined in range order
+    parallel_chunks(n, [&](int64_t lo, int64_t hi, int t) {
+        unsigned long long h = 0x9e3779b97f4a7c15ull + (unsigned long long)t;
+        auto mix = [&h](const int32_t* p, size_t cnt) {
+            size_t i = 0;
+            for (; i + 2 <= cnt; i += 2) {
+                unsigned long long v;
+                std::memcpy(&v, p + i, 8);
+                h = (h ^ v) * 0xff51afd7ed558ccdull;
+                h ^= h >> 32;
+            }
+            if (i < cnt) { h = (h ^ (unsigned long long)(uint32_t)p[i]) * 0xc4ceb9fe1a85ec53ull; h ^= h >> 29; }
+        };
+        for (int64_t i = lo; i < hi; ++i) {
+            const int32_t* cn = counts + i * 4;
+            mix(cn, 4);
+            if (cn[1]) mix(r_idx + (size_t)i * c.nr_max * 2, (size_t)cn[1] * 2);
+            if (cn[2]) mix(p_idx + (size_t)i * c.np_max, (size_t)cn[2]);
+            if (cn[3]) mix(s_idx + (size_t)i * c.ns_max * 4, (size_t)cn[3] * 4);
         }
-        if (i < cnt) { h = (h ^ (unsigned long long)(uint32_t)p[i]) * 0xc4ceb9fe1a85ec53ull; h ^= h >> 29; }
-    };
-    mix(counts, (size_t)n * 4);
-    for (int64_t i = 0; i < n; ++i) {
-        const int32_t* cn = counts + i * 4;
-        if (cn[1]) mix(r_idx + (size_t)i * c.nr_max * 2, (size_t)cn[1] * 2);
-        if (cn[2]) mix(p_idx + (size_t)i * c.np_max, (size_t)cn[2]);
-        if (cn[3]) mix(s_idx + (size_t)i * c.ns_max * 4, (size_t)cn[3] * 4);
-    }
+        part[t & 7] = h;
+    });
+    unsigned long long h = 0x9e3779b97f4a7c15ull ^ (unsigned long long)n ^ (w->has_off1 ? 0x51ull << 56 : 0);
+    for (int t = 0; t < 8; ++t) { h = (h ^ part[t]) * 0xff51afd7ed558ccdull; h ^= h >> 32; }
     return h;
 }
 
@@ -691,32 +726,42 @@ static int batch_topology(loc_window* w, int which, int64_t n, const int32_t* co
     bool chain = true;
     bool single_pairs = true;   // no EdgeSE3 anywhere and at most one range edge per pair of consecutive poses (wave6_lm_kernel's rank-1 couplings)
     if (hit) { chain = tc.chain; single_pairs = tc.single_pairs; }
-    for (int64_t i = 0; i < n && chain && !hit; ++i) {
-        const int32_t* cn = counts + i * 4;
-        if (cn[3] != 0) single_pairs = false;
-        int last = 0;
-        for (int e = 0; e < cn[3]; ++e) {   // EdgeSE3 factors: between consecutive poses, ordered by their later pose (addTwistEdge)
-            const int32_t* ix = s_idx + ((size_t)i * c.ns_max + e) * 4;
-            const int key2 = ix[1] > ix[0] ? ix[1] : ix[0];
-            if (key2 < last || (ix[0] - ix[1] != 1 && ix[1] - ix[0] != 1)) { chain = false; break; }
-            last = key2;
-        }
-        last = 0;
-        int last_pair = -1;
-        for (int e = 0; e < cn[1] && chain; ++e) {
-            const int32_t* ix = r_idx + ((size_t)i * c.nr_max + e) * 2;
-            const int key2 = ix[1] > ix[0] ? ix[1] : ix[0];
-            if (key2 < last) chain = false;
-            if (ix[1] >= 0) { if (key2 == last_pair) single_pairs = false; last_pair = key2; }
-            last = key2;
-            if (ix[1] >= 0 && ix[0] - ix[1] != 1 && ix[1] - ix[0] != 1) chain = false;
-        }
-        last = 0;
-        for (int e = 0; e < cn[2] && chain; ++e) {
-            const int32_t v = p_idx[(size_t)i * c.np_max + e];
-            if (v < last) chain = false;
-            last = v;
-        }
+    if (!hit) {
+        std::atomic<bool> a_chain{true}, a_single{true};
+        parallel_chunks(n, [&](int64_t lo, int64_t hi, int) {
+            bool chain_l = true, single_l = true;
+            for (int64_t i = lo; i < hi && chain_l && a_chain.load(std::memory_order_relaxed); ++i) {
+                const int32_t* cn = counts + i * 4;
+                if (cn[3] != 0) single_l = false;
+                int last = 0;
+                for (int e = 0; e < cn[3]; ++e) {   // EdgeSE3 factors: between consecutive poses, ordered by their later pose (addTwistEdge)
+                    const int32_t* ix = s_idx + ((size_t)i * c.ns_max + e) * 4;
+                    const int key2 = ix[1] > ix[0] ? ix[1] : ix[0];
+                    if (key2 < last || (ix[0] - ix[1] != 1 && ix[1] - ix[0] != 1)) { chain_l = false; break; }
+                    last = key2;
+                }
+                last = 0;
+                int last_pair = -1;
+                for (int e = 0; e < cn[1] && chain_l; ++e) {
+                    const int32_t* ix = r_idx + ((size_t)i * c.nr_max + e) * 2;
+                    const int key2 = ix[1] > ix[0] ? ix[1] : ix[0];
+                    if (key2 < last) chain_l = false;
+                    if (ix[1] >= 0) { if (key2 == last_pair) single_l = false; last_pair = key2; }
+                    last = key2;
+                    if (ix[1] >= 0 && ix[0] - ix[1] != 1 && ix[1] - ix[0] != 1) chain_l = false;
+                }
+                last = 0;
+                for (int e = 0; e < cn[2] && chain_l; ++e) {
+                    const int32_t v = p_idx[(size_t)i * c.np_max + e];
+                    if (v < last) chain_l = false;
+                    last = v;
+                }
+            }
+            if (!chain_l) a_chain.store(false);
+            if (!single_l) a_single.store(false);
+        });
+        chain = a_chain.load();
+        single_pairs = a_single.load();   // (only meaningful for chain batches, where every range was scanned)
     }
     if (use_cache && !hit) { tc.valid = true; tc.key = key; tc.n = n; tc.chain = chain; tc.single_pairs = single_pairs; tc.tree_tried = false; tc.tree_ok = false; }
     if (chain) {
