@@ -634,7 +634,9 @@ static bool build_tree_sched(loc_window* w, int which, int64_t n, const int32_t*
     }
     A.tsched.nlev = hmax + 1;
     A.tsched.max_se3_per_node = 0;
+    A.tsched.max_r_per_node = 0;
     for (int k = 0; k < nv; ++k) if ((int)se[(size_t)k].size() > A.tsched.max_se3_per_node) A.tsched.max_se3_per_node = (int)se[(size_t)k].size();
+    for (int k = 0; k < nv; ++k) if ((int)re[(size_t)k].size() > A.tsched.max_r_per_node) A.tsched.max_r_per_node = (int)re[(size_t)k].size();
     A.tsched.nv = nv; A.tsched.nr = nr; A.tsched.np = np; A.tsched.ns = ns; A.tsched.depth = maxdepth + 1; A.tsched.nroots = nroots;
     return true;
 }
@@ -766,7 +768,11 @@ static int batch_topology(loc_window* w, int which, int64_t n, const int32_t* co
     if (use_cache && !hit) { tc.valid = true; tc.key = key; tc.n = n; tc.chain = chain; tc.single_pairs = single_pairs; tc.tree_tried = false; tc.tree_ok = false; }
     if (chain) {
         if (translation_only(w, n, counts, poses, r_val, p_val)) return LOC_WINDOW_KERNEL_CHAIN3;
-        return (single_pairs && c.nv_max <= 64 && locamd::window_wave6_lds_bytes(c) <= locamd::kWave6MaxLds) ? LOC_WINDOW_KERNEL_WAVE6 : LOC_WINDOW_KERNEL_CHAIN;
+        if (single_pairs && c.nv_max <= 64 && locamd::window_wave6_lds_bytes(c) <= locamd::kWave6MaxLds) return LOC_WINDOW_KERNEL_WAVE6;
+        // (A node's own 15-pose window with twist EdgeSE3 factors, cfg/uwb_twist.yaml, was also tried on tree_wave_kernel — a chain is a forest,
+        //  rooted at its centre it has 8 levels: 0.58 … 0.67 ms per solve against the general kernel's 0.62 ms; its 21 LM trials each pay seven
+        //  sequential 6x6 eliminations of ~3.9 k cycles in one or two lanes (tools/dev/probe_tree_chain.py).  Not routed.)
+        return LOC_WINDOW_KERNEL_CHAIN;
     }
     {
         // (option "arrow3": 0 = never, 1 = whenever the batch qualifies; default: windows of more than 64 poses — below that the
@@ -962,7 +968,11 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
             // writes 1 KB of results — it does so straight from / to the page-locked staging block (host-coherent memory, mapped
             // into the device's address space), which saves the two DMA operations around a ~75 us kernel.
             const size_t anchor_bytes = (size_t)w->n_anchors * 3 * sizeof(double);
-            const bool zero_copy = (kind == LOC_WINDOW_KERNEL_WAVE3 || kind == LOC_WINDOW_KERNEL_WAVE6) && n <= 4 && w->B <= 4 && w->h_anchors.size() == (size_t)w->n_anchors * 3 &&
+            // (tree_wave_kernel likewise reads its inputs once, in its prologue — unless a pose has priors or more than two range edges, which it
+            //  fetches from memory on every sweep: such windows are copied to the device first)
+            const bool tree_once = kind == LOC_WINDOW_KERNEL_TREE && w->aux[0].tsched.np == 0 && w->aux[0].tsched.max_r_per_node <= 2 &&
+                                   w->aux[0].tsched.max_se3_per_node <= 1 && w->opt.tree != 2;
+            const bool zero_copy = (kind == LOC_WINDOW_KERNEL_WAVE3 || kind == LOC_WINDOW_KERNEL_WAVE6 || tree_once) && n <= 4 && w->B <= 4 && w->h_anchors.size() == (size_t)w->n_anchors * 3 &&
                                    off[9] + anchor_bytes <= kStageBytes && w->opt.zero_copy;
             if (zero_copy) {
                 d = h;

@@ -26,8 +26,8 @@
 //     range that one v_readlane of a packed per-node word yields — eight independent LDS reads in flight per inner node instead of 189
 //     dependent reads (and a table look-up per child) in the node's own lane.
 // HBM traffic per window: the inputs once (poses, the edge records) and the poses out.
-// LDS: 48 x 64 + 27 x 65 doubles = 38 680 B per wave, four waves per CU.  Nodes with more than one range edge, priors, or more than
-// two non-leaf children take (correct, slower) generic loops over the tables in memory.
+// LDS: 48 x 64 + 27 x 65 doubles = 38 680 B per wave, four waves per CU.  Nodes with more than two range edges, or priors, take
+// (correct, slower) generic loops over the tables in memory.
 #include "se3_edge_device.h"
 
 namespace locamd {
@@ -57,6 +57,8 @@ struct LaneNode {
     int rv1;                // first range edge: endpoint 1 (pose slot, or -1 - anchor)
     bool r_first_is_cur;    // ... endpoint 0 (the one with the lever arm) is this node
     int rc0, rc1;           // ... the pose slots of its endpoints (rc1 = rc0 for a fixed endpoint 1)
+    int r2v1, r2c0, r2c1;   // the SECOND range edge likewise (a chain pose: one anchor range + the smoothness range to its neighbour)
+    bool r2_first_is_cur;
     int col;                // the LDS column this node's hand-over to its parent uses = its position in the children list
     int kn0, k1;            // columns of this node's NON-LEAF children: [kn0, k1) (a node's children are consecutive columns, leaves first)
 };
@@ -160,6 +162,8 @@ template <bool FULL, int JAC>
 __device__ __forceinline__ void wave_node_edges(const WindowArgs& a, const TreeSched& ts, long long inst, int lane, const LaneNode& nd,
                                                 const double* sv, const double* xp, const double rm, const double rinfo, const double ro0, const double ro1,
                                                 const double ro2, const double rf0, const double rf1, const double rf2,
+                                                const double qm, const double qinfo, const double qo0, const double qo1, const double qo2,
+                                                const double qf0, const double qf1, const double qf2,
                                                 double& rsum, double& csum, double* D, double* Dp, double* O, int& nbin) {
     const WindowCaps& c = a.caps;
     if (FULL) {
@@ -192,12 +196,16 @@ __device__ __forceinline__ void wave_node_edges(const WindowArgs& a, const TreeS
         csum += chi;
     }
     {
-        // the first range edge's record is in registers; a node with several takes the others from memory, every sweep
+        // the first two range edges' records are in registers; a node with more takes the others from memory, every sweep
         double meas = rm, info = rinfo, o0 = ro0, o1 = ro1, o2 = ro2, f0 = rf0, f1 = rf1, f2 = rf2;
         bool first_is_cur = nd.r_first_is_cur, binary = nd.rv1 >= 0;
         int c0 = nd.rc0, c1 = nd.rc1;
         for (int ri = nd.r0; ri < nd.r1; ++ri) {
-            if (ri != nd.r0) {
+            if (ri == nd.r0 + 1) {
+                meas = qm; info = qinfo; o0 = qo0; o1 = qo1; o2 = qo2; f0 = qf0; f1 = qf1; f2 = qf2;
+                first_is_cur = nd.r2_first_is_cur; binary = nd.r2v1 >= 0;
+                c0 = nd.r2c0; c1 = nd.r2c1;
+            } else if (ri != nd.r0) {
                 const int e = ts.w_rlist[ri];
                 const int v0 = ts.r_idx[2 * e], v1 = ts.r_idx[2 * e + 1];
                 const double* val = a.r_val + ((size_t)inst * c.nr_max + e) * 5;
@@ -275,9 +283,10 @@ __global__ void __launch_bounds__(64, 1) tree_wave_kernel(const WindowArgs a, co
     const int nv = ts.nv;
     const bool node = lane < nv;
     // ---- prologue: everything a sweep needs, once -------------------------------------------------------------------------------------
-    LaneNode nd = {-1, -1, 0, 0, 0, 0, -1, false, false, 0, 0, -1, false, 0, 0, lane, 0, 0};
+    LaneNode nd = {-1, -1, 0, 0, 0, 0, -1, false, false, 0, 0, -1, false, 0, 0, -1, 0, 0, false, lane, 0, 0};
     int kleaf = 0;
     double rm = 0, rinfo = 0, ro0 = 0, ro1 = 0, ro2 = 0, rf0 = 0, rf1 = 0, rf2 = 0;   // first range edge: measurement, information, lever arm; its fixed endpoint
+    double qm = 0, qinfo = 0, qo0 = 0, qo1 = 0, qo2 = 0, qf0 = 0, qf1 = 0, qf2 = 0;   // second range edge
     // the tables the wave walks, one entry per lane: children list, first child / number of children / of leaf children per slot, inner nodes parents first
     int t_upack = 0;   // lane ui: the ui-th inner node (parents first): first child column | children << 8 | leaf children << 16 | own column << 24
     if (node) {
@@ -306,6 +315,19 @@ __global__ void __launch_bounds__(64, 1) tree_wave_kernel(const WindowArgs a, co
             if (nd.rv1 < 0) {
                 const double* an = a.anchors + (size_t)(-1 - nd.rv1) * 3;
                 rf0 = an[0]; rf1 = an[1]; rf2 = an[2];
+            }
+        }
+        if (nd.r0 + 1 < nd.r1) {
+            const int e = ts.w_rlist[nd.r0 + 1];
+            nd.r2c0 = ts.r_idx[2 * e];
+            nd.r2_first_is_cur = nd.r2c0 == lane;
+            nd.r2v1 = ts.r_idx[2 * e + 1];
+            nd.r2c1 = nd.r2v1 >= 0 ? nd.r2v1 : nd.r2c0;
+            const double* val = a.r_val + ((size_t)inst * c.nr_max + e) * 5;
+            qm = val[0]; qinfo = val[1]; qo0 = val[2]; qo1 = val[3]; qo2 = val[4];
+            if (nd.r2v1 < 0) {
+                const double* an = a.anchors + (size_t)(-1 - nd.r2v1) * 3;
+                qf0 = an[0]; qf1 = an[1]; qf2 = an[2];
             }
         }
     }
@@ -401,7 +423,7 @@ __global__ void __launch_bounds__(64, 1) tree_wave_kernel(const WindowArgs a, co
                 double D[27], Dp[27], rs = 0.0, cs = 0.0;
                 int nbin;
                 publish_pose(Xa);
-                if (node) wave_node_edges<true, JAC>(a, ts, inst, lane, nd, sv, dep, rm, rinfo, ro0, ro1, ro2, rf0, rf1, rf2, rs, cs, D, Dp, HO, nbin);
+                if (node) wave_node_edges<true, JAC>(a, ts, inst, lane, nd, sv, dep, rm, rinfo, ro0, ro1, ro2, rf0, rf1, rf2, qm, qinfo, qo0, qo1, qo2, qf0, qf1, qf2, rs, cs, D, Dp, HO, nbin);
                 else {
 #pragma unroll
                     for (int k = 0; k < 27; ++k) { D[k] = 0.0; Dp[k] = 0.0; }
@@ -612,7 +634,7 @@ __global__ void __launch_bounds__(64, 1) tree_wave_kernel(const WindowArgs a, co
                     double rs = 0.0, cs = 0.0, D[1], Dp[1], O[1];
                     int nbin;
                     publish_pose(Xb);
-                    if (node) wave_node_edges<false, JAC>(a, ts, inst, lane, nd, sv, dep, rm, rinfo, ro0, ro1, ro2, rf0, rf1, rf2, rs, cs, D, Dp, O, nbin);
+                    if (node) wave_node_edges<false, JAC>(a, ts, inst, lane, nd, sv, dep, rm, rinfo, ro0, ro1, ro2, rf0, rf1, rf2, qm, qinfo, qo0, qo1, qo2, qf0, qf1, qf2, rs, cs, D, Dp, O, nbin);
                     temp_chi = wave_sum(rs);
                     last_plain = wave_sum(cs);
                 }

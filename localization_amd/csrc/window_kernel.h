@@ -101,7 +101,7 @@ struct TreeSched {
     const int32_t* w_ulist;   // [nu] the inner nodes (height >= 1) by pose slot, PARENTS FIRST (decreasing height)
     const int32_t* w_kpos;    // [nv] a pose's position in w_klist (= the LDS column its hand-over to the parent uses: a node's children are
                               //      consecutive columns); roots: nv - nroots, nv - nroots + 1, ...
-    int nv, nr, np, ns, depth, nroots, nlev, max_se3_per_node, nu;
+    int nv, nr, np, ns, depth, nroots, nlev, max_se3_per_node, nu, max_r_per_node;
 };
 size_t window_tree_workspace_doubles(const WindowCaps& c, long long B);
 hipError_t launch_window_tree(const WindowArgs& a, const TreeSched& ts, double* ws, hipStream_t stream);
