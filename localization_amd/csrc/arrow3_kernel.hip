@@ -145,6 +145,31 @@ __device__ __forceinline__ void wsync_lds() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 }
+// Inclusive scan, over the lanes of a wave, of maps F(z) = c + a (b . z) on 3-vectors under composition, earlier lanes first: afterwards
+// lane l holds the composite of the maps of lanes 0 .. l.  The chain's two substitution sweeps are such recurrences — z_p = L_p^-1 (b_p -
+// u_p (g_p . z_{p-1})) — and their linear part is RANK ONE, which composition preserves: (a_q b_q^T)(a_p b_p^T) = a_q (b_q . a_p) b_p^T.  Six
+// DPP steps (row shifts by 1, 2, 4, 8, then the row broadcasts: the scan the compiler itself emits for wave-wide atomics) instead of 64
+// dependent hand-overs from lane to lane; lanes without a source in a step keep their map.
+struct Map3 { double a0, a1, a2, b0, b1, b2, c0, c1, c2; };
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void map3_scan_step(Map3& m, const bool valid) {
+    const double pa0 = dpp_or_zero<CTRL, ROW_MASK>(m.a0, 0.0), pa1 = dpp_or_zero<CTRL, ROW_MASK>(m.a1, 0.0), pa2 = dpp_or_zero<CTRL, ROW_MASK>(m.a2, 0.0);
+    const double pb0 = dpp_or_zero<CTRL, ROW_MASK>(m.b0, 0.0), pb1 = dpp_or_zero<CTRL, ROW_MASK>(m.b1, 0.0), pb2 = dpp_or_zero<CTRL, ROW_MASK>(m.b2, 0.0);
+    const double pc0 = dpp_or_zero<CTRL, ROW_MASK>(m.c0, 0.0), pc1 = dpp_or_zero<CTRL, ROW_MASK>(m.c1, 0.0), pc2 = dpp_or_zero<CTRL, ROW_MASK>(m.c2, 0.0);
+    const double s1 = m.b0 * pc0 + m.b1 * pc1 + m.b2 * pc2;   // (this map after the earlier one: c' = c + a (b . c_p), a' = a (b . a_p), b' = b_p)
+    const double s2 = m.b0 * pa0 + m.b1 * pa1 + m.b2 * pa2;
+    m.c0 = __builtin_fma(m.a0, s1, m.c0); m.c1 = __builtin_fma(m.a1, s1, m.c1); m.c2 = __builtin_fma(m.a2, s1, m.c2);   // (no source: c_p = 0)
+    m.a0 = valid ? m.a0 * s2 : m.a0; m.a1 = valid ? m.a1 * s2 : m.a1; m.a2 = valid ? m.a2 * s2 : m.a2;
+    m.b0 = valid ? pb0 : m.b0; m.b1 = valid ? pb1 : m.b1; m.b2 = valid ? pb2 : m.b2;
+}
+__device__ __forceinline__ void map3_scan(Map3& m, const int lane) {
+    map3_scan_step<0x111, 0xF>(m, (lane & 15) >= 1);
+    map3_scan_step<0x112, 0xF>(m, (lane & 15) >= 2);
+    map3_scan_step<0x114, 0xF>(m, (lane & 15) >= 4);
+    map3_scan_step<0x118, 0xF>(m, (lane & 15) >= 8);
+    map3_scan_step<0x142, 0xA>(m, ((lane >> 4) & 1) != 0);
+    map3_scan_step<0x143, 0xC>(m, lane >= 32);
+}
 __device__ __forceinline__ double pivot_rsqrtA(double d) {   // window_kernel.hip: pivot_rsqrt
     const double y = __builtin_amdgcn_rsq(d);
     const double t = d * y;
@@ -831,16 +856,19 @@ __device__ __forceinline__ bool arrow_solve(const ArrowCtx& c, double lambda, in
 #pragma unroll
             for (int k = 0; k < 12; ++k) G[k] = live ? c.GZ[12 * p + k] : 0.0;
             if (live) { u0 = c.PK[16 * p + 9]; u1 = c.PK[16 * p + 10]; u2 = c.PK[16 * p + 11]; }
-            double z0 = 0.0, z1 = 0.0, z2 = 0.0;
-            for (int r = 0; r < rows; ++r) {
-                double i0 = lane_from_prev(z0), i1 = lane_from_prev(z1), i2 = lane_from_prev(z2);
-                if (lane == 0) { i0 = cz0; i1 = cz1; i2 = cz2; }
-                const double gz_ = G[9] * i0 + G[10] * i1 + G[11] * i2;   // g_p . z_{p-1}
-                const double r0 = __builtin_fma(-u0, gz_, G[6]), r1 = __builtin_fma(-u1, gz_, G[7]), r2 = __builtin_fma(-u2, gz_, G[8]);
-                z0 = r0 * G[3];
-                z1 = __builtin_fma(-z0, G[0], r1) * G[4];
-                z2 = __builtin_fma(-z1, G[2], __builtin_fma(-z0, G[1], r2)) * G[5];
-            }
+            // z_p = L_p^-1 b_p - (L_p^-1 u_p) (g_p . z_{p-1}): the map (a, b, c) = (-L^-1 u, g, L^-1 b) of every row at once, then the scan
+            Map3 m;
+            m.c0 = G[6] * G[3];
+            m.c1 = __builtin_fma(-m.c0, G[0], G[7]) * G[4];
+            m.c2 = __builtin_fma(-m.c1, G[2], __builtin_fma(-m.c0, G[1], G[8])) * G[5];
+            const double lu0 = u0 * G[3];
+            const double lu1 = __builtin_fma(-lu0, G[0], u1) * G[4];
+            const double lu2 = __builtin_fma(-lu1, G[2], __builtin_fma(-lu0, G[1], u2)) * G[5];
+            m.a0 = -lu0; m.a1 = -lu1; m.a2 = -lu2;
+            m.b0 = G[9]; m.b1 = G[10]; m.b2 = G[11];
+            map3_scan(m, lane);
+            const double bz = m.b0 * cz0 + m.b1 * cz1 + m.b2 * cz2;   // (every lane's composite starts at the chunk's first row: b = that row's g)
+            const double z0 = __builtin_fma(m.a0, bz, m.c0), z1 = __builtin_fma(m.a1, bz, m.c1), z2 = __builtin_fma(m.a2, bz, m.c2);
             if (live) { c.GZ[12 * p + 6] = z0; c.GZ[12 * p + 7] = z1; c.GZ[12 * p + 8] = z2; }
             cz0 = read_lane_dyn(z0, rows - 1); cz1 = read_lane_dyn(z1, rows - 1); cz2 = read_lane_dyn(z2, rows - 1);
         }
@@ -850,33 +878,34 @@ __device__ __forceinline__ bool arrow_solve(const ArrowCtx& c, double lambda, in
         const int nchunks = (s1 - s0 + 63) / 64;
         for (int ch = nchunks - 1; ch >= 0; --ch) {
             const int c0 = s0 + 64 * ch;
-            const int p = c0 + lane;
-            const bool live = p < s1;
             const int rows = s1 - c0 < 64 ? s1 - c0 : 64;
+            // lanes in REVERSE row order (lane 0 = the chunk's last row): the backward recurrence is then the same forward scan of maps
+            // x_p = U_p^-1 z_p - (U_p^-1 g_{p+1}) (u_{p+1} . x_{p+1}), the row after p sitting in the lane before
+            const bool live = lane < rows;
+            const int p = c0 + (live ? rows - 1 - lane : 0);
             double G[12], u0 = 0.0, u1 = 0.0, u2 = 0.0;
 #pragma unroll
             for (int k = 0; k < 12; ++k) G[k] = live ? c.GZ[12 * p + k] : 0.0;
             if (live) { u0 = c.PK[16 * p + 9]; u1 = c.PK[16 * p + 10]; u2 = c.PK[16 * p + 11]; }
-            double nu0 = lane_from_next(u0), nu1 = lane_from_next(u1), nu2 = lane_from_next(u2);
-            double ng0 = lane_from_next(G[9]), ng1 = lane_from_next(G[10]), ng2 = lane_from_next(G[11]);
-            const bool last = lane == rows - 1;
-            if (last) { nu0 = cu0; nu1 = cu1; nu2 = cu2; ng0 = cg0; ng1 = cg1; ng2 = cg2; }
-            double x0 = 0.0, x1 = 0.0, x2 = 0.0;
-            for (int r = 0; r < rows; ++r) {
-                double i0 = lane_from_next(x0), i1 = lane_from_next(x1), i2 = lane_from_next(x2);
-                if (last) { i0 = cx0; i1 = cx1; i2 = cx2; }
-                const double ux = nu0 * i0 + nu1 * i1 + nu2 * i2;
-                double t0 = __builtin_fma(-ng0, ux, G[6]), t1 = __builtin_fma(-ng1, ux, G[7]), t2 = __builtin_fma(-ng2, ux, G[8]);
-                x2 = t2 * G[5];
-                t1 = __builtin_fma(-G[2], x2, t1); t0 = __builtin_fma(-G[1], x2, t0);
-                x1 = t1 * G[4];
-                t0 = __builtin_fma(-G[0], x1, t0);
-                x0 = t0 * G[3];
-            }
+            double nu0 = lane_from_prev(u0), nu1 = lane_from_prev(u1), nu2 = lane_from_prev(u2);
+            double ng0 = lane_from_prev(G[9]), ng1 = lane_from_prev(G[10]), ng2 = lane_from_prev(G[11]);
+            if (lane == 0) { nu0 = cu0; nu1 = cu1; nu2 = cu2; ng0 = cg0; ng1 = cg1; ng2 = cg2; }
+            Map3 m;
+            m.c2 = G[8] * G[5];
+            m.c1 = __builtin_fma(-G[2], m.c2, G[7]) * G[4];
+            m.c0 = __builtin_fma(-G[0], m.c1, __builtin_fma(-G[1], m.c2, G[6])) * G[3];
+            const double w2 = ng2 * G[5];
+            const double w1 = __builtin_fma(-G[2], w2, ng1) * G[4];
+            const double w0 = __builtin_fma(-G[0], w1, __builtin_fma(-G[1], w2, ng0)) * G[3];
+            m.a0 = -w0; m.a1 = -w1; m.a2 = -w2;
+            m.b0 = nu0; m.b1 = nu1; m.b2 = nu2;
+            map3_scan(m, lane);
+            const double bx = m.b0 * cx0 + m.b1 * cx1 + m.b2 * cx2;   // (b of every lane's composite: u of the row after the chunk)
+            const double x0 = __builtin_fma(m.a0, bx, m.c0), x1 = __builtin_fma(m.a1, bx, m.c1), x2 = __builtin_fma(m.a2, bx, m.c2);
             if (live) { c.GZ[12 * p + 6] = x0; c.GZ[12 * p + 7] = x1; c.GZ[12 * p + 8] = x2; }
-            cx0 = read_lane_dyn(x0, 0); cx1 = read_lane_dyn(x1, 0); cx2 = read_lane_dyn(x2, 0);
-            cu0 = read_lane_dyn(u0, 0); cu1 = read_lane_dyn(u1, 0); cu2 = read_lane_dyn(u2, 0);
-            cg0 = read_lane_dyn(G[9], 0); cg1 = read_lane_dyn(G[10], 0); cg2 = read_lane_dyn(G[11], 0);
+            cx0 = read_lane_dyn(x0, rows - 1); cx1 = read_lane_dyn(x1, rows - 1); cx2 = read_lane_dyn(x2, rows - 1);
+            cu0 = read_lane_dyn(u0, rows - 1); cu1 = read_lane_dyn(u1, rows - 1); cu2 = read_lane_dyn(u2, rows - 1);
+            cg0 = read_lane_dyn(G[9], rows - 1); cg1 = read_lane_dyn(G[10], rows - 1); cg2 = read_lane_dyn(G[11], rows - 1);
         }
     }
     __syncthreads();
