@@ -20,7 +20,8 @@
 //   Schur      S = C + lambda I - sum_p F_p F_p^T: a (3 nb) x (3 n) x (3 nb) SYRK — the one GEMM-shaped piece, on the f64 matrix
 //              cores (v_mfma_f64_16x16x4_f64), four poses per step, accumulators in registers for the whole sweep;
 //   border     dense Cholesky of S in LDS (<= 45 x 45, lower triangle packed), the right-hand side riding along as one more row;
-//   chain      z = L^-1 (b_c - B^T x_b), x_c = L^-T z: two more sweeps with lane = row, the 3-vector handed from lane to lane by DPP.
+//   chain      z = L^-1 (b_c - B^T x_b), x_c = L^-T z: two more sweeps with lane = row — recurrences z_p = c_p + a_p (b_p . z_{p-1}) whose
+//              linear part is rank one, run as prefix scans of such maps (map3_scan: six DPP steps per 64 rows; round 4).
 // F is never stored (it would be 184 KB per instance and trial); B is (dense 3x3 blocks in an HBM workspace, streamed: 3 D doubles
 // per chain row, read twice per trial).  What the sequential sweeps touch lives in LDS (26 doubles per chain row + the border's
 // dense arrays), what only thread-parallel phases touch (translations, the stale step, edge records) in HBM with coalesced access.
