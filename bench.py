@@ -636,7 +636,7 @@ def leg_cfg1_node(D, args):
     out["uwb_imu"] = {"workload": "cfg/uwb_imu.yaml on the same recording: 12-pose 6-DoF window, IMU orientation priors, antenna lever arm; numeric Jacobians",
                       "solves": int(len(c_imu) + 20), "ms_per_message_median": float(np.median(c_imu)), "p99": float(np.percentile(c_imu, 99)),
                       "last_solve_inside_library": {"pack_host": pt[0], "window_solve_call": pt[1], "of_which_kernel": pt[2]}}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and D.world == 1:   # (the CPU baseline is timed at N = 1 only: at N > 1 the other ranks would wait for it)
         from oracle import oracle as O
         ora_imu = O.LocalizationOracle(ids, pos, jac_mode=O.JAC_NUMERIC_G2O, antenna_offsets=ant_imu, **kw_imu)
 
@@ -723,7 +723,7 @@ def leg_node_se3(D, args, which):
                "workload": "cfg/uwb_twist.yaml: 15-pose window, range edges + twist EdgeSE3 between consecutive poses, Cauchy, 12 LM iterations; numeric Jacobians",
                "value": float(np.median(lat)), "p99": float(np.percentile(lat, 99)), "solves": int(len(lat) + 20), "kernel": kind, "jacobian": "numeric",
                "last_solve_inside_library": {"pack_host": pt[0], "window_solve_call": pt[1], "of_which_kernel": pt[2]}}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and D.world == 1:
             from oracle import oracle as O
             ora = O.LocalizationOracle(ids, pos, jac_mode=O.JAC_NUMERIC_G2O, **cfg)
             olat, oxyz = replay(ora)
@@ -772,7 +772,7 @@ def leg_node_se3(D, args, which):
                                      "of_which_kernel": float(np.median([p[2] for p in parts]))},
            "value_note": "repeated loc_node_solve calls on the filled window (each continues from the previous estimates, as consecutive messages would)"}
     node.close()
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and D.world == 1:
         from oracle import oracle as O
         ora = O.LocalizationOracle(ids, pos, jac_mode=O.JAC_NUMERIC_G2O, **cfg)
         fill(ora)
