@@ -256,3 +256,27 @@ def test_tree_wave_kernel_on_random_forests(gpu, seed, T, jac):
             assert res[i, 3] == st.outer_iterations
     kids = np.bincount(parent[parent >= 0], minlength=T)
     assert kids.max() >= 4     # (the generator really makes bushy nodes)
+
+
+def test_tree_wave_kernel_on_a_small_handle_reads_the_staging_block_in_place(gpu):
+    """A handle of <= 4 windows whose threshold was lowered runs tree_wave_kernel on the page-locked staging block itself (no copies around the
+    kernel, as for the node's wave3 / wave6 windows) when no pose has priors or more than two ranges — the kernel reads its inputs once, in its
+    prologue; with priors the batch is copied to the device first.  Both against the general kernel."""
+    import localization_amd as la
+    for rich in (False, True):
+        B, T = 2, 24
+        wb = _forest_batch(la, np.random.default_rng(77), B, T, 4, rich)
+        ref = _copy_batch(la, wb)
+        g = la.WindowSolver(ANCH, B, *wb.caps, jacobian="analytic", bw_max=T - 1, chain_threshold=0)
+        g.solve(ref)
+        assert g.last_kernel_kind() == "window_lm_kernel"
+        g.close()
+        s = la.WindowSolver(ANCH, B, *wb.caps, jacobian="analytic", bw_max=T - 1, chain_threshold=1)
+        s.solve(wb)
+        assert s.last_kernel_kind() == "tree_wave_kernel"
+        again = _copy_batch(la, ref); again.poses[:] = _forest_batch(la, np.random.default_rng(77), B, T, 4, rich).poses
+        s.set_option("zero_copy", 0)
+        s.solve(again)
+        s.close()
+        assert np.abs(wb.poses - ref.poses).max() < 1e-7
+        assert np.array_equal(again.poses, wb.poses)          # staged in place or copied first: the same bits
