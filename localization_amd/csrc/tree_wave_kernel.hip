@@ -105,9 +105,13 @@ __device__ __forceinline__ void range_edge_terms(const double meas, const double
             J0[0] = range_jac_numeric<0>(X0, off, X1, p1, 0, meas);
             J0[1] = range_jac_numeric<1>(X0, off, X1, p1, 0, meas);
             J0[2] = range_jac_numeric<2>(X0, off, X1, p1, 0, meas);
-            J0[3] = range_jac_numeric<3>(X0, off, X1, p1, 0, meas);
-            J0[4] = range_jac_numeric<4>(X0, off, X1, p1, 0, meas);
-            J0[5] = range_jac_numeric<5>(X0, off, X1, p1, 0, meas);
+            // With a zero lever arm a rotation of endpoint 0 does not move the ranged point at all: both perturbed evaluations of g2o's central
+            // difference return the same number and the column is exactly +0 — the three columns are skipped when no lane of the wave has a lever arm.
+            if (__any(off0 != 0.0 || off1 != 0.0 || off2 != 0.0)) {
+                J0[3] = range_jac_numeric<3>(X0, off, X1, p1, 0, meas);
+                J0[4] = range_jac_numeric<4>(X0, off, X1, p1, 0, meas);
+                J0[5] = range_jac_numeric<5>(X0, off, X1, p1, 0, meas);
+            } else { J0[3] = 0.0; J0[4] = 0.0; J0[5] = 0.0; }
             if (binary) {
                 J1[0] = range_jac_numeric<0>(X0, off, X1, p1, 1, meas);
                 J1[1] = range_jac_numeric<1>(X0, off, X1, p1, 1, meas);
