@@ -183,7 +183,7 @@ __device__ __forceinline__ double pivot_rsqrtA(double d) {   // window_kernel.hi
 #pragma clang fp contract(off)
 __device__ __forceinline__ double sq3_plainA(double dx, double dy, double dz) { return dx * dx + dy * dy + dz * dz; }
 // g2o's central difference along axis D of endpoint `which` (chain3_kernel.hip: range_jac_numeric3); NEAR: the perturbed norms
-// from the central one n0 (device_math.h: sqrt_ieee_near — the same correctly rounded numbers)
+// from the central one n0 (device_math.h: sqrt_ieee_near_c — the same correctly rounded numbers)
 template <int D, bool NEAR>
 __device__ __forceinline__ double range_jac_numericA(const double* p0, const double* p1, int which, double meas, double n0, double h0) {
     constexpr double delta = 1e-9;
@@ -192,8 +192,8 @@ __device__ __forceinline__ double range_jac_numericA(const double* p0, const dou
     if (which == 0) { a[D] = delta + p0[D]; am[D] = -delta + p0[D]; }
     else { b[D] = delta + p1[D]; bm[D] = -delta + p1[D]; }
     const double xp = sq3_plainA(a[0] - b[0], a[1] - b[1], a[2] - b[2]), xm = sq3_plainA(am[0] - bm[0], am[1] - bm[1], am[2] - bm[2]);
-    const double ep = meas - (NEAR ? sqrt_ieee_near(xp, n0, h0) : sqrt_ieee_unscaled(xp));
-    const double em = meas - (NEAR ? sqrt_ieee_near(xm, n0, h0) : sqrt_ieee_unscaled(xm));
+    const double ep = meas - (NEAR ? sqrt_ieee_near_c(xp, n0, h0, (h0 * h0) * (h0 + h0)) : sqrt_ieee_unscaled(xp));
+    const double em = meas - (NEAR ? sqrt_ieee_near_c(xm, n0, h0, (h0 * h0) * (h0 + h0)) : sqrt_ieee_unscaled(xm));
     double bak = ep;
     bak -= em;
     return scalar * bak;

@@ -74,7 +74,7 @@ __device__ __forceinline__ double pivot_rsqrt3(double d) {   // window_kernel.hi
 __device__ __forceinline__ double sq3_plain(double dx, double dy, double dz) { return dx * dx + dy * dy + dz * dz; }
 // g2o's central difference of e = meas - ||p0 - p1|| along axis D of endpoint `which`'s translation (numeric_jacobian.h /
 // window_kernel.hip: range_jac_numeric with R = I and a zero lever arm: X * fromVectorMQT(+-delta e_D) = (I, t +- delta e_D))
-// NEAR: the perturbed norms from the central one n0 (device_math.h: sqrt_ieee_near — the same correctly rounded numbers)
+// NEAR: the perturbed norms from the central one n0 (device_math.h: sqrt_ieee_near_c — the same correctly rounded numbers)
 template <int D, bool NEAR>
 __device__ __forceinline__ double range_jac_numeric3(const double* p0, const double* p1, int which, double meas, double n0, double h0) {
     constexpr double delta = 1e-9;
@@ -83,8 +83,8 @@ __device__ __forceinline__ double range_jac_numeric3(const double* p0, const dou
     if (which == 0) { a[D] = delta + p0[D]; am[D] = -delta + p0[D]; }
     else { b[D] = delta + p1[D]; bm[D] = -delta + p1[D]; }
     const double xp = sq3_plain(a[0] - b[0], a[1] - b[1], a[2] - b[2]), xm = sq3_plain(am[0] - bm[0], am[1] - bm[1], am[2] - bm[2]);
-    const double ep = meas - (NEAR ? sqrt_ieee_near(xp, n0, h0) : sqrt_ieee_unscaled(xp));
-    const double em = meas - (NEAR ? sqrt_ieee_near(xm, n0, h0) : sqrt_ieee_unscaled(xm));
+    const double ep = meas - (NEAR ? sqrt_ieee_near_c(xp, n0, h0, (h0 * h0) * (h0 + h0)) : sqrt_ieee_unscaled(xp));
+    const double em = meas - (NEAR ? sqrt_ieee_near_c(xm, n0, h0, (h0 * h0) * (h0 + h0)) : sqrt_ieee_unscaled(xm));
     double bak = ep;
     bak -= em;
     return scalar * bak;

@@ -150,7 +150,7 @@ __device__ __forceinline__ double w6_range_sq_plain(const double* R, const doubl
 }
 // one column of g2o's numeric Jacobian (window_kernel.hip: range_jac_numeric; delta = 1e-9 through VertexSE3::oplus) of endpoint
 // `which` (0: the pose carrying the lever arm, 1: the other pose — no lever arm there: its point is its translation).
-// NEAR: the perturbed norms from the central one (device_math.h: sqrt_ieee_near — the same correctly rounded numbers).
+// NEAR: the perturbed norms from the central one (device_math.h: sqrt_ieee_near_c — the same correctly rounded numbers).
 template <int D, bool NEAR>
 __device__ __forceinline__ double w6_jac_numeric(const double* X0, const double* off, const double* X1, const double* q1, int which, double meas,
                                                  double n0, double h0) {
@@ -169,8 +169,8 @@ __device__ __forceinline__ double w6_jac_numeric(const double* X0, const double*
         xp = w6_range_sq_plain(X0, X0 + 9, off, tp);
         xm = w6_range_sq_plain(X0, X0 + 9, off, tm);
     }
-    const double ep = meas - (NEAR ? sqrt_ieee_near(xp, n0, h0) : sqrt_ieee_unscaled(xp));
-    const double em = meas - (NEAR ? sqrt_ieee_near(xm, n0, h0) : sqrt_ieee_unscaled(xm));
+    const double ep = meas - (NEAR ? sqrt_ieee_near_c(xp, n0, h0, (h0 * h0) * (h0 + h0)) : sqrt_ieee_unscaled(xp));
+    const double em = meas - (NEAR ? sqrt_ieee_near_c(xm, n0, h0, (h0 * h0) * (h0 + h0)) : sqrt_ieee_unscaled(xm));
     double bak = ep;
     bak -= em;
     return scalar * bak;
