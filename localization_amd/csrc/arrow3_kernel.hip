@@ -220,6 +220,7 @@ struct ArrowCtx {
     const double *rec, *prec;              // host-packed edge / prior records of this instance
     const int32_t* seg;                    // seg[0 .. nseg]: chain rows of segment s = [seg[s], seg[s + 1])
     int n, nb, D, D16, rows, nseg, jmax, jpmax, tid, lane, wv;
+    unsigned long long jpk0, jpk1, ppk0, ppk1;   // per chunk of 64 rows, one byte each: edge / prior slots really in use (chunks 0 .. 7, 8 .. 15)
 };
 __device__ __forceinline__ int tri(int R, int C) { return R * (R + 1) / 2 + C; }
 
@@ -326,6 +327,10 @@ __device__ __forceinline__ void arrow_edges(const WindowArgs& a, const ArrowCtx&
         double hd[6] = {0, 0, 0, 0, 0, 0}, hb[3] = {0, 0, 0}, cu[3] = {0, 0, 0}, cv[3] = {0, 0, 0}, cp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         unsigned mask = 0, dup = 0;
         int ndup = 0;
+        // (slots in use in THIS chunk: the loop below is as long for ten border rows with three records each as for 64 chain rows with
+        //  fourteen — with rows = 266 the fifth chunk doubled the first wave's share of every sweep)
+        const int jm = ch < 16 ? (int)(((ch < 8 ? c.jpk0 : c.jpk1) >> (8 * (ch & 7))) & 255) : c.jmax;
+        const int jpm = ch < 16 ? (int)(((ch < 8 ? c.ppk0 : c.ppk1) >> (8 * (ch & 7))) & 255) : c.jpmax;
         const double* rec = c.rec + ((size_t)ch * c.jmax * 64 + lane) * 3;
         // the row's records: four slots in flight (one slot ahead, every slot paid an HBM round trip)
         constexpr int PF = 4;
@@ -333,14 +338,14 @@ __device__ __forceinline__ void arrow_edges(const WindowArgs& a, const ArrowCtx&
 #pragma unroll
         for (int q = 0; q < PF; ++q)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) rq[q][k] = q < c.jmax ? rec[(size_t)q * 64 * 3 + k] : -1.0;
-        for (int j0 = 0; j0 < c.jmax; j0 += PF) {
+            for (int k = 0; k < 3; ++k) rq[q][k] = q < jm ? rec[(size_t)q * 64 * 3 + k] : -1.0;
+        for (int j0 = 0; j0 < jm; j0 += PF) {
 #pragma unroll
             for (int q = 0; q < PF; ++q) {
                 const int j = j0 + q;
-                if (j >= c.jmax) break;
+                if (j >= jm) break;
                 const double code_d = rq[q][0], meas = rq[q][1], info = rq[q][2];
-                if (j + PF < c.jmax) {
+                if (j + PF < jm) {
                     const double* rn = rec + (size_t)(j + PF) * 64 * 3;
                     rq[q][0] = rn[0]; rq[q][1] = rn[1]; rq[q][2] = rn[2];
                 }
@@ -426,7 +431,7 @@ __device__ __forceinline__ void arrow_edges(const WindowArgs& a, const ArrowCtx&
             }
         }
         const double* prec = c.prec + ((size_t)ch * c.jpmax * 64 + lane) * 7;
-        for (int j = 0; j < c.jpmax; ++j) {   // priors: e = t + Z^-1.t, diagonal translation information, no robust kernel
+        for (int j = 0; j < jpm; ++j) {   // priors: e = t + Z^-1.t, diagonal translation information, no robust kernel
             const double* pr = prec + (size_t)j * 64 * 7;
             if (!valid || pr[0] <= 0.0) continue;
             double chi = 0.0;
@@ -941,6 +946,12 @@ __global__ void __launch_bounds__(64 * ARROW_NW, 1) arrow3_lm_kernel(const Windo
     const int Dm = 3 * x.nb_max, D16m = 16 * ((Dm + 15) / 16);
     c.D16 = D16m;   // (FX rows: the batch's tile count)
     c.jmax = x.jmax; c.jpmax = x.jpmax;
+    c.jpk0 = 0; c.jpk1 = 0; c.ppk0 = 0; c.ppk1 = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        c.jpk0 |= (unsigned long long)(x.jch[k] & 255) << (8 * k); c.jpk1 |= (unsigned long long)(x.jch[8 + k] & 255) << (8 * k);
+        c.ppk0 |= (unsigned long long)(x.jpch[k] & 255) << (8 * k); c.ppk1 |= (unsigned long long)(x.jpch[8 + k] & 255) << (8 * k);
+    }
     const int n = c.n, nb = c.nb, D = c.D;
     {   // LDS carve-up (sized by the batch's capacities: arrow3_lds_doubles)
         double* q = ldsA;

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -53,6 +54,7 @@ struct loc_window {
         double *d_arec = nullptr, *d_aprec = nullptr;
         size_t arec_cap = 0, aprec_cap = 0;   // doubles allocated
         int arrow_nb_max = 0, arrow_jmax = 0, arrow_jpmax = 0;
+        int arrow_jch[16] = {0}, arrow_jpch[16] = {0};   // records per chunk of 64 rows (the most any row of the chunk has, over the batch)
         std::vector<int32_t> h_ahdr, h_arslot;
         std::vector<double> h_arec, h_aprec;
     } aux[2];
@@ -345,6 +347,8 @@ static bool build_arrow_aux(loc_window* w, int which, int64_t n, const int32_t* 
     std::vector<int> seps;
     // pass 1: structure, record counts
     int nb_max = 0, jmax = 1, jpmax = 1;
+    int jch[16], jpch[16];
+    for (int k = 0; k < 16; ++k) { jch[k] = 1; jpch[k] = 1; }
     for (int64_t i = 0; i < n; ++i) {
         const int32_t* cn = counts + i * 4;
         const int nv = cn[0], nr = cn[1], np = cn[2];
@@ -392,11 +396,13 @@ static bool build_arrow_aux(loc_window* w, int which, int64_t n, const int32_t* 
                 else row = nc + ((-1 - c0) > (-1 - c1) ? (-1 - c0) : (-1 - c1));
             }
             if (++nedge[row] > jmax) jmax = nedge[row];
+            if (row / 64 < 16 && nedge[row] > jch[row / 64]) jch[row / 64] = nedge[row];
         }
         const int32_t* pi = p_idx + (size_t)i * c.np_max;
         for (int e = 0; e < np; ++e) {
             const int cv = cls[pi[e]], row = cv >= 0 ? cv : nc + (-1 - cv);
             if (++nprior[row] > jpmax) jpmax = nprior[row];
+            if (row / 64 < 16 && nprior[row] > jpch[row / 64]) jpch[row / 64] = nprior[row];
         }
         if (nb > nb_max) nb_max = nb;
     }
@@ -447,6 +453,7 @@ static bool build_arrow_aux(loc_window* w, int which, int64_t n, const int32_t* 
         }
     }
     A.arrow_nb_max = nb_max; A.arrow_jmax = jmax; A.arrow_jpmax = jpmax;
+    for (int k = 0; k < 16; ++k) { A.arrow_jch[k] = jch[k]; A.arrow_jpch[k] = jpch[k]; }
     return true;
 }
 static hipError_t upload_arrow_aux(loc_window* w, int which, int64_t n, hipStream_t st) {
@@ -836,6 +843,7 @@ static hipError_t launch_any(loc_window* w, int which, const locamd::WindowArgs&
         locamd::ArrowAux x;
         x.hdr = A.d_ahdr; x.rslot = A.d_arslot; x.rec = A.d_arec; x.prec = A.d_aprec;
         x.ws = w->d_arrow_ws; x.nb_max = A.arrow_nb_max; x.jmax = A.arrow_jmax; x.jpmax = A.arrow_jpmax; x.nchunk = (w->caps.nv_max + 63) / 64;
+        for (int k = 0; k < 16; ++k) { x.jch[k] = A.arrow_jch[k]; x.jpch[k] = A.arrow_jpch[k]; }
         return locamd::launch_window_arrow3(a, x, st);
     }
     if (kind == LOC_WINDOW_KERNEL_TREE) {   // (option "tree" = 2: the one-lane-per-window variant, for A/B runs)

@@ -78,6 +78,7 @@ struct ArrowAux {
     const double* prec;     // [B][nchunk][jpmax][64][7] flag (> 0: a prior), Z^-1.t (3), information diagonal (3)
     double* ws;             // [B][window_arrow3_workspace_doubles]
     int nb_max, jmax, jpmax, nchunk;
+    int jch[16], jpch[16];  // per chunk of 64 rows: the most edge / prior records any of its rows has, over the batch (<= jmax, jpmax; chunks from 16 on: jmax, jpmax)
 };
 size_t window_arrow3_workspace_doubles(const WindowCaps& c, int nb_max);
 size_t window_arrow3_lds_bytes(const WindowCaps& c, int nb_max);
