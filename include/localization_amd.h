@@ -255,7 +255,8 @@ int loc_window_set_chain_threshold(loc_window* w, int64_t min_batch);
 enum { LOC_WINDOW_KERNEL_NONE = -1, LOC_WINDOW_KERNEL_GENERAL = 0, LOC_WINDOW_KERNEL_CHAIN = 1, LOC_WINDOW_KERNEL_CHAIN3 = 2, LOC_WINDOW_KERNEL_ARROW3 = 3, LOC_WINDOW_KERNEL_TREE = 4,
        LOC_WINDOW_KERNEL_TREE_LANE = 5 /* reported only: the lane-per-window variant of TREE ran */,
        LOC_WINDOW_KERNEL_WAVE3 = 6 /* translation-only chains of <= 64 poses: one wave per window (wave3_lm_kernel) */,
-       LOC_WINDOW_KERNEL_WAVE6 = 7 /* 6-DoF chains of <= 64 poses (no EdgeSE3, one range edge per consecutive pair): wave6_lm_kernel */ };
+       LOC_WINDOW_KERNEL_WAVE6 = 7 /* 6-DoF chains of <= 64 poses (no EdgeSE3, one range edge per consecutive pair): wave6_lm_kernel */,
+       LOC_WINDOW_KERNEL_WAVE6S = 8 /* the same with EdgeSE3 factors between consecutive poses (cfg/uwb_twist.yaml), at most one per pair: wave6_lm_kernel<.., SE3> */ };
 int loc_window_last_kernel_kind(const loc_window* w, int32_t* kind);
 /* Kernel-selection switches of ONE handle.  They are read from the environment ONCE, when the handle is created (LOCAMD_CHAIN_MIN_BATCH,
  * LOCAMD_ARROW3, LOCAMD_TREE, LOCAMD_WAVE3, LOCAMD_WAVE6, LOCAMD_CHAIN3, LOCAMD_NO_ZERO_COPY: A/B runs and tests), never at solve

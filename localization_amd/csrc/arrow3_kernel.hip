@@ -66,7 +66,7 @@ size_t window_arrow3_workspace_doubles(const WindowCaps& c, int nb_max) { return
 // doubles of LDS per instance
 static __host__ __device__ inline size_t arrow3_lds_doubles(int nv_max, int nb_max) {
     const size_t D = 3 * (size_t)nb_max, D16 = 16 * ((D + 15) / 16);
-    return (size_t)nv_max * 28 + D * (D + 1) / 2 + (D + 1) * (D + 2) / 2 + 3 * D + ARROW_NW * D + ARROW_NW * 4 * D16 * 3 + 6 * (size_t)nb_max + 16;
+    return (size_t)nv_max * 28 + D * (D + 1) / 2 + (D + 1) * (D + 2) / 2 + 3 * D + ARROW_NW * D + ARROW_NW * 4 * D16 * 3 + 6 * (size_t)nb_max + 16 + 3 * (size_t)kArrowMaxAnchors;
 }
 size_t window_arrow3_lds_bytes(const WindowCaps& c, int nb_max) { return arrow3_lds_doubles(c.nv_max, nb_max) * sizeof(double); }
 
@@ -210,6 +210,7 @@ struct ArrowCtx {
     double *RA;                            // [NW][D] the segments' shares of the border's right-hand side
     double *FX;                            // [NW][4][D16][3]
     double *TB;                            // [2][nb][3] border translations (state / trial state)
+    double *AN;                            // [kArrowMaxAnchors][3] the fixed anchors an edge may name (the host checks the indices)
     double *red;                           // block reductions
     // HBM
     double *TT;                            // [2][n][3] chain translations by row
@@ -332,36 +333,51 @@ __device__ __forceinline__ void arrow_edges(const WindowArgs& a, const ArrowCtx&
         const int jm = ch < 16 ? (int)(((ch < 8 ? c.jpk0 : c.jpk1) >> (8 * (ch & 7))) & 255) : c.jmax;
         const int jpm = ch < 16 ? (int)(((ch < 8 ? c.ppk0 : c.ppk1) >> (8 * (ch & 7))) & 255) : c.jpmax;
         const double* rec = c.rec + ((size_t)ch * c.jmax * 64 + lane) * 3;
-        // the row's records: four slots in flight (one slot ahead, every slot paid an HBM round trip)
-        constexpr int PF = 4;
-        double rq[PF][3];
+        // The row's records, NS slots per block: the next block's 3 NS loads are issued before this block's first slot and awaited after its
+        // last one.  vmcnt counts loads AND stores on gfx9 and the two return out of order, so the wait for ANY load in a stream of stores is
+        // `s_waitcnt vmcnt(0)` — with a load (a record one slot ahead, an anchor) inside the slot every slot drained the stores of the slot
+        // before it (~1.5 k cycles of ~5 k per slot).  One rolled slot body: the block's records sit in a register array that shifts down by
+        // one entry per slot (constant indices only: no scratch), a quarter of the code of four unrolled slots.
+        constexpr int NS = 8;
+        double rq[NS][3], rn[NS][3];
 #pragma unroll
-        for (int q = 0; q < PF; ++q)
+        for (int q = 0; q < NS; ++q) {
+            const double* rp = rec + (size_t)(q < c.jmax ? q : c.jmax - 1) * 64 * 3;   // (slots jm .. jmax - 1 exist and hold code -1)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) rq[q][k] = q < jm ? rec[(size_t)q * 64 * 3 + k] : -1.0;
-        for (int j0 = 0; j0 < jm; j0 += PF) {
+            for (int k = 0; k < 3; ++k) rn[q][k] = rp[k];
+        }
+        for (int j0 = 0; j0 < jm; j0 += NS) {
 #pragma unroll
-            for (int q = 0; q < PF; ++q) {
-                const int j = j0 + q;
-                if (j >= jm) break;
-                const double code_d = rq[q][0], meas = rq[q][1], info = rq[q][2];
-                if (j + PF < jm) {
-                    const double* rn = rec + (size_t)(j + PF) * 64 * 3;
-                    rq[q][0] = rn[0]; rq[q][1] = rn[1]; rq[q][2] = rn[2];
+            for (int q = 0; q < NS; ++q)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) rq[q][k] = rn[q][k];
+            if (j0 + NS < jm) {
+#pragma unroll
+                for (int q = 0; q < NS; ++q) {
+                    const int jn = j0 + NS + q;
+                    const double* rp = rec + (size_t)(jn < c.jmax ? jn : c.jmax - 1) * 64 * 3;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) rn[q][k] = rp[k];
                 }
-                // (the slot's work is written out here, not in a lambda: inside a lambda the row's register arrays are reached through the
-                //  closure pointer, InstCombine folds `kind == 1 ? tq[k] : tb[k]` into a load through a selected — flat — pointer before the
-                //  lambda is inlined, and tq then lives in scratch memory)
+            }
+            const int jend = jm - j0 < NS ? jm - j0 : NS;
+#pragma nounroll
+            for (int q = 0; q < jend; ++q) {
+                const double code_d = rq[0][0], meas = rq[0][1], info = rq[0][2];
+#pragma unroll
+                for (int t = 0; t + 1 < NS; ++t)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) rq[t][k] = rq[t + 1][k];
                 if (valid && code_d >= 0.0) {
                     const int code = (int)code_d;
                     const bool own0 = code & 1;
                     const int kind = (code >> 1) & 3, idx = code >> 3;
                     // The other endpoint by VALUE, never through a pointer chosen among the anchor table (global), the previous row's translation
                     // (registers) and the border's (LDS): such a pointer is a flat one, the register array behind it is pinned in scratch memory and
-                    // every edge pays a flat load.  The border's translation is read unconditionally (LDS, index 0 when unused).
-                    const double* tb = TB + 3 * (kind == 2 ? idx : 0);
+                    // every edge pays a flat load.  Anchors and border translations are both read from LDS, unconditionally (index 0 when unused):
+                    // a global load here would put an `s_waitcnt vmcnt(0)` in front of every slot — on gfx9 that also drains the slot before's stores.
+                    const double* tb = kind == 0 ? c.AN + 3 * idx : TB + 3 * (kind == 2 ? idx : 0);   // (both LDS)
                     double po0 = kind == 1 ? tq0 : tb[0], po1 = kind == 1 ? tq1 : tb[1], po2 = kind == 1 ? tq2 : tb[2];
-                    if (kind == 0) { const double* an = a.anchors + (size_t)idx * 3; po0 = an[0]; po1 = an[1]; po2 = an[2]; }
                     const double e0[3] = {own0 ? tp0 : po0, own0 ? tp1 : po1, own0 ? tp2 : po2};
                     const double e1[3] = {own0 ? po0 : tp0, own0 ? po1 : tp1, own0 ? po2 : tp2};
                     const EdgeTerms t = range_terms<FULL, JAC>(e0, e1, own0 ? kind != 0 : true, meas, info);
@@ -430,6 +446,7 @@ __device__ __forceinline__ void arrow_edges(const WindowArgs& a, const ArrowCtx&
                 }
             }
         }
+        if (FULL) { AT2(7); }
         const double* prec = c.prec + ((size_t)ch * c.jpmax * 64 + lane) * 7;
         for (int j = 0; j < jpm; ++j) {   // priors: e = t + Z^-1.t, diagonal translation information, no robust kernel
             const double* pr = prec + (size_t)j * 64 * 7;
@@ -487,34 +504,51 @@ __device__ __forceinline__ void arrow_edges(const WindowArgs& a, const ArrowCtx&
         AT2(2);
         // a border pose's diagonal block and b: the sum over all rows of the shares left in CS — one wave per (border pose, entry),
         // lane partial sums over its rows then the DPP tree: one fixed order
-        for (int t0 = 8 * c.wv; t0 < nb * 9; t0 += 8 * ARROW_NW) {   // (eight sums' loads in flight before the first DPP tree)
-            double sp[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            for (int ck0 = 0; ck0 * 64 < rows; ck0 += 4) {   // 32 independent loads, then the sums (fixed order)
-                double v[8][4];
+        // (a sum's chunks are added in groups of four — (v0 + v1) + (v2 + v3) — in chunk order: one fixed order.  SIXTEEN sums per wave and
+        //  round with the loads of FIVE chunks (cfg4's 266 rows) issued before the first addition: a round is one HBM round trip, and with
+        //  eight sums and a second pass for the fifth chunk a linearisation paid eight of them here instead of two.)
+        constexpr int CSU = 16;
+        for (int t0 = CSU * c.wv; t0 < nb * 9; t0 += CSU * ARROW_NW) {
+            double sp[CSU];
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < CSU; ++u) sp[u] = 0.0;
+            for (int ck0 = 0; ck0 * 64 < rows; ck0 += 5) {
+                double v[CSU][5];
 #pragma unroll
-                    for (int c4 = 0; c4 < 4; ++c4) {
-                        const int p = (ck0 + c4) * 64 + lane;
-                        v[u][c4] = (t0 + u < nb * 9 && p < rows) ? c.CS[(size_t)(t0 + u) * c.npad + p] : 0.0;
+                for (int u = 0; u < CSU; ++u)
+#pragma unroll
+                    for (int c5 = 0; c5 < 5; ++c5) {
+                        const int p = (ck0 + c5) * 64 + lane;
+                        v[u][c5] = (t0 + u < nb * 9 && p < rows) ? c.CS[(size_t)(t0 + u) * c.npad + p] : 0.0;
                     }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) sp[u] += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+                for (int u = 0; u < CSU; ++u) {
+                    sp[u] += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+                    sp[u] += v[u][4];
+                }
             }
+            AT2(5);
+            // the CSU DPP trees step by step side by side (independent chains: no dependent-issue stalls); the totals end up in lane 63
+#define LOCAMD_CS_STEP(CTRL, MASK) _Pragma("unroll") for (int u = 0; u < CSU; ++u) sp[u] += dpp_or_zero<CTRL, MASK>(sp[u], 0.0)
+            LOCAMD_CS_STEP(0x111, 0xF); LOCAMD_CS_STEP(0x112, 0xF); LOCAMD_CS_STEP(0x114, 0xF); LOCAMD_CS_STEP(0x118, 0xF);
+            LOCAMD_CS_STEP(0x142, 0xA); LOCAMD_CS_STEP(0x143, 0xC);
+#undef LOCAMD_CS_STEP
+            if (lane == 63) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const double sv = wave_sum(sp[u]);
-                const int t = t0 + u;
-                if (lane == 0 && t < nb * 9) {
-                    const int xb = t / 9, k = t % 9;
-                    if (k < 6) {
-                        const int rr = k < 1 ? 0 : (k < 3 ? 1 : 2), cc = k - rr * (rr + 1) / 2;
-                        c.C0[tri(3 * xb + rr, 3 * xb + cc)] = sv;
-                    } else {
-                        c.bB[3 * xb + k - 6] = sv;
+                for (int u = 0; u < CSU; ++u) {
+                    const int t = t0 + u;
+                    if (t < nb * 9) {
+                        const int xb = t / 9, k = t % 9;
+                        if (k < 6) {
+                            const int rr = k < 1 ? 0 : (k < 3 ? 1 : 2), cc = k - rr * (rr + 1) / 2;
+                            c.C0[tri(3 * xb + rr, 3 * xb + cc)] = sp[u];
+                        } else {
+                            c.bB[3 * xb + k - 6] = sp[u];
+                        }
                     }
                 }
             }
+            AT2(6);
         }
         __syncthreads();
         AT2(3);
@@ -961,7 +995,8 @@ __global__ void __launch_bounds__(64 * ARROW_NW, 1) arrow3_lm_kernel(const Windo
         c.RA = q; q += (size_t)ARROW_NW * Dm;
         c.FX = q; q += (size_t)ARROW_NW * 4 * D16m * 3;
         c.TB = q; q += (size_t)6 * x.nb_max;
-        c.red = q;
+        c.red = q; q += 16;
+        c.AN = q;
     }
     {
         double* w = x.ws + (size_t)inst * window_arrow3_workspace_doubles_dev(cp, x.nb_max);
@@ -979,6 +1014,7 @@ __global__ void __launch_bounds__(64 * ARROW_NW, 1) arrow3_lm_kernel(const Windo
     for (int i = tid; i < 3 * n; i += 64 * ARROW_NW) { c.TT[i] = gin[rslot[i / 3] * 12 + 9 + i % 3]; c.XS[i] = 0.0; }
     for (int r = tid; r < D; r += 64 * ARROW_NW) { c.TB[r] = gin[rslot[n + r / 3] * 12 + 9 + r % 3]; c.xsB[r] = 0.0; }
     for (int i = tid; i < ARROW_NW * Dm; i += 64 * ARROW_NW) c.RA[i] = 0.0;
+    for (int i = tid; i < 3 * (a.n_anchors < kArrowMaxAnchors ? a.n_anchors : kArrowMaxAnchors); i += 64 * ARROW_NW) c.AN[i] = a.anchors[i];
     if (tid < 16) c.red[tid] = 0.0;
     __threadfence_block();
     __syncthreads();

@@ -85,7 +85,7 @@ struct loc_window {
         bool valid = false;
         unsigned long long key = 0;
         int64_t n = 0;
-        bool chain = false, single_pairs = false, tree_ok = false, tree_tried = false;
+        bool chain = false, single_pairs = false, se3_pairs = false, tree_ok = false, tree_tried = false;
     } topo_cache;
     double t_validate_ms = 0, t_topology_ms = 0, t_run_ms = 0;   // loc_window_last_host_timing
     bool t_cached = false;
@@ -356,7 +356,10 @@ static bool build_arrow_aux(loc_window* w, int which, int64_t n, const int32_t* 
         int nb0 = 0;
         for (int e = 0; e < nr; ++e) {
             const int v0 = ri[2 * e], v1 = ri[2 * e + 1];
-            if (v1 < 0) continue;
+            if (v1 < 0) {
+                if (-1 - v1 >= locamd::kArrowMaxAnchors) return false;   // (the kernel keeps the anchor table in LDS)
+                continue;
+            }
             const int hi = v0 > v1 ? v0 : v1, lo = v0 > v1 ? v1 : v0;
             if (hi - lo != 1 && nv - hi > nb0) nb0 = nv - hi;
         }
@@ -734,19 +737,21 @@ static int batch_topology(loc_window* w, int which, int64_t n, const int32_t* co
     if (which == 0) w->t_cached = hit;
     bool chain = true;
     bool single_pairs = true;   // no EdgeSE3 anywhere and at most one range edge per pair of consecutive poses (wave6_lm_kernel's rank-1 couplings)
-    if (hit) { chain = tc.chain; single_pairs = tc.single_pairs; }
+    bool se3_pairs = false;     // EdgeSE3 factors, at most one per pair of consecutive poses, and at most one range edge per pair (wave6_lm_kernel<JAC, true>)
+    if (hit) { chain = tc.chain; single_pairs = tc.single_pairs; se3_pairs = tc.se3_pairs; }
     if (!hit) {
-        std::atomic<bool> a_chain{true}, a_single{true};
+        std::atomic<bool> a_chain{true}, a_single{true}, a_single_r{true}, a_single_s{true}, a_any_s{false};
         parallel_chunks(n, [&](int64_t lo, int64_t hi, int) {
-            bool chain_l = true, single_l = true;
+            bool chain_l = true, single_l = true, single_r = true, single_s = true, any_s = false;
             for (int64_t i = lo; i < hi && chain_l && a_chain.load(std::memory_order_relaxed); ++i) {
                 const int32_t* cn = counts + i * 4;
-                if (cn[3] != 0) single_l = false;
+                if (cn[3] != 0) { single_l = false; any_s = true; }
                 int last = 0;
                 for (int e = 0; e < cn[3]; ++e) {   // EdgeSE3 factors: between consecutive poses, ordered by their later pose (addTwistEdge)
                     const int32_t* ix = s_idx + ((size_t)i * c.ns_max + e) * 4;
                     const int key2 = ix[1] > ix[0] ? ix[1] : ix[0];
                     if (key2 < last || (ix[0] - ix[1] != 1 && ix[1] - ix[0] != 1)) { chain_l = false; break; }
+                    if (key2 == last) single_s = false;   // (a second EdgeSE3 on the same pair; poses are numbered from 0, so `last` = 0 is no pair)
                     last = key2;
                 }
                 last = 0;
@@ -755,7 +760,7 @@ static int batch_topology(loc_window* w, int which, int64_t n, const int32_t* co
                     const int32_t* ix = r_idx + ((size_t)i * c.nr_max + e) * 2;
                     const int key2 = ix[1] > ix[0] ? ix[1] : ix[0];
                     if (key2 < last) chain_l = false;
-                    if (ix[1] >= 0) { if (key2 == last_pair) single_l = false; last_pair = key2; }
+                    if (ix[1] >= 0) { if (key2 == last_pair) { single_l = false; single_r = false; } last_pair = key2; }
                     last = key2;
                     if (ix[1] >= 0 && ix[0] - ix[1] != 1 && ix[1] - ix[0] != 1) chain_l = false;
                 }
@@ -768,17 +773,22 @@ static int batch_topology(loc_window* w, int which, int64_t n, const int32_t* co
             }
             if (!chain_l) a_chain.store(false);
             if (!single_l) a_single.store(false);
+            if (!single_r) a_single_r.store(false);
+            if (!single_s) a_single_s.store(false);
+            if (any_s) a_any_s.store(true);
         });
         chain = a_chain.load();
         single_pairs = a_single.load();   // (only meaningful for chain batches, where every range was scanned)
+        se3_pairs = a_any_s.load() && a_single_r.load() && a_single_s.load();
     }
-    if (use_cache && !hit) { tc.valid = true; tc.key = key; tc.n = n; tc.chain = chain; tc.single_pairs = single_pairs; tc.tree_tried = false; tc.tree_ok = false; }
+    if (use_cache && !hit) { tc.valid = true; tc.key = key; tc.n = n; tc.chain = chain; tc.single_pairs = single_pairs; tc.se3_pairs = se3_pairs; tc.tree_tried = false; tc.tree_ok = false; }
     if (chain) {
         if (translation_only(w, n, counts, poses, r_val, p_val)) return LOC_WINDOW_KERNEL_CHAIN3;
         if (single_pairs && c.nv_max <= 64 && locamd::window_wave6_lds_bytes(c) <= locamd::kWave6MaxLds) return LOC_WINDOW_KERNEL_WAVE6;
-        // (A node's own 15-pose window with twist EdgeSE3 factors, cfg/uwb_twist.yaml, was also tried on tree_wave_kernel — a chain is a forest,
-        //  rooted at its centre it has 8 levels: 0.58 … 0.67 ms per solve against the general kernel's 0.62 ms; its 21 LM trials each pay seven
-        //  sequential 6x6 eliminations of ~3.9 k cycles in one or two lanes (tools/dev/probe_tree_chain.py).  Not routed.)
+        // cfg/uwb_twist.yaml's window: a twist EdgeSE3 per consecutive pair next to the ranges — the wave-per-window kernel with full coupling
+        // blocks.  (The same window was tried on tree_wave_kernel first — a chain is a forest, rooted at its centre it has 8 levels: 0.58 … 0.67 ms
+        // per solve against the general kernel's 0.62 ms, tools/dev/probe_tree_chain.py: no speculative trials, one or two busy lanes per level.)
+        if (se3_pairs && c.nv_max <= 64 && c.ns_max <= 64 && locamd::window_wave6_lds_bytes(c, true) <= locamd::kWave6MaxLds) return LOC_WINDOW_KERNEL_WAVE6S;
         return LOC_WINDOW_KERNEL_CHAIN;
     }
     {
@@ -816,6 +826,11 @@ static int pick_kernel(const loc_window* w, int64_t n, int topology) {
         const bool off = !w->opt.wave6;
         if (n >= mn && (off || !default_rule)) return LOC_WINDOW_KERNEL_CHAIN;
         return off ? LOC_WINDOW_KERNEL_GENERAL : LOC_WINDOW_KERNEL_WAVE6;
+    }
+    if (topology == LOC_WINDOW_KERNEL_WAVE6S) {   // the same rule for chains with EdgeSE3 factors
+        const bool off = !w->opt.wave6;
+        if (n >= mn && (off || !default_rule)) return LOC_WINDOW_KERNEL_CHAIN;
+        return off ? LOC_WINDOW_KERNEL_GENERAL : LOC_WINDOW_KERNEL_WAVE6S;
     }
     if (topology == LOC_WINDOW_KERNEL_ARROW3) return LOC_WINDOW_KERNEL_ARROW3;   // (one workgroup per window: any batch size)
     if (topology == LOC_WINDOW_KERNEL_TREE) return n < tree_min_batch(w) ? LOC_WINDOW_KERNEL_GENERAL : LOC_WINDOW_KERNEL_TREE;
@@ -861,7 +876,8 @@ static hipError_t launch_any(loc_window* w, int which, const locamd::WindowArgs&
         return locamd::launch_window_chain3(a, w->d_chain3_ws, st);
     }
     if (kind == LOC_WINDOW_KERNEL_WAVE3) return locamd::launch_window_wave3(a, st);
-    if (kind == LOC_WINDOW_KERNEL_WAVE6) return locamd::launch_window_wave6(a, st);
+    if (kind == LOC_WINDOW_KERNEL_WAVE6) return locamd::launch_window_wave6(a, false, st);
+    if (kind == LOC_WINDOW_KERNEL_WAVE6S) return locamd::launch_window_wave6(a, true, st);
     if (kind == LOC_WINDOW_KERNEL_GENERAL) return locamd::launch_window(a, st);
     if (!w->d_chain_ws) {
         hipError_t e = hipMalloc((void**)&w->d_chain_ws, locamd::window_chain_workspace_doubles(w->caps, w->B) * sizeof(double));
@@ -980,7 +996,7 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
             //  fetches from memory on every sweep: such windows are copied to the device first)
             const bool tree_once = kind == LOC_WINDOW_KERNEL_TREE && w->aux[0].tsched.np == 0 && w->aux[0].tsched.max_r_per_node <= 2 &&
                                    w->aux[0].tsched.max_se3_per_node <= 1 && w->opt.tree != 2;
-            const bool zero_copy = (kind == LOC_WINDOW_KERNEL_WAVE3 || kind == LOC_WINDOW_KERNEL_WAVE6 || tree_once) && n <= 4 && w->B <= 4 && w->h_anchors.size() == (size_t)w->n_anchors * 3 &&
+            const bool zero_copy = (kind == LOC_WINDOW_KERNEL_WAVE3 || kind == LOC_WINDOW_KERNEL_WAVE6 || kind == LOC_WINDOW_KERNEL_WAVE6S || tree_once) && n <= 4 && w->B <= 4 && w->h_anchors.size() == (size_t)w->n_anchors * 3 &&
                                    off[9] + anchor_bytes <= kStageBytes && w->opt.zero_copy;
             if (zero_copy) {
                 d = h;

@@ -15,9 +15,15 @@
 // and Sherman-Morrison turns the sequential elimination into a recurrence on TWO SCALARS per pose while every pose factors its own
 // 6x6 block at once (see "The solve" in the kernel).  Everything else stays on window_lm_kernel.  Measured: cfg/uwb_imu.yaml's
 // twelve-pose window 0.10 ms (window_lm_kernel 0.40), 0.12 ms per range message through the node (the oracle: 0.26 ms).
-#include "window_kernel.h"
-#include "device_math.h"
-#include "numeric_jacobian.h"
+//
+// SE3 = true (round 4): the same windows WITH an EdgeSE3 factor between consecutive poses — Localization::addTwistEdge
+// (localization.cpp:438-459, 560-605; cfg/uwb_twist.yaml), at most one per pair.  The coupling block of a pair is then a full 6x6
+// (H_p,p-1 of the EdgeSE3 + the range edge's rank-1 part), so the elimination is the plain block-tridiagonal Cholesky — S_p = A_p -
+// W_p^T W_p, W_p = G_{p-1}^-1 K_p^T — handed from lane to lane by DPP: every repetition every lane takes its neighbour's factor (21 + 6
+// numbers) and redoes its own step, after repetition r the poses 0 .. r hold final values.  The EdgeSE3 of the pair (p - 1, p) is
+// linearised by lane p (its record in LDS, [entry][lane]), the share of pose p - 1 goes down one lane by DPP.  Everything else —
+// records, gather, speculative trials, LM — is shared with the rank-1 kernel.
+#include "se3_edge_device.h"
 
 #include <float.h>
 #include <math.h>
@@ -189,11 +195,13 @@ struct W6Lds {
     double* ev;     // [nr_max][5]   measurement, information, lever arm of endpoint 0
     double* fix;    // [nr_max][3]   the fixed endpoint of an anchor edge
     double* pv;     // [np_max][18]  Z^-1 as R (9), t (3); information diagonal (6)
+    double* sv;     // SE3: [48][64] the EdgeSE3 record of the pair (p - 1, p) in column p: Z^-1 as R t (12), information (36)
     int* eidx;      // [nr_max][2]
     int* epos;      // [nr_max][2]
     int* pidx;      // [np_max]
     int* ppos;      // [np_max]       where the prior's record goes (records grouped by pose)
 };
+template <bool SE3>
 __device__ __forceinline__ W6Lds w6_carve(const WindowCaps& c) {
     W6Lds l;
     double* p = w6lds;
@@ -203,6 +211,7 @@ __device__ __forceinline__ W6Lds w6_carve(const WindowCaps& c) {
     l.ev = p; p += (size_t)c.nr_max * 5;
     l.fix = p; p += (size_t)c.nr_max * 3;
     l.pv = p; p += (size_t)c.np_max * 18;
+    l.sv = p; if (SE3) p += 48 * 64;
     int* q = reinterpret_cast<int*>(p);
     l.eidx = q; q += (size_t)c.nr_max * 2;
     l.epos = q; q += (size_t)c.nr_max * 2;
@@ -385,12 +394,33 @@ __device__ __forceinline__ void w6_edges(const W6Lds& l, const W6Edge& E0, int n
 
 #define W6_TRI(r, c) ((r) * ((r) + 1) / 2 + (c))
 
-template <int JAC>
+// the EdgeSE3 of the pair (p - 1, p), evaluated by the lane of pose p at the poses P: chi; FULL: own / the earlier pose's share of H
+// and b (21 + 6 each), the coupling block KO (rows: pose p, column-major)
+struct W6Se3 { int e, i, j; bool robust; };
+template <bool FULL>
+__device__ __forceinline__ double w6_se3(const W6Lds& l, const double* P, const W6Se3& se, int col, double* own, double* oth, double* KO, double& rterm) {
+    double Xi[12], Xj[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) { Xi[k] = P[se.i * 12 + k]; Xj[k] = P[se.j * 12 + k]; }
+    const bool jl = se.j > se.i;
+    if (FULL) {
+        double Hii[21], Hjj[21], bi[6], bj[6];
+        const double chi = chain_se3_terms<true, 64>(Xi, Xj, l.sv + col, se.robust, jl, Hii, Hjj, KO, bi, bj, rterm);
+#pragma unroll
+        for (int k = 0; k < 21; ++k) { own[k] = jl ? Hjj[k] : Hii[k]; oth[k] = jl ? Hii[k] : Hjj[k]; }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { own[21 + k] = jl ? bj[k] : bi[k]; oth[21 + k] = jl ? bi[k] : bj[k]; }
+        return chi;
+    }
+    return chain_se3_terms<false, 64>(Xi, Xj, l.sv + col, se.robust, jl, nullptr, nullptr, nullptr, nullptr, nullptr, rterm);
+}
+
+template <int JAC, bool SE3>
 __global__ void __launch_bounds__(64) wave6_lm_kernel(const WindowArgs a) {
     const int lane = threadIdx.x;
     const long long inst = blockIdx.x;
     const WindowCaps& cp = a.caps;
-    const W6Lds l = w6_carve(cp);
+    const W6Lds l = w6_carve<SE3>(cp);
     const int nvm = cp.nv_max;
     const double* gin = a.poses_in + (size_t)inst * nvm * 12;
     double* gout = a.poses + (size_t)inst * nvm * 12;
@@ -434,6 +464,23 @@ __global__ void __launch_bounds__(64) wave6_lm_kernel(const WindowArgs a) {
             l.pidx[q] = pidx[q];
 #pragma unroll
             for (int k = 0; k < 18; ++k) l.pv[18 * q + k] = pval[18 * q + k];
+        }
+    }
+    W6Se3 se = {-1, 0, 0, false};
+    if (SE3) {
+        // lane e takes edge e's index row (one round trip for all of them), then every lane looks for the edge whose LATER pose is its own
+        const int ns = a.counts[inst * 4 + 3];
+        const int32_t* sidx = a.s_idx + (size_t)inst * cp.ns_max * 4;
+        int ei = -1, ej = -1, er = 0;
+        if (lane < ns) { ei = sidx[4 * lane]; ej = sidx[4 * lane + 1]; er = sidx[4 * lane + 2]; }
+        for (int e = 0; e < ns && e < 64; ++e) {
+            const int i2 = __builtin_amdgcn_readlane(ei, e), j2 = __builtin_amdgcn_readlane(ej, e), r2 = __builtin_amdgcn_readlane(er, e);
+            if (pose && (i2 > j2 ? i2 : j2) == pp) { se.e = e; se.i = i2; se.j = j2; se.robust = r2 != 0; }
+        }
+        if (lane < nv && se.e >= 0) {
+            const double* val = a.s_val + ((size_t)inst * cp.ns_max + se.e) * 48;
+#pragma unroll
+            for (int k = 0; k < 48; ++k) l.sv[k * 64 + lane] = val[k];
         }
     }
     w6_sync();
@@ -492,6 +539,8 @@ __global__ void __launch_bounds__(64) wave6_lm_kernel(const WindowArgs a) {
     bool need_lin = true;
     bool done = nv <= 0 || nr + np <= 0 || a.iterations <= 0;
     double D[21], b[6], u[6], vnext[6], X[6];   // this pose's H_pp (lower), b_p; H_p,p-1 = u v^T; the v of pose p + 1's block; x_p of this group's last solve
+    double K[SE3 ? 36 : 1];                      // SE3: the full coupling block H_p,p-1 (rows: pose p), column-major
+    int shared_edges = 0;
 #pragma unroll
     for (int k = 0; k < 21; ++k) D[k] = 0.0;
 #pragma unroll
@@ -500,6 +549,22 @@ __global__ void __launch_bounds__(64) wave6_lm_kernel(const WindowArgs a) {
         if (need_lin) {
             double plain;
             w6_edges<true, JAC>(l, E0, nvm, nr, np, cur, lane, cur_chi, plain);
+            double own[SE3 ? 27 : 1], oth[SE3 ? 27 : 1];
+            if (SE3) {
+                // (every group's lane of pose p linearises the pair's EdgeSE3 — the same instructions for all groups; group 0's chi counts)
+                double rs = 0.0, cs = 0.0;
+#pragma unroll
+                for (int k = 0; k < 27; ++k) { own[k] = 0.0; oth[k] = 0.0; }
+#pragma unroll
+                for (int k = 0; k < 36; ++k) K[k] = 0.0;
+                if (se.e >= 0) {
+                    double rterm;
+                    const double chi = w6_se3<true>(l, l.pose + (size_t)cur * nvm * 12, se, pp, own, oth, K, rterm);
+                    if (grp == 0) { rs = rterm; cs = chi; }
+                }
+                cur_chi += w6_sum(rs);
+                plain += w6_sum(cs);
+            }
             last_plain = plain;
             w6_sync();
             W6_T(1);
@@ -537,6 +602,19 @@ __global__ void __launch_bounds__(64) wave6_lm_kernel(const WindowArgs a) {
             }
 #pragma unroll
             for (int c = 0; c < 6; ++c) vnext[c] = w6_from_next(vv[c]);
+            if (SE3) {
+                // the EdgeSE3's shares: own, and pose p + 1's lane hands down what its edge gives pose p (zeros from a lane without one);
+                // the pair's coupling block = the EdgeSE3's + the range edge's rank-1 part
+#pragma unroll
+                for (int k = 0; k < 21; ++k) D[k] += own[k] + w6_from_next(oth[k]);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) b[k] += own[21 + k] + w6_from_next(oth[21 + k]);
+#pragma unroll
+                for (int c = 0; c < 6; ++c)
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) K[6 * c + r] = __builtin_fma(u[r], vv[c], K[6 * c + r]);
+                if (it == 0) shared_edges = (int)w6_sum(grp == 0 && se.e >= 0 && kc >= 0 ? 2.0 : 0.0);
+            }
             if (it == 0) {
                 double md = 0.0;
 #pragma unroll
@@ -563,97 +641,204 @@ __global__ void __launch_bounds__(64) wave6_lm_kernel(const WindowArgs a) {
         // a recurrence on two scalars per pose (forward: alpha, beta; backward: gamma = u_{p+1} . x_{p+1}), ~15 instructions per pose
         // instead of a 6x6 Cholesky and two triangular solves.  Each repetition every lane takes its neighbour's scalars through DPP and
         // redoes its own step (wave3_kernel.hip): after repetition r the poses 0 .. r hold final values; all G groups ride along.
-        double pA[6], qA[6], rA[6];   // A^-1 u, A^-1 v_next, A^-1 b
-        double uu = 0.0, uv = 0.0, vvq = 0.0, ub = 0.0, vb = 0.0;
-        bool piv_ok = true;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) { pA[k] = 0.0; qA[k] = 0.0; rA[k] = 0.0; }
-        if (pose) {
-            double A[6][6], ig[6];
-#pragma unroll
-            for (int rr = 0; rr < 6; ++rr) {
-#pragma unroll
-                for (int c = 0; c <= rr; ++c) A[rr][c] = D[W6_TRI(rr, c)];
-                A[rr][rr] += mylam;
-            }
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const double g = w6_pivot_rsqrt(A[j][j]);
-                ig[j] = g;
-#pragma unroll
-                for (int i2 = j + 1; i2 < 6; ++i2) A[i2][j] *= g;
-#pragma unroll
-                for (int i2 = j + 1; i2 < 6; ++i2)
-#pragma unroll
-                    for (int cc = j + 1; cc <= i2; ++cc) A[i2][cc] = __builtin_fma(-A[i2][j], A[cc][j], A[i2][cc]);
-            }
-            piv_ok = ((ig[0] + ig[1]) + (ig[2] + ig[3])) + (ig[4] + ig[5]) < DBL_MAX;
-            // three right-hand sides through G and G^T
-#pragma unroll
-            for (int k = 0; k < 6; ++k) { pA[k] = u[k]; qA[k] = vnext[k]; rA[k] = b[k]; }
-#pragma unroll
-            for (int cc = 0; cc < 6; ++cc) {
-                pA[cc] *= ig[cc]; qA[cc] *= ig[cc]; rA[cc] *= ig[cc];
-#pragma unroll
-                for (int c2 = cc + 1; c2 < 6; ++c2) {
-                    pA[c2] = __builtin_fma(-pA[cc], A[c2][cc], pA[c2]);
-                    qA[c2] = __builtin_fma(-qA[cc], A[c2][cc], qA[c2]);
-                    rA[c2] = __builtin_fma(-rA[cc], A[c2][cc], rA[c2]);
-                }
-            }
-#pragma unroll
-            for (int cc = 5; cc >= 0; --cc) {
-                double a0 = pA[cc], a1 = qA[cc], a2 = rA[cc];
-#pragma unroll
-                for (int c2 = cc + 1; c2 < 6; ++c2) {
-                    a0 = __builtin_fma(-A[c2][cc], pA[c2], a0);
-                    a1 = __builtin_fma(-A[c2][cc], qA[c2], a1);
-                    a2 = __builtin_fma(-A[c2][cc], rA[c2], a2);
-                }
-                pA[cc] = a0 * ig[cc]; qA[cc] = a1 * ig[cc]; rA[cc] = a2 * ig[cc];
-            }
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                uu = __builtin_fma(u[k], pA[k], uu); uv = __builtin_fma(u[k], qA[k], uv); vvq = __builtin_fma(vnext[k], qA[k], vvq);
-                ub = __builtin_fma(u[k], rA[k], ub); vb = __builtin_fma(vnext[k], rA[k], vb);
-            }
-        }
-        W6_T(3);
-        // forward recurrence: (alpha, beta) of pose p from those of pose p - 1
-        double bin = 0.0, kk = 0.0, rden = 1.0, den = 1.0;
-        {
-            double al = 0.0, be = 0.0;
-            for (int r = 0; r < nv; ++r) {
-                const double pal = w6_from_prev(al), pbe = w6_from_prev(be);
-                if (pose) {
-                    bin = pbe;
-                    den = __builtin_fma(-pal, uu, 1.0);
-                    rden = fast_rcp(den);
-                    kk = pal * rden;
-                    const double kuv = kk * uv;
-                    al = __builtin_fma(kuv, uv, vvq);
-                    be = __builtin_fma(kuv, __builtin_fma(-pbe, uu, ub), __builtin_fma(-pbe, uv, vb));
-                }
-            }
-        }
-        // a group in which some A_p or some Schur complement is not positive definite (or not finite) has failed
-        const unsigned long long bad = __ballot(pose && !(piv_ok && den > 0.0 && den < DBL_MAX));
-        // backward recurrence: gamma = u_{p+1} . x_{p+1};  x_p = S_p^-1 (b_p - beta_p u_p - gamma v_{p+1})
+        unsigned long long bad = 0;
         double Xn[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        {
-            double ga = 0.0, gin = 0.0, cfin = 0.0;
-            for (int r = 0; r < nv; ++r) {
-                const double pga = w6_from_next(ga);
-                if (pose) {
-                    gin = pga;
-                    cfin = __builtin_fma(-pga, uv, __builtin_fma(-bin, uu, ub));   // u^T A^-1 (b - beta u - gamma v)
-                    ga = cfin * rden;
+        if constexpr (!SE3) {
+            double pA[6], qA[6], rA[6];   // A^-1 u, A^-1 v_next, A^-1 b
+            double uu = 0.0, uv = 0.0, vvq = 0.0, ub = 0.0, vb = 0.0;
+            bool piv_ok = true;
+    #pragma unroll
+            for (int k = 0; k < 6; ++k) { pA[k] = 0.0; qA[k] = 0.0; rA[k] = 0.0; }
+            if (pose) {
+                double A[6][6], ig[6];
+    #pragma unroll
+                for (int rr = 0; rr < 6; ++rr) {
+    #pragma unroll
+                    for (int c = 0; c <= rr; ++c) A[rr][c] = D[W6_TRI(rr, c)];
+                    A[rr][rr] += mylam;
+                }
+    #pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const double g = w6_pivot_rsqrt(A[j][j]);
+                    ig[j] = g;
+    #pragma unroll
+                    for (int i2 = j + 1; i2 < 6; ++i2) A[i2][j] *= g;
+    #pragma unroll
+                    for (int i2 = j + 1; i2 < 6; ++i2)
+    #pragma unroll
+                        for (int cc = j + 1; cc <= i2; ++cc) A[i2][cc] = __builtin_fma(-A[i2][j], A[cc][j], A[i2][cc]);
+                }
+                piv_ok = ((ig[0] + ig[1]) + (ig[2] + ig[3])) + (ig[4] + ig[5]) < DBL_MAX;
+                // three right-hand sides through G and G^T
+    #pragma unroll
+                for (int k = 0; k < 6; ++k) { pA[k] = u[k]; qA[k] = vnext[k]; rA[k] = b[k]; }
+    #pragma unroll
+                for (int cc = 0; cc < 6; ++cc) {
+                    pA[cc] *= ig[cc]; qA[cc] *= ig[cc]; rA[cc] *= ig[cc];
+    #pragma unroll
+                    for (int c2 = cc + 1; c2 < 6; ++c2) {
+                        pA[c2] = __builtin_fma(-pA[cc], A[c2][cc], pA[c2]);
+                        qA[c2] = __builtin_fma(-qA[cc], A[c2][cc], qA[c2]);
+                        rA[c2] = __builtin_fma(-rA[cc], A[c2][cc], rA[c2]);
+                    }
+                }
+    #pragma unroll
+                for (int cc = 5; cc >= 0; --cc) {
+                    double a0 = pA[cc], a1 = qA[cc], a2 = rA[cc];
+    #pragma unroll
+                    for (int c2 = cc + 1; c2 < 6; ++c2) {
+                        a0 = __builtin_fma(-A[c2][cc], pA[c2], a0);
+                        a1 = __builtin_fma(-A[c2][cc], qA[c2], a1);
+                        a2 = __builtin_fma(-A[c2][cc], rA[c2], a2);
+                    }
+                    pA[cc] = a0 * ig[cc]; qA[cc] = a1 * ig[cc]; rA[cc] = a2 * ig[cc];
+                }
+    #pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    uu = __builtin_fma(u[k], pA[k], uu); uv = __builtin_fma(u[k], qA[k], uv); vvq = __builtin_fma(vnext[k], qA[k], vvq);
+                    ub = __builtin_fma(u[k], rA[k], ub); vb = __builtin_fma(vnext[k], rA[k], vb);
                 }
             }
-            if (pose) {
-                const double cb = __builtin_fma(-kk, cfin, bin);   // x = A^-1 b - (beta - k c) A^-1 u - gamma A^-1 v
+            W6_T(3);
+            // forward recurrence: (alpha, beta) of pose p from those of pose p - 1
+            double bin = 0.0, kk = 0.0, rden = 1.0, den = 1.0;
+            {
+                double al = 0.0, be = 0.0;
+                for (int r = 0; r < nv; ++r) {
+                    const double pal = w6_from_prev(al), pbe = w6_from_prev(be);
+                    if (pose) {
+                        bin = pbe;
+                        den = __builtin_fma(-pal, uu, 1.0);
+                        rden = fast_rcp(den);
+                        kk = pal * rden;
+                        const double kuv = kk * uv;
+                        al = __builtin_fma(kuv, uv, vvq);
+                        be = __builtin_fma(kuv, __builtin_fma(-pbe, uu, ub), __builtin_fma(-pbe, uv, vb));
+                    }
+                }
+            }
+            // a group in which some A_p or some Schur complement is not positive definite (or not finite) has failed
+            bad = __ballot(pose && !(piv_ok && den > 0.0 && den < DBL_MAX));
+            // backward recurrence: gamma = u_{p+1} . x_{p+1};  x_p = S_p^-1 (b_p - beta_p u_p - gamma v_{p+1})
+            {
+                double ga = 0.0, gin = 0.0, cfin = 0.0;
+                for (int r = 0; r < nv; ++r) {
+                    const double pga = w6_from_next(ga);
+                    if (pose) {
+                        gin = pga;
+                        cfin = __builtin_fma(-pga, uv, __builtin_fma(-bin, uu, ub));   // u^T A^-1 (b - beta u - gamma v)
+                        ga = cfin * rden;
+                    }
+                }
+                if (pose) {
+                    const double cb = __builtin_fma(-kk, cfin, bin);   // x = A^-1 b - (beta - k c) A^-1 u - gamma A^-1 v
+    #pragma unroll
+                    for (int k = 0; k < 6; ++k) Xn[k] = __builtin_fma(-gin, qA[k], __builtin_fma(-cb, pA[k], rA[k]));
+                }
+            }
+        } else {
+            // The solve with full coupling blocks K_p = H_p,p-1: block Cholesky of the block-tridiagonal H + lambda I,
+            //   W_p = G_{p-1}^-1 K_p^T,  S_p = A_p - W_p^T W_p = G_p G_p^T,  y_p = G_p^-1 (b_p - W_p^T y_{p-1});  x_p = G_p^-T (y_p - W_{p+1} x_{p+1}).
+            // Forward: every repetition every lane takes its left neighbour's factor and y through DPP (15 + 6 + 6 numbers) and redoes its
+            // step; after repetition r the poses 0 .. r hold final values (a lane whose inputs are final recomputes the same numbers; the
+            // idle lane after a group's last pose keeps zeros, which is what pose 0 of the next group must see).  Backward the same way round.
+            double Gl[15], ig[6], yv[6], Wm[36];   // strict lower triangle of G_p (column-major: (1,0) .. (5,0), (2,1) ..), reciprocal pivots, y_p, W_p (entry (k, c) at 6 k + c)
 #pragma unroll
-                for (int k = 0; k < 6; ++k) Xn[k] = __builtin_fma(-gin, qA[k], __builtin_fma(-cb, pA[k], rA[k]));
+            for (int k = 0; k < 15; ++k) Gl[k] = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { ig[k] = 0.0; yv[k] = 0.0; }
+#pragma unroll
+            for (int k = 0; k < 36; ++k) Wm[k] = 0.0;
+            for (int r = 0; r < nv; ++r) {
+                double Gq[15], iq[6], yq[6];
+#pragma unroll
+                for (int k = 0; k < 15; ++k) Gq[k] = w6_from_prev(Gl[k]);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { iq[k] = w6_from_prev(ig[k]); yq[k] = w6_from_prev(yv[k]); }
+                if (pose) {
+                    // W = G_{p-1}^-1 K^T: column c of K^T = row c of K ... one forward substitution per row rr of K
+#pragma unroll
+                    for (int rr = 0; rr < 6; ++rr) {
+                        double w[6];
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) w[c] = K[6 * c + rr];
+                        int kk2 = 0;
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) {
+                            w[c] *= iq[c];
+#pragma unroll
+                            for (int c2 = c + 1; c2 < 6; ++c2) { w[c2] = __builtin_fma(-w[c], Gq[kk2], w[c2]); ++kk2; }
+                        }
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) Wm[6 * c + rr] = w[c];
+                    }
+                    double A[6][6], rhs[6];
+#pragma unroll
+                    for (int rr = 0; rr < 6; ++rr) {
+#pragma unroll
+                        for (int c = 0; c <= rr; ++c) {
+                            double s2 = D[W6_TRI(rr, c)];
+#pragma unroll
+                            for (int k = 0; k < 6; ++k) s2 = __builtin_fma(-Wm[6 * k + rr], Wm[6 * k + c], s2);
+                            A[rr][c] = s2;
+                        }
+                        A[rr][rr] += mylam;
+                        double s3 = b[rr];
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) s3 = __builtin_fma(-Wm[6 * k + rr], yq[k], s3);
+                        rhs[rr] = s3;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        const double g = w6_pivot_rsqrt(A[j][j]);
+                        ig[j] = g;
+#pragma unroll
+                        for (int i2 = j + 1; i2 < 6; ++i2) A[i2][j] *= g;
+#pragma unroll
+                        for (int i2 = j + 1; i2 < 6; ++i2)
+#pragma unroll
+                            for (int cc = j + 1; cc <= i2; ++cc) A[i2][cc] = __builtin_fma(-A[i2][j], A[cc][j], A[i2][cc]);
+                    }
+                    {
+                        int kk2 = 0;
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) {
+                            rhs[c] *= ig[c];
+#pragma unroll
+                            for (int c2 = c + 1; c2 < 6; ++c2) { rhs[c2] = __builtin_fma(-rhs[c], A[c2][c], rhs[c2]); Gl[kk2] = A[c2][c]; ++kk2; }
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) yv[k] = rhs[k];
+                }
+            }
+            // a group in which some Schur complement is not positive definite (or not finite) has failed
+            bad = __ballot(pose && !(((ig[0] + ig[1]) + (ig[2] + ig[3])) + (ig[4] + ig[5]) < DBL_MAX));
+            {
+                double tn[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // W_p x_p: what pose p - 1 subtracts
+                for (int r = 0; r < nv; ++r) {
+                    double tq[6];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) tq[k] = w6_from_next(tn[k]);
+                    if (pose) {
+                        double t[6];
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) t[k] = yv[k] - tq[k];
+#pragma unroll
+                        for (int rr = 5; rr >= 0; --rr) {
+                            Xn[rr] = t[rr] * ig[rr];
+#pragma unroll
+                            for (int q2 = 0; q2 < rr; ++q2) t[q2] = __builtin_fma(-Gl[q2 * 5 - q2 * (q2 - 1) / 2 + (rr - q2 - 1)], Xn[rr], t[q2]);   // G(rr, q2)
+                        }
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) {
+                            double s2 = 0.0;
+#pragma unroll
+                            for (int c = 0; c < 6; ++c) s2 = __builtin_fma(Wm[6 * k + c], Xn[c], s2);
+                            tn[k] = s2;
+                        }
+                    }
+                }
             }
         }
         // x of a failed factorisation: g2o leaves its x alone, and LM applies that stale x all the same
@@ -718,6 +903,12 @@ __global__ void __launch_bounds__(64) wave6_lm_kernel(const WindowArgs a) {
                 const int slot = cur + 1 + g - (cur + 1 + g >= W6_NSLOT ? W6_NSLOT : 0);
                 double temp_chi, plain2;
                 w6_edges<false, JAC>(l, E0, nvm, nr, np, slot, lane, temp_chi, plain2);
+                if (SE3) {   // the EdgeSE3 factors, lane = later pose (group 0's lanes)
+                    double rs = 0.0, cs = 0.0;
+                    if (grp == 0 && se.e >= 0) cs = w6_se3<false>(l, l.pose + (size_t)slot * nvm * 12, se, pp, nullptr, nullptr, nullptr, rs);
+                    temp_chi += w6_sum(rs);
+                    plain2 += w6_sum(cs);
+                }
                 last_plain = plain2;
                 ++trials;
                 jlast = g;
@@ -759,7 +950,7 @@ __global__ void __launch_bounds__(64) wave6_lm_kernel(const WindowArgs a) {
     if (lane == 0) {
         double* res = a.result + (size_t)inst * 8;
         res[0] = last_plain; res[1] = cur_chi; res[2] = lambda; res[3] = (double)it; res[4] = (double)trials;
-        res[5] = (double)terminated; res[6] = 0.0; res[7] = nv > 0 ? (double)(nv * 65536 + 2 * nv - 1) : 0.0;
+        res[5] = (double)terminated; res[6] = (double)shared_edges; res[7] = nv > 0 ? (double)(nv * 65536 + 2 * nv - 1) : 0.0;
 #ifdef LOCAMD_WAVE6_TIMING
         for (int k = 0; k < 7; ++k) res[k] = (double)w6_ph[k];
         res[7] = (double)(__builtin_readcyclecounter() - w6_start) + 1e12 * trials;
@@ -769,14 +960,14 @@ __global__ void __launch_bounds__(64) wave6_lm_kernel(const WindowArgs a) {
 
 }  // namespace
 
-size_t window_wave6_lds_bytes(const WindowCaps& c) {
-    const size_t doubles = (size_t)W6_NSLOT * c.nv_max * 12 + (size_t)c.nr_max * (2 * W6_REC + 5 + 3) + (size_t)c.np_max * (W6_PREC + 18);
+size_t window_wave6_lds_bytes(const WindowCaps& c, bool se3) {
+    const size_t doubles = (size_t)W6_NSLOT * c.nv_max * 12 + (size_t)c.nr_max * (2 * W6_REC + 5 + 3) + (size_t)c.np_max * (W6_PREC + 18) + (se3 ? 48 * 64 : 0);
     const size_t ints = (size_t)c.nr_max * 4 + 2 * (size_t)c.np_max;
     return doubles * sizeof(double) + ((ints + 1) & ~(size_t)1) * sizeof(int);
 }
 
 namespace {
-template <int JAC>
+template <int JAC, bool SE3>
 hipError_t launch_wave6_t(const WindowArgs& a, size_t lds, hipStream_t stream) {
     static std::atomic<uint64_t> attr_set{0};
     int dev = 0;
@@ -784,20 +975,21 @@ hipError_t launch_wave6_t(const WindowArgs& a, size_t lds, hipStream_t stream) {
     if (e != hipSuccess) return e;
     const uint64_t bit = 1ull << (dev & 63);
     if (!(attr_set.load(std::memory_order_acquire) & bit)) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wave6_lm_kernel<JAC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWave6MaxLds);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wave6_lm_kernel<JAC, SE3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWave6MaxLds);
         if (e != hipSuccess) return e;
         attr_set.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL((wave6_lm_kernel<JAC>), dim3((unsigned)a.B), dim3(64), lds, stream, a);
+    hipLaunchKernelGGL((wave6_lm_kernel<JAC, SE3>), dim3((unsigned)a.B), dim3(64), lds, stream, a);
     return hipGetLastError();
 }
 }  // namespace
 
-hipError_t launch_window_wave6(const WindowArgs& a, hipStream_t stream) {
-    if (a.B <= 0 || a.caps.nv_max > 64 || a.caps.nv_max <= 0) return hipErrorInvalidValue;
-    const size_t lds = window_wave6_lds_bytes(a.caps);
+hipError_t launch_window_wave6(const WindowArgs& a, bool se3, hipStream_t stream) {
+    if (a.B <= 0 || a.caps.nv_max > 64 || a.caps.nv_max <= 0 || (se3 && a.caps.ns_max > 64)) return hipErrorInvalidValue;
+    const size_t lds = window_wave6_lds_bytes(a.caps, se3);
     if (lds > kWave6MaxLds) return hipErrorInvalidValue;
-    return a.jacobian ? launch_wave6_t<1>(a, lds, stream) : launch_wave6_t<0>(a, lds, stream);
+    if (se3) return a.jacobian ? launch_wave6_t<1, true>(a, lds, stream) : launch_wave6_t<0, true>(a, lds, stream);
+    return a.jacobian ? launch_wave6_t<1, false>(a, lds, stream) : launch_wave6_t<0, false>(a, lds, stream);
 }
 
 }  // namespace locamd

@@ -64,12 +64,13 @@ hipError_t launch_window_wave3(const WindowArgs& a, hipStream_t stream);
 // 6-DoF chain windows of <= 64 poses without EdgeSE3 factors and with at most one range edge per pair of consecutive poses, one wave
 // per window (wave6_kernel.hip): the node's own solve with IMU priors / lever arms, small batches
 constexpr size_t kWave6MaxLds = 128 * 1024;   // per window (one workgroup of one wave)
-size_t window_wave6_lds_bytes(const WindowCaps& c);
-hipError_t launch_window_wave6(const WindowArgs& a, hipStream_t stream);
+size_t window_wave6_lds_bytes(const WindowCaps& c, bool se3 = false);   // se3: with the EdgeSE3 records of wave6_lm_kernel<JAC, true> (an EdgeSE3 per consecutive pair)
+hipError_t launch_window_wave6(const WindowArgs& a, bool se3, hipStream_t stream);
 
 // translation-only chain + dense border windows (arrow3_kernel.hip): four waves per window.  The host cuts the chain into up to
 // four segments at separator poses (which join the border), orders the rows (chain rows by segment, then border rows) and packs
 // every row's edges and priors as records [chunk of 64 rows][slot][lane] once per upload (capi_window.cpp: build_arrow_aux).
+constexpr int kArrowMaxAnchors = 256;   // fixed anchors an edge of such a window may name: the table is staged in LDS (6 KB)
 struct ArrowAux {
     const int32_t* hdr;     // [B][8]  nb (border poses incl. separators), nseg, n (chain rows), seg[0 .. 4] (chain rows of segment s: [seg[s], seg[s+1]))
     const int32_t* rslot;   // [B][nv_max] pose slot of row r (rows 0 .. n-1: chain, n .. n+nb-1: border)

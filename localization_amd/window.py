@@ -149,7 +149,7 @@ class WindowSolver:
         check(self.L.loc_window_timing_end(self.h, C.byref(n), C.byref(tot), C.byref(avg)))
         return n.value, tot.value, avg.value
 
-    KERNEL_KINDS = {-1: "none", 0: "window_lm_kernel", 1: "chain_lm_kernel", 2: "chain3_lm_kernel", 3: "arrow3_lm_kernel", 4: "tree_wave_kernel", 5: "tree_lm_kernel", 6: "wave3_lm_kernel", 7: "wave6_lm_kernel"}
+    KERNEL_KINDS = {-1: "none", 0: "window_lm_kernel", 1: "chain_lm_kernel", 2: "chain3_lm_kernel", 3: "arrow3_lm_kernel", 4: "tree_wave_kernel", 5: "tree_lm_kernel", 6: "wave3_lm_kernel", 7: "wave6_lm_kernel", 8: "wave6_lm_kernel<SE3>"}
 
     def last_kernel_kind(self):
         """name of the kernel the last solve ran (loc_window_last_kernel_kind)"""

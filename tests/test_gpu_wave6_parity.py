@@ -144,7 +144,7 @@ def test_wave6_selection_rules(gpu):
     rng = np.random.default_rng(5)
     B, T = 16, 6
     base = _chain_batch(la, rng, B, T, True, True)
-    caps = (T, 2 * T + 2, T, 1)
+    caps = (T, 2 * T + 2, T, 2)
     wbase = la.WindowBatch(B, *caps)
     for name in ("counts", "poses", "r_idx", "r_val", "p_idx", "p_val"):
         getattr(wbase, name)[:] = getattr(base, name)
@@ -161,9 +161,12 @@ def test_wave6_selection_rules(gpu):
     def doubled(wb): wb.add_range(9, 2, 1, 0.02, 10.0)                        # a second edge on one pair of consecutive poses — not in creation order either
     def doubled_in_order(wb):                                                  # ... and one that keeps the chain order (the last pose's anchor range becomes a second smoothness edge)
         n = int(wb.counts[9, 1]); wb.r_idx[9, n - 2] = wb.r_idx[9, n - 1]
-    def se3(wb): wb.add_se3(4, 1, 2, np.zeros(3), np.eye(3), np.eye(6), True)  # an EdgeSE3 (twist / pose factors)
+    def se3(wb): wb.add_se3(4, 1, 2, np.zeros(3), np.eye(3), np.eye(6), True)  # an EdgeSE3 between consecutive poses (a twist factor): the kernel's SE3 variant
+    def se3_twice(wb): se3(wb); wb.add_se3(4, 2, 1, np.zeros(3), np.eye(3), np.eye(6), False)   # two on one pair
+    def se3_far(wb): wb.add_se3(4, 0, 3, np.zeros(3), np.eye(3), np.eye(6), True)   # a key-frame factor: not a chain
     def far_pair(wb): wb.r_idx[11, int(wb.counts[11, 1]) - 1] = (4, 1)        # not a chain
-    for mut in (doubled, doubled_in_order, se3, far_pair):
+    assert kind(se3) == "wave6_lm_kernel<SE3>"
+    for mut in (doubled, doubled_in_order, se3_twice, se3_far, far_pair):
         assert kind(mut) == "window_lm_kernel", mut.__name__
     s.set_option("wave6", 0)
     assert kind(lambda wb: None) == "window_lm_kernel"
@@ -173,3 +176,126 @@ def test_wave6_selection_rules(gpu):
     s.L.loc_window_set_chain_threshold(s.h, 8)                                # a batch of 16 is then large enough for one lane per window
     assert kind(lambda wb: None) == "chain_lm_kernel"
     s.close()
+
+
+def _twist_batch(la, rng, B, T, with_imu, lever):
+    """cfg/uwb_twist.yaml's window (Localization::addTwistEdge, localization.cpp:438-459): per pose an anchor range and the smoothness
+    edge to the previous pose, and an EdgeSE3 between consecutive poses (full 6x6 information, Cauchy on two of three) — ragged lengths,
+    every other EdgeSE3 stored the other way round, some windows with a missing range link or a missing EdgeSE3."""
+    nr_max, np_max, ns_max = max(2 * T + 2, 4), (T if with_imu else 0), max(T, 1)
+    wb = la.WindowBatch(B, T, nr_max, np_max, ns_max)
+    for i in range(B):
+        Ti = T if i % 7 else max(T // 2, 1)
+        est_t, est_R, off, ranges, smooth, priors, _ = _random_window(rng, Ti, with_imu, False, lever)
+        for k in range(Ti):
+            wb.add_pose(i, est_t[k], est_R[k])
+        for k in range(1, Ti):
+            if i % 6 == 4 and k == 2: continue   # (a pair without its EdgeSE3: only the range edge couples it)
+            a, b = (k - 1, k) if k % 2 else (k, k - 1)
+            Ra, Rb = Rotation.from_matrix(est_R[a]), Rotation.from_matrix(est_R[b])
+            Zt = Ra.inv().apply(est_t[b] - est_t[a]) + rng.normal(0, 0.01, 3)
+            ZR = (Ra.inv() * Rb * Rotation.from_rotvec(rng.normal(0, 0.01, 3))).as_matrix()
+            A = rng.normal(size=(6, 6)); info = A @ A.T + 6 * np.eye(6); info *= 1e3 / np.trace(info)
+            wb.add_se3(i, a, b, Zt, ZR, info, bool(k % 3))
+        for k in range(Ti):
+            for (kk, a, d, info) in ranges:
+                if kk == k: wb.add_range(i, k, a, d, info, off, anchor=True)
+            for (k0, k1, d, info) in smooth:
+                if k1 == k and not (i % 5 == 2 and k == 3):   # (some windows miss a range link: the EdgeSE3 alone couples the pair)
+                    if i % 3 == 1: wb.add_range(i, k1, k0, d, info)
+                    else: wb.add_range(i, k0, k1, d, info)
+        for (k, t, R, dg) in priors: wb.add_prior(i, k, t, R, dg)
+    return wb
+
+
+@pytest.mark.parametrize("T,with_imu,lever,jac", [
+    (15, False, False, "numeric"),    # cfg/uwb_twist.yaml's own window (trajectory_length 15), the reference's Jacobian mode: four groups of 16 lanes
+    (15, False, True, "analytic"),
+    (10, True, True, "numeric"),      # with IMU priors and a lever arm
+    (2, False, True, "analytic"),
+    (24, False, True, "numeric"),     # two groups of 32 lanes
+    (40, True, False, "analytic"),    # one group
+    (64, False, True, "analytic"),    # every lane a pose
+])
+def test_wave6_se3_kernel_matches_oracle_and_general_kernel(gpu, T, with_imu, lever, jac):
+    """wave6_lm_kernel<JAC, SE3 = true>: chain windows with an EdgeSE3 between consecutive poses — full 6x6 coupling blocks, the block
+    Cholesky handed from lane to lane — against the oracle, against the general kernel, through the resident API."""
+    import localization_amd as la
+    from oracle import oracle as O
+    from _oracle_window import oracle_solve_instance
+    B = 36 if T < 40 else 12
+    rng = np.random.default_rng(7000 + 10 * T + len(jac))
+    wb = _twist_batch(la, rng, B, T, with_imu, lever)
+    wb.counts[3, 1:] = 0   # an instance whose poses have no edge at all: comes back untouched
+    before = wb.poses.copy()
+    wb0 = _copy_batch(la, wb)
+    mode = O.JAC_ANALYTIC if jac == "analytic" else O.JAC_NUMERIC_G2O
+    want = [oracle_solve_instance(wb, i, ANCH, jac_mode=mode) for i in range(B)]
+    ref = _copy_batch(la, wb)
+    general = la.WindowSolver(ANCH, B, *wb.caps, jacobian=jac, chain_threshold=0)
+    res_general = general.solve(ref).copy()
+    assert general.last_kernel_kind() == "window_lm_kernel"
+    general.close()
+    s = la.WindowSolver(ANCH, B, *wb.caps, jacobian=jac)
+    res = s.solve(wb).copy()
+    assert s.last_kernel_kind() == "wave6_lm_kernel<SE3>"
+    tol = 1e-7 if jac == "analytic" else 3e-5
+    escaped = 0
+    for i in range(B):
+        nv = int(wb.counts[i, 0])
+        if nv == 0 or wb.counts[i, 1] + wb.counts[i, 2] + wb.counts[i, 3] == 0:
+            assert np.array_equal(wb.poses[i, :nv], before[i, :nv]) and res[i, 4] == 0
+            continue
+        poses, chi, st = want[i]
+        d = np.abs(wb.poses[i, :nv] - poses).max()
+        dg = np.abs(ref.poses[i, :nv] - poses).max()
+        if not d < tol:
+            # numeric mode: the difference quotient's 1e-7 noise moves an unconverged window by what its conditioning makes of it — counted, and
+            # bounded by what the general kernel does on it or by the oracle's own spread between its two Jacobian modes on this very window
+            da = np.abs(oracle_solve_instance(wb0, i, ANCH, jac_mode=O.JAC_ANALYTIC)[0] - poses).max()
+            assert jac == "numeric" and d < max(2 * dg, 3 * da, tol) and d < 1e-3, (i, d, dg, da)
+            escaped += 1
+            assert abs(res[i, 0] - chi) <= 1e-3 * max(1.0, abs(chi)), (i, res[i, 0], chi)   # (such a window's chi2: to what its poses are)
+        else:
+            assert abs(res[i, 0] - chi) <= (1e-6 if jac == "analytic" else 1e-4) * max(1.0, abs(chi)), (i, res[i, 0], chi)
+        assert res[i, 7] == nv * 65536 + 2 * nv - 1
+        assert res[i, 6] == res_general[i, 6], (i, res[i, 6], res_general[i, 6])   # pairs carrying both a range edge and an EdgeSE3
+    assert escaped <= (B // 8 if jac == "numeric" else 0), escaped
+    assert np.abs(wb.poses - ref.poses).max() < (tol if jac == "analytic" else 1e-3)
+    if T > 2:
+        assert (res[:, 4] != res_general[:, 4]).mean() < 0.06   # LM trial counts
+    wb2 = _copy_batch(la, wb); wb2.poses[:] = before
+    s.upload(wb2); s.solve_resident(); s.download(wb2)
+    assert s.last_kernel_kind() == "wave6_lm_kernel<SE3>"
+    for i in range(B):
+        nv = int(wb.counts[i, 0])
+        assert np.array_equal(wb2.poses[i, :nv], wb.poses[i, :nv]) and np.array_equal(wb2.result[i], res[i]), i
+    # option "wave6" = 0: the general kernel, as before
+    s.set_option("wave6", 0)
+    wb3 = _copy_batch(la, wb); wb3.poses[:] = before
+    s.solve(wb3)
+    assert s.last_kernel_kind() == "window_lm_kernel"
+    s.close()
+
+
+def test_wave6_se3_failed_cholesky_like_g2o(gpu):
+    """Zero information everywhere (H = 0, lambda_0 = 0): every factorisation fails — 10 trials, 1 outer iteration, terminated, poses
+    untouched — next to healthy windows of the same launch."""
+    import localization_amd as la
+    from _oracle_window import oracle_solve_instance
+    rng = np.random.default_rng(19)
+    B, T = 5, 8
+    wb = _twist_batch(la, rng, B, T, False, True)
+    wb.r_val[2, :, 1] = 0.0
+    wb.s_val[2, :, 12:] = 0.0
+    before = wb.poses.copy()
+    want = [oracle_solve_instance(wb, i, ANCH) for i in range(B)]
+    s = la.WindowSolver(ANCH, B, *wb.caps, jacobian="analytic")
+    res = s.solve(wb).copy()
+    assert s.last_kernel_kind() == "wave6_lm_kernel<SE3>"
+    s.close()
+    assert res[2, 5] == 1 and res[2, 4] == 10 and res[2, 3] == 1 and np.array_equal(wb.poses[2], before[2])
+    assert want[2][2].terminated == 1 and want[2][2].lm_trials == 10
+    for i in (0, 1, 3, 4):
+        nv = int(wb.counts[i, 0])
+        assert np.abs(wb.poses[i, :nv] - want[i][0]).max() < 1e-7

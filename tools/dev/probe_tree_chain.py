@@ -25,7 +25,12 @@ for _ in range(3):
     s.solve(wb)
 r = wb.result[0]
 print("kernel", s.last_kernel_kind(), f"{s.last_kernel_ms()*1e3:.1f} us", "host timing", s.last_host_timing())
-if r[7] > 1e11:
+if r[7] > 1e11 and s.last_kernel_kind().startswith("wave6"):   # (make wave6timing)
+    trials = int(r[7] // 1e12); total = r[7] - 1e12 * trials
+    names = ["set-up", "edges + EdgeSE3 (lin.)", "gather", "(rank-1 factor)", "block Cholesky + x", "apply + trial scoring", "LM update"]
+    print(f"cycles {total:.0f}; LM trials {trials}")
+    for k in range(7): print(f"  {names[k]:34s} {r[k]:10.0f} cycles  {100*r[k]/total:5.1f} %")
+elif r[7] > 1e11:
     trials = int(r[7] // 1e12); total = r[7] - 1e12 * trials
     names = ["linearise: edges", "factor leaves", "leaf-child sums", "factor upper levels", "back-subst", "apply step + loop", "trial scoring", "linearise: hand-over + child sums"]
     v = list(r[:6]) + [r[6] % 1e9, np.floor(r[6] / 1e9)]
