@@ -788,7 +788,7 @@ static int batch_topology(loc_window* w, int which, int64_t n, const int32_t* co
         // cfg/uwb_twist.yaml's window: a twist EdgeSE3 per consecutive pair next to the ranges — the wave-per-window kernel with full coupling
         // blocks.  (The same window was tried on tree_wave_kernel first — a chain is a forest, rooted at its centre it has 8 levels: 0.58 … 0.67 ms
         // per solve against the general kernel's 0.62 ms, tools/dev/probe_tree_chain.py: no speculative trials, one or two busy lanes per level.)
-        if (se3_pairs && c.nv_max <= 64 && c.ns_max <= 64 && locamd::window_wave6_lds_bytes(c, true) <= locamd::kWave6MaxLds) return LOC_WINDOW_KERNEL_WAVE6S;
+        if (se3_pairs && c.nv_max <= 63 && c.ns_max <= 64 && locamd::window_wave6_lds_bytes(c, true) <= locamd::kWave6MaxLds) return LOC_WINDOW_KERNEL_WAVE6S;   // (nv + 1 lanes: the middle pose twice)
         return LOC_WINDOW_KERNEL_CHAIN;
     }
     {

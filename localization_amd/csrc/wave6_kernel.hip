@@ -236,7 +236,7 @@ __device__ __forceinline__ W6Edge w6_load_edge(const W6Lds& l, int e) {
 
 // one range edge at the poses P: its robust / plain chi2; FULL: its linearisation records as well
 template <bool FULL, int JAC>
-__device__ __forceinline__ void w6_edge(const W6Lds& l, const double* P, const W6Edge& E, double& rsum, double& csum) {
+__device__ __forceinline__ void w6_edge(const W6Lds& l, const double* P, const W6Edge& E, int tm, double& rsum, double& csum) {
     const int v0 = E.v0, v1 = E.v1;
     const double meas = E.meas, info = E.info;
     const double off[3] = {E.ox, E.oy, E.oz};
@@ -288,9 +288,13 @@ __device__ __forceinline__ void w6_edge(const W6Lds& l, const double* P, const W
                 J0[0] = w6_jac_numeric<0, true>(X0, off, X1, p1, 0, meas, n0, h0);
                 J0[1] = w6_jac_numeric<1, true>(X0, off, X1, p1, 0, meas, n0, h0);
                 J0[2] = w6_jac_numeric<2, true>(X0, off, X1, p1, 0, meas, n0, h0);
-                J0[3] = w6_jac_numeric<3, true>(X0, off, X1, p1, 0, meas, n0, h0);
-                J0[4] = w6_jac_numeric<4, true>(X0, off, X1, p1, 0, meas, n0, h0);
-                J0[5] = w6_jac_numeric<5, true>(X0, off, X1, p1, 0, meas, n0, h0);
+                // With a zero lever arm a rotation of endpoint 0 does not move the ranged point at all: both perturbed evaluations of g2o's central
+                // difference return the same number and the column is exactly +0 — the three columns are skipped when no lane here has a lever arm.
+                if (__any(off[0] != 0.0 || off[1] != 0.0 || off[2] != 0.0)) {
+                    J0[3] = w6_jac_numeric<3, true>(X0, off, X1, p1, 0, meas, n0, h0);
+                    J0[4] = w6_jac_numeric<4, true>(X0, off, X1, p1, 0, meas, n0, h0);
+                    J0[5] = w6_jac_numeric<5, true>(X0, off, X1, p1, 0, meas, n0, h0);
+                } else { J0[3] = 0.0; J0[4] = 0.0; J0[5] = 0.0; }
                 if (v1 >= 0) {
                     J1[0] = w6_jac_numeric<0, true>(X0, off, X1, p1, 1, meas, n0, h0);
                     J1[1] = w6_jac_numeric<1, true>(X0, off, X1, p1, 1, meas, n0, h0);
@@ -311,7 +315,11 @@ __device__ __forceinline__ void w6_edge(const W6Lds& l, const double* P, const W
             }
         }
         const double wr = info * fast_rcp(aux), wre = -wr * err;
-        const bool c0 = v1 >= 0 && v1 == v0 - 1, c1 = v0 == v1 - 1;   // the endpoint that is the later pose of a consecutive pair keeps the coupling
+        // the endpoint that RECEIVES the other's Schur complement keeps the coupling (the other endpoint's J): the later pose of a consecutive
+        // pair — in the two-sided elimination of the SE3 kernel (poses beyond the middle pose tm are eliminated downwards) the earlier one,
+        // and the middle pose for both its neighbours (tm = INT_MAX: one-sided)
+        const bool c0 = v1 >= 0 && ((v1 == v0 - 1 && v0 <= tm) || (v1 == v0 + 1 && v0 >= tm));
+        const bool c1 = v1 >= 0 && ((v0 == v1 - 1 && v1 <= tm) || (v0 == v1 + 1 && v1 >= tm));
         double* r = l.rec + (size_t)E.s0 * W6_REC;
         r[0] = wr; r[1] = wre;
 #pragma unroll
@@ -382,11 +390,11 @@ __device__ __forceinline__ void w6_prior(const W6Lds& l, const double* P, int q,
 
 // every edge and prior of the window at the poses of buffer `buf`: the robust and plain chi2 sums; FULL: the linearisation records
 template <bool FULL, int JAC>
-__device__ __forceinline__ void w6_edges(const W6Lds& l, const W6Edge& E0, int nvm, int nr, int np, int buf, int lane, double& robust_chi, double& plain_chi) {
+__device__ __forceinline__ void w6_edges(const W6Lds& l, const W6Edge& E0, int nvm, int nr, int np, int buf, int lane, int tm, double& robust_chi, double& plain_chi) {
     double rsum = 0.0, csum = 0.0;
     const double* P = l.pose + (size_t)buf * nvm * 12;
-    if (lane < nr) w6_edge<FULL, JAC>(l, P, E0, rsum, csum);
-    for (int e = lane + 64; e < nr; e += 64) w6_edge<FULL, JAC>(l, P, w6_load_edge(l, e), rsum, csum);
+    if (lane < nr) w6_edge<FULL, JAC>(l, P, E0, tm, rsum, csum);
+    for (int e = lane + 64; e < nr; e += 64) w6_edge<FULL, JAC>(l, P, w6_load_edge(l, e), tm, rsum, csum);
     for (int q = lane; q < np; q += 64) w6_prior<FULL>(l, P, q, rsum, csum);
     robust_chi = w6_sum(rsum);
     plain_chi = w6_sum(csum);
@@ -394,15 +402,15 @@ __device__ __forceinline__ void w6_edges(const W6Lds& l, const W6Edge& E0, int n
 
 #define W6_TRI(r, c) ((r) * ((r) + 1) / 2 + (c))
 
-// the EdgeSE3 of the pair (p - 1, p), evaluated by the lane of pose p at the poses P: chi; FULL: own / the earlier pose's share of H
-// and b (21 + 6 each), the coupling block KO (rows: pose p, column-major)
+// the EdgeSE3 between a lane's pose and its sender, evaluated by that lane at the poses P: chi; FULL: its own / the sender's share of H
+// and b (21 + 6 each), the coupling block KO (rows: the lane's pose, column-major)
 struct W6Se3 { int e, i, j; bool robust; };
 template <bool FULL>
-__device__ __forceinline__ double w6_se3(const W6Lds& l, const double* P, const W6Se3& se, int col, double* own, double* oth, double* KO, double& rterm) {
+__device__ __forceinline__ double w6_se3(const W6Lds& l, const double* P, const W6Se3& se, int col, int own_pose, double* own, double* oth, double* KO, double& rterm) {
     double Xi[12], Xj[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) { Xi[k] = P[se.i * 12 + k]; Xj[k] = P[se.j * 12 + k]; }
-    const bool jl = se.j > se.i;
+    const bool jl = se.j == own_pose;   // (chain_se3_terms: the coupling block's rows are pose j's when the flag is set, pose i's otherwise)
     if (FULL) {
         double Hii[21], Hjj[21], bi[6], bj[6];
         const double chi = chain_se3_terms<true, 64>(Xi, Xj, l.sv + col, se.robust, jl, Hii, Hjj, KO, bi, bj, rterm);
@@ -439,8 +447,22 @@ __global__ void __launch_bounds__(64) wave6_lm_kernel(const WindowArgs a) {
     // keeps one idle lane after its last pose (the hand-over between lanes reads zeros there)
     const int W = nv <= 15 ? 16 : (nv <= 31 ? 32 : 64);
     const int G = 64 / W;
-    const int grp = lane / W, pp = lane & (W - 1);
-    const bool pose = pp < nv;
+    const int grp = lane / W, lg = lane & (W - 1);
+    // lane <-> pose.  Rank-1 kernel: lane lg of a group is pose lg, eliminated after pose lg - 1.  SE3: the block elimination runs from BOTH
+    // ends of the chain towards the middle pose tm in the same instructions — poses 0 .. tm in lanes 0 .. tm, poses nv - 1 .. tm + 1 in lanes
+    // tm + 1 .. nv - 1 and the middle pose ONCE MORE in lane nv (`dup`: the end of the second chain), so that in both chains a lane takes
+    // its sender's factor from the lane before it; the two Schur complements of the middle pose are added at the end.  Half the
+    // sequential steps.  (nv + 1 lanes per group: nv <= 63.)
+    const int tm = SE3 ? (nv - 1) / 2 : 0x7fffffff;
+    int pp = lg, qq = lg - 1;      // this lane's pose; the pose eliminated just before it in its chain (the sender), -1: none
+    bool pose = lg < nv, dup = false;
+    if (SE3) {
+        if (lg > tm) { pp = nv + tm - lg; qq = lg > tm + 1 ? pp + 1 : -1; }
+        pose = lg <= nv && nv > 0 && !(nv == 1 && lg == 1);
+        dup = nv > 1 && lg == nv;
+        if (!pose) { pp = 0; qq = -1; }
+    }
+    const bool mid = SE3 && pose && lg == tm;   // (its chain's last step; with `dup` the two halves of the middle pose)
     const unsigned long long group_mask = W == 64 ? ~0ull : ((1ull << W) - 1ull);
     W6_T0();
     // ---- set-up ------------------------------------------------------------------------------------------------------------------
@@ -468,16 +490,16 @@ __global__ void __launch_bounds__(64) wave6_lm_kernel(const WindowArgs a) {
     }
     W6Se3 se = {-1, 0, 0, false};
     if (SE3) {
-        // lane e takes edge e's index row (one round trip for all of them), then every lane looks for the edge whose LATER pose is its own
+        // lane e takes edge e's index row (one round trip for all of them), then every lane looks for the edge between its pose and its sender
         const int ns = a.counts[inst * 4 + 3];
         const int32_t* sidx = a.s_idx + (size_t)inst * cp.ns_max * 4;
         int ei = -1, ej = -1, er = 0;
         if (lane < ns) { ei = sidx[4 * lane]; ej = sidx[4 * lane + 1]; er = sidx[4 * lane + 2]; }
         for (int e = 0; e < ns && e < 64; ++e) {
             const int i2 = __builtin_amdgcn_readlane(ei, e), j2 = __builtin_amdgcn_readlane(ej, e), r2 = __builtin_amdgcn_readlane(er, e);
-            if (pose && (i2 > j2 ? i2 : j2) == pp) { se.e = e; se.i = i2; se.j = j2; se.robust = r2 != 0; }
+            if (pose && qq >= 0 && ((i2 == pp && j2 == qq) || (i2 == qq && j2 == pp))) { se.e = e; se.i = i2; se.j = j2; se.robust = r2 != 0; }
         }
-        if (lane < nv && se.e >= 0) {
+        if (lane < W && se.e >= 0) {
             const double* val = a.s_val + ((size_t)inst * cp.ns_max + se.e) * 48;
 #pragma unroll
             for (int k = 0; k < 48; ++k) l.sv[k * 64 + lane] = val[k];
@@ -490,7 +512,7 @@ __global__ void __launch_bounds__(64) wave6_lm_kernel(const WindowArgs a) {
         deg += (v0 == lane) + (v1 == lane);
     }
     int lst = 0;   // first record of this pose: exclusive prefix sum of deg over the lanes
-    int kc = -1;   // the record of the edge to the previous pose
+    int kc = -1, kcr = -1;   // the record of the edge to the previous / (SE3) to the next pose
     {
         int incl = deg;
 #pragma unroll
@@ -502,8 +524,8 @@ __global__ void __launch_bounds__(64) wave6_lm_kernel(const WindowArgs a) {
         int k = lst;
         for (int e = 0; e < nr; ++e) {
             const int v0 = l.eidx[2 * e], v1 = l.eidx[2 * e + 1];
-            if (v0 == lane) { if (v1 >= 0 && v1 == lane - 1) kc = k; l.epos[2 * e] = k++; }
-            if (v1 == lane) { if (v0 == lane - 1) kc = k; l.epos[2 * e + 1] = k++; }
+            if (v0 == lane) { if (v1 >= 0 && v1 == lane - 1) kc = k; if (v1 == lane + 1) kcr = k; l.epos[2 * e] = k++; }
+            if (v1 == lane) { if (v0 == lane - 1) kc = k; if (v0 == lane + 1) kcr = k; l.epos[2 * e + 1] = k++; }
         }
     }
     int pdeg = 0, plst = 0;   // the same for the pose's priors
@@ -523,6 +545,8 @@ __global__ void __launch_bounds__(64) wave6_lm_kernel(const WindowArgs a) {
     deg = __shfl(deg, pp, 64);   // every group's lane of pose pp
     lst = __shfl(lst, pp, 64);
     kc = __shfl(kc, pp, 64);
+    kcr = __shfl(kcr, pp, 64);
+    if (SE3) kc = qq < 0 ? -1 : (qq == pp + 1 ? kcr : kc);   // the record of the edge to the SENDER
     pdeg = __shfl(pdeg, pp, 64);
     plst = __shfl(plst, pp, 64);
     w6_sync();
@@ -548,7 +572,7 @@ __global__ void __launch_bounds__(64) wave6_lm_kernel(const WindowArgs a) {
     while (!done) {
         if (need_lin) {
             double plain;
-            w6_edges<true, JAC>(l, E0, nvm, nr, np, cur, lane, cur_chi, plain);
+            w6_edges<true, JAC>(l, E0, nvm, nr, np, cur, lane, tm, cur_chi, plain);
             double own[SE3 ? 27 : 1], oth[SE3 ? 27 : 1];
             if (SE3) {
                 // (every group's lane of pose p linearises the pair's EdgeSE3 — the same instructions for all groups; group 0's chi counts)
@@ -559,7 +583,7 @@ __global__ void __launch_bounds__(64) wave6_lm_kernel(const WindowArgs a) {
                 for (int k = 0; k < 36; ++k) K[k] = 0.0;
                 if (se.e >= 0) {
                     double rterm;
-                    const double chi = w6_se3<true>(l, l.pose + (size_t)cur * nvm * 12, se, pp, own, oth, K, rterm);
+                    const double chi = w6_se3<true>(l, l.pose + (size_t)cur * nvm * 12, se, lg, pp, own, oth, K, rterm);
                     if (grp == 0) { rs = rterm; cs = chi; }
                 }
                 cur_chi += w6_sum(rs);
@@ -581,18 +605,20 @@ __global__ void __launch_bounds__(64) wave6_lm_kernel(const WindowArgs a) {
                     double Jm[6], wj[6];
 #pragma unroll
                     for (int c = 0; c < 6; ++c) { Jm[c] = r[2 + c]; wj[c] = wr * Jm[c]; }
+                    if (!dup) {   // (the middle pose's second lane only takes the coupling with ITS sender)
 #pragma unroll
-                    for (int rr = 0; rr < 6; ++rr) {
+                        for (int rr = 0; rr < 6; ++rr) {
 #pragma unroll
-                        for (int cc = 0; cc <= rr; ++cc) D[W6_TRI(rr, cc)] = __builtin_fma(wj[rr], Jm[cc], D[W6_TRI(rr, cc)]);
-                        b[rr] = __builtin_fma(Jm[rr], wre, b[rr]);
+                            for (int cc = 0; cc <= rr; ++cc) D[W6_TRI(rr, cc)] = __builtin_fma(wj[rr], Jm[cc], D[W6_TRI(rr, cc)]);
+                            b[rr] = __builtin_fma(Jm[rr], wre, b[rr]);
+                        }
                     }
                     if (k == kc) {
 #pragma unroll
                         for (int c = 0; c < 6; ++c) { u[c] = wj[c]; vv[c] = r[8 + c]; }
                     }
                 }
-                for (int pq = plst; pq < plst + pdeg; ++pq) {
+                for (int pq = plst; pq < (dup ? plst : plst + pdeg); ++pq) {
                     const double* r = l.prec + (size_t)pq * W6_PREC;
 #pragma unroll
                     for (int k = 0; k < 21; ++k) D[k] += r[k];
@@ -603,8 +629,9 @@ __global__ void __launch_bounds__(64) wave6_lm_kernel(const WindowArgs a) {
 #pragma unroll
             for (int c = 0; c < 6; ++c) vnext[c] = w6_from_next(vv[c]);
             if (SE3) {
-                // the EdgeSE3's shares: own, and pose p + 1's lane hands down what its edge gives pose p (zeros from a lane without one);
-                // the pair's coupling block = the EdgeSE3's + the range edge's rank-1 part
+                // the EdgeSE3's shares: own, and the NEXT lane (whose sender this lane is) hands down what its edge gives this lane's pose
+                // (zeros from a lane without one); the pair's coupling block = the EdgeSE3's + the range edge's rank-1 part.  The middle pose's
+                // H_mm and b_m stay split over its two lanes (the second holds the share of ITS edge): every use below is a sum over both.
 #pragma unroll
                 for (int k = 0; k < 21; ++k) D[k] += own[k] + w6_from_next(oth[k]);
 #pragma unroll
@@ -618,7 +645,11 @@ __global__ void __launch_bounds__(64) wave6_lm_kernel(const WindowArgs a) {
             if (it == 0) {
                 double md = 0.0;
 #pragma unroll
-                for (int r = 0; r < 6; ++r) md = fmax(md, fabs(D[W6_TRI(r, r)]));
+                for (int r = 0; r < 6; ++r) {
+                    double dg = D[W6_TRI(r, r)];
+                    if (SE3 && nv > 1) { const double t = __shfl(dg, grp * W + nv, 64); dg = mid ? dg + t : (dup ? 0.0 : dg); }   // (the middle pose's diagonal: both lanes' shares)
+                    md = fmax(md, fabs(dg));
+                }
                 lambda = tau * w6_max(pose ? md : 0.0);
                 ni = 2.0;
             }
@@ -737,40 +768,74 @@ __global__ void __launch_bounds__(64) wave6_lm_kernel(const WindowArgs a) {
                 }
             }
         } else {
-            // The solve with full coupling blocks K_p = H_p,p-1: block Cholesky of the block-tridiagonal H + lambda I,
-            //   W_p = G_{p-1}^-1 K_p^T,  S_p = A_p - W_p^T W_p = G_p G_p^T,  y_p = G_p^-1 (b_p - W_p^T y_{p-1});  x_p = G_p^-T (y_p - W_{p+1} x_{p+1}).
-            // Forward: every repetition every lane takes its left neighbour's factor and y through DPP (15 + 6 + 6 numbers) and redoes its
-            // step; after repetition r the poses 0 .. r hold final values (a lane whose inputs are final recomputes the same numbers; the
-            // idle lane after a group's last pose keeps zeros, which is what pose 0 of the next group must see).  Backward the same way round.
+            // The solve with full coupling blocks: block Cholesky of the block-tridiagonal H + lambda I, eliminated from both ends towards the
+            // middle pose.  With q the sender of pose p (the pose before it in its chain) and K_p = H_p,q:
+            //   W_p = G_q^-1 K_p^T,  S_p = A_p - W_p^T W_p = G_p G_p^T,  y_p = G_p^-1 (b_p - W_p^T y_q);   back: x_q = G_q^-T (y_q - W_p x_p).
+            // Forward: every repetition every lane takes the factor and y of the lane before it through DPP (15 + 6 + 6 numbers) and redoes its
+            // step; after repetition r the first r + 1 poses of both chains hold final values (a lane whose inputs are final recomputes the
+            // same numbers).  The middle pose's two lanes then add their Schur complements and both factor the sum.  Backward the same way round.
             double Gl[15], ig[6], yv[6], Wm[36];   // strict lower triangle of G_p (column-major: (1,0) .. (5,0), (2,1) ..), reciprocal pivots, y_p, W_p (entry (k, c) at 6 k + c)
+            double Su[27];                         // S_p and its right-hand side before the factorisation (the middle pose's lanes add theirs)
 #pragma unroll
             for (int k = 0; k < 15; ++k) Gl[k] = 0.0;
 #pragma unroll
             for (int k = 0; k < 6; ++k) { ig[k] = 0.0; yv[k] = 0.0; }
 #pragma unroll
             for (int k = 0; k < 36; ++k) Wm[k] = 0.0;
-            for (int r = 0; r < nv; ++r) {
+#pragma unroll
+            for (int k = 0; k < 27; ++k) Su[k] = 0.0;
+            const int reps = (tm > nv - 1 - tm ? tm : nv - 1 - tm) + 1;
+            const double lamd = dup ? 0.0 : mylam;   // (the middle pose's lambda rides in its first lane)
+            auto factor = [&](double (&A)[6][6], double* rhs) __attribute__((always_inline)) {   // A = G G^T in place, ig, Gl; rhs <- G^-1 rhs = yv
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const double g = w6_pivot_rsqrt(A[j][j]);
+                    ig[j] = g;
+#pragma unroll
+                    for (int i2 = j + 1; i2 < 6; ++i2) A[i2][j] *= g;
+#pragma unroll
+                    for (int i2 = j + 1; i2 < 6; ++i2)
+#pragma unroll
+                        for (int cc = j + 1; cc <= i2; ++cc) A[i2][cc] = __builtin_fma(-A[i2][j], A[cc][j], A[i2][cc]);
+                }
+                int kk2 = 0;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    rhs[c] *= ig[c];
+#pragma unroll
+                    for (int c2 = c + 1; c2 < 6; ++c2) { rhs[c2] = __builtin_fma(-rhs[c], A[c2][c], rhs[c2]); Gl[kk2] = A[c2][c]; ++kk2; }
+                }
+#pragma unroll
+                for (int k = 0; k < 6; ++k) yv[k] = rhs[k];
+            };
+            for (int r = 0; r < reps; ++r) {
                 double Gq[15], iq[6], yq[6];
 #pragma unroll
                 for (int k = 0; k < 15; ++k) Gq[k] = w6_from_prev(Gl[k]);
 #pragma unroll
                 for (int k = 0; k < 6; ++k) { iq[k] = w6_from_prev(ig[k]); yq[k] = w6_from_prev(yv[k]); }
                 if (pose) {
-                    // W = G_{p-1}^-1 K^T: column c of K^T = row c of K ... one forward substitution per row rr of K
+                    // W = G_q^-1 K^T, one forward substitution per row rr of K.  (A chain's first pose has no sender: W stays 0, and what the
+                    // lane before it holds — another chain's or group's end, possibly not finite — is not looked at.)
+                    if (qq >= 0) {
 #pragma unroll
-                    for (int rr = 0; rr < 6; ++rr) {
-                        double w[6];
+                        for (int rr = 0; rr < 6; ++rr) {
+                            double w[6];
 #pragma unroll
-                        for (int c = 0; c < 6; ++c) w[c] = K[6 * c + rr];
-                        int kk2 = 0;
+                            for (int c = 0; c < 6; ++c) w[c] = K[6 * c + rr];
+                            int kk2 = 0;
 #pragma unroll
-                        for (int c = 0; c < 6; ++c) {
-                            w[c] *= iq[c];
+                            for (int c = 0; c < 6; ++c) {
+                                w[c] *= iq[c];
 #pragma unroll
-                            for (int c2 = c + 1; c2 < 6; ++c2) { w[c2] = __builtin_fma(-w[c], Gq[kk2], w[c2]); ++kk2; }
+                                for (int c2 = c + 1; c2 < 6; ++c2) { w[c2] = __builtin_fma(-w[c], Gq[kk2], w[c2]); ++kk2; }
+                            }
+#pragma unroll
+                            for (int c = 0; c < 6; ++c) Wm[6 * c + rr] = w[c];
                         }
+                    } else {
 #pragma unroll
-                        for (int c = 0; c < 6; ++c) Wm[6 * c + rr] = w[c];
+                        for (int k = 0; k < 6; ++k) yq[k] = 0.0;
                     }
                     double A[6][6], rhs[6];
 #pragma unroll
@@ -782,62 +847,66 @@ __global__ void __launch_bounds__(64) wave6_lm_kernel(const WindowArgs a) {
                             for (int k = 0; k < 6; ++k) s2 = __builtin_fma(-Wm[6 * k + rr], Wm[6 * k + c], s2);
                             A[rr][c] = s2;
                         }
-                        A[rr][rr] += mylam;
+                        A[rr][rr] += lamd;
                         double s3 = b[rr];
 #pragma unroll
                         for (int k = 0; k < 6; ++k) s3 = __builtin_fma(-Wm[6 * k + rr], yq[k], s3);
                         rhs[rr] = s3;
                     }
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) {
-                        const double g = w6_pivot_rsqrt(A[j][j]);
-                        ig[j] = g;
+                    for (int rr = 0; rr < 6; ++rr) {
 #pragma unroll
-                        for (int i2 = j + 1; i2 < 6; ++i2) A[i2][j] *= g;
-#pragma unroll
-                        for (int i2 = j + 1; i2 < 6; ++i2)
-#pragma unroll
-                            for (int cc = j + 1; cc <= i2; ++cc) A[i2][cc] = __builtin_fma(-A[i2][j], A[cc][j], A[i2][cc]);
+                        for (int c = 0; c <= rr; ++c) Su[W6_TRI(rr, c)] = A[rr][c];
+                        Su[21 + rr] = rhs[rr];
                     }
-                    {
-                        int kk2 = 0;
+                    factor(A, rhs);
+                }
+            }
+            if (nv > 1) {   // the middle pose: S_m = (A_m - W^T W of its first chain) + (- W^T W of the second), factored by both its lanes
+                const int partner = grp * W + (mid ? nv : tm);
+                double Sp[27];
 #pragma unroll
-                        for (int c = 0; c < 6; ++c) {
-                            rhs[c] *= ig[c];
+                for (int k = 0; k < 27; ++k) Sp[k] = __shfl(Su[k], partner, 64);
+                if (mid || dup) {
+                    double A[6][6], rhs[6];
 #pragma unroll
-                            for (int c2 = c + 1; c2 < 6; ++c2) { rhs[c2] = __builtin_fma(-rhs[c], A[c2][c], rhs[c2]); Gl[kk2] = A[c2][c]; ++kk2; }
-                        }
+                    for (int rr = 0; rr < 6; ++rr) {
+#pragma unroll
+                        for (int c = 0; c <= rr; ++c) A[rr][c] = Su[W6_TRI(rr, c)] + Sp[W6_TRI(rr, c)];
+                        rhs[rr] = Su[21 + rr] + Sp[21 + rr];
                     }
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) yv[k] = rhs[k];
+                    factor(A, rhs);
                 }
             }
             // a group in which some Schur complement is not positive definite (or not finite) has failed
             bad = __ballot(pose && !(((ig[0] + ig[1]) + (ig[2] + ig[3])) + (ig[4] + ig[5]) < DBL_MAX));
             {
-                double tn[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // W_p x_p: what pose p - 1 subtracts
-                for (int r = 0; r < nv; ++r) {
+                double tn[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // W_p x_p: what the sender of pose p subtracts
+                auto back = [&](const double* tq) __attribute__((always_inline)) {
+                    double t[6];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) t[k] = yv[k] - tq[k];
+#pragma unroll
+                    for (int rr = 5; rr >= 0; --rr) {
+                        Xn[rr] = t[rr] * ig[rr];
+#pragma unroll
+                        for (int q2 = 0; q2 < rr; ++q2) t[q2] = __builtin_fma(-Gl[q2 * 5 - q2 * (q2 - 1) / 2 + (rr - q2 - 1)], Xn[rr], t[q2]);   // G(rr, q2)
+                    }
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        double s2 = 0.0;
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) s2 = __builtin_fma(Wm[6 * k + c], Xn[c], s2);
+                        tn[k] = s2;
+                    }
+                };
+                const double zero6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+                if (mid || dup) back(zero6);   // x of the middle pose (the last one eliminated), in both its lanes
+                for (int r = 0; r + 1 < reps; ++r) {
                     double tq[6];
 #pragma unroll
                     for (int k = 0; k < 6; ++k) tq[k] = w6_from_next(tn[k]);
-                    if (pose) {
-                        double t[6];
-#pragma unroll
-                        for (int k = 0; k < 6; ++k) t[k] = yv[k] - tq[k];
-#pragma unroll
-                        for (int rr = 5; rr >= 0; --rr) {
-                            Xn[rr] = t[rr] * ig[rr];
-#pragma unroll
-                            for (int q2 = 0; q2 < rr; ++q2) t[q2] = __builtin_fma(-Gl[q2 * 5 - q2 * (q2 - 1) / 2 + (rr - q2 - 1)], Xn[rr], t[q2]);   // G(rr, q2)
-                        }
-#pragma unroll
-                        for (int k = 0; k < 6; ++k) {
-                            double s2 = 0.0;
-#pragma unroll
-                            for (int c = 0; c < 6; ++c) s2 = __builtin_fma(Wm[6 * k + c], Xn[c], s2);
-                            tn[k] = s2;
-                        }
-                    }
+                    if (pose && !mid && !dup) back(tq);
                 }
             }
         }
@@ -845,14 +914,14 @@ __global__ void __launch_bounds__(64) wave6_lm_kernel(const WindowArgs a) {
         if (bad) {
             double st[6];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) st[k] = __shfl(X[k], jlast * W + pp, 64);
+            for (int k = 0; k < 6; ++k) st[k] = __shfl(X[k], jlast * W + lg, 64);
             for (int g = 0; g < G; ++g) {
                 if (grp == g && ((bad >> (g * W)) & group_mask)) {
 #pragma unroll
                     for (int k = 0; k < 6; ++k) Xn[k] = st[k];
                 }
 #pragma unroll
-                for (int k = 0; k < 6; ++k) st[k] = __shfl(Xn[k], g * W + pp, 64);
+                for (int k = 0; k < 6; ++k) st[k] = __shfl(Xn[k], g * W + lg, 64);
             }
         }
 #pragma unroll
@@ -862,7 +931,11 @@ __global__ void __launch_bounds__(64) wave6_lm_kernel(const WindowArgs a) {
         double scv[4];
         {
             double sc = 0.0;
-            if (pose) {
+            if (dup) {   // (b_m's second share: x_m . b_m is a sum over both lanes, lambda |x_m|^2 rides in the first)
+#pragma unroll
+                for (int k = 0; k < 6; ++k) sc += X[k] * b[k];
+            }
+            if (pose && !dup) {
                 const int slot = cur + 1 + grp - (cur + 1 + grp >= W6_NSLOT ? W6_NSLOT : 0);
                 const double* s = l.pose + ((size_t)cur * nvm + pp) * 12;
                 double* d = l.pose + ((size_t)slot * nvm + pp) * 12;
@@ -902,10 +975,10 @@ __global__ void __launch_bounds__(64) wave6_lm_kernel(const WindowArgs a) {
             if (g < G && !iteration_over) {
                 const int slot = cur + 1 + g - (cur + 1 + g >= W6_NSLOT ? W6_NSLOT : 0);
                 double temp_chi, plain2;
-                w6_edges<false, JAC>(l, E0, nvm, nr, np, slot, lane, temp_chi, plain2);
+                w6_edges<false, JAC>(l, E0, nvm, nr, np, slot, lane, tm, temp_chi, plain2);
                 if (SE3) {   // the EdgeSE3 factors, lane = later pose (group 0's lanes)
                     double rs = 0.0, cs = 0.0;
-                    if (grp == 0 && se.e >= 0) cs = w6_se3<false>(l, l.pose + (size_t)slot * nvm * 12, se, pp, nullptr, nullptr, nullptr, rs);
+                    if (grp == 0 && se.e >= 0) cs = w6_se3<false>(l, l.pose + (size_t)slot * nvm * 12, se, lg, pp, nullptr, nullptr, nullptr, rs);
                     temp_chi += w6_sum(rs);
                     plain2 += w6_sum(cs);
                 }
@@ -985,7 +1058,7 @@ hipError_t launch_wave6_t(const WindowArgs& a, size_t lds, hipStream_t stream) {
 }  // namespace
 
 hipError_t launch_window_wave6(const WindowArgs& a, bool se3, hipStream_t stream) {
-    if (a.B <= 0 || a.caps.nv_max > 64 || a.caps.nv_max <= 0 || (se3 && a.caps.ns_max > 64)) return hipErrorInvalidValue;
+    if (a.B <= 0 || a.caps.nv_max > 64 || a.caps.nv_max <= 0 || (se3 && (a.caps.ns_max > 64 || a.caps.nv_max > 63))) return hipErrorInvalidValue;
     const size_t lds = window_wave6_lds_bytes(a.caps, se3);
     if (lds > kWave6MaxLds) return hipErrorInvalidValue;
     if (se3) return a.jacobian ? launch_wave6_t<1, true>(a, lds, stream) : launch_wave6_t<0, true>(a, lds, stream);

@@ -39,12 +39,15 @@ def build(B, shape, seed=0):
         T, anchors, imu, lever, per_pose = 1, ANCHORS_8, True, True, 8
     elif shape == "uwb_imu":
         T, anchors, imu, lever, per_pose = 12, ANCH4, True, True, 1
+    elif shape == "uwb_twist":   # cfg/uwb_twist.yaml: trajectory_length 15, a twist EdgeSE3 between consecutive poses (addTwistEdge)
+        T, anchors, imu, lever, per_pose = 15, ANCH4, False, False, 1
     else:
         T, anchors, imu, lever, per_pose = 10, ANCH4, False, False, 1
     if POSES_OVERRIDE and T > 1:
         T = POSES_OVERRIDE
     off = np.array([0.1, 0.0, -0.05]) if lever else np.zeros(3)
-    wb = la.WindowBatch(B, T, max(2 * T, per_pose), T if imu else 0, 0)
+    twist = shape == "uwb_twist"
+    wb = la.WindowBatch(B, T, max(2 * T, per_pose), T if imu else 0, T if twist else 0)
     graphs = []
     for i in range(B):
         tt = np.cumsum(rng.normal(0, 0.05, (T, 3)), axis=0) + np.array([rng.uniform(-1.5, 1.5), rng.uniform(-1.5, 1.5), 1.1])
@@ -54,9 +57,13 @@ def build(B, shape, seed=0):
             # cfg/uwb_only.yaml has no rotation source: Robot::init gives every pose the identity rotation (robot.cpp:47) and, with the
             # default identity antenna offsets (localization.h:170), nothing ever turns it
             eR = np.tile(np.eye(3), (T, 1, 1))
-        g = dict(et=et, eR=eR, off=off, ranges=[], smooth=[], priors=[])
+        g = dict(et=et, eR=eR, off=off, ranges=[], smooth=[], priors=[], se3=[])
         for k in range(T):
             wb.add_pose(i, et[k], eR[k])
+            if twist and k:
+                Zt = tR[k - 1].inv().apply(tt[k] - tt[k - 1]) + rng.normal(0, 0.002, 3)
+                ZR = (tR[k - 1].inv() * tR[k] * Rotation.from_rotvec(rng.normal(0, 0.002, 3))).as_matrix()
+                wb.add_se3(i, k - 1, k, Zt, ZR, np.eye(6) * 1e4, True); g["se3"].append((k - 1, k, Zt, ZR))
             for a in (range(per_pose) if per_pose > 1 else [int(rng.integers(0, len(anchors)))]):
                 d = float(np.float32(np.linalg.norm(tt[k] + tR[k].apply(off) - anchors[a]) + rng.normal(0, 0.03)))
                 wb.add_range(i, k, a, d, 1 / 0.055 ** 2, off, anchor=True); g["ranges"].append((k, a, d))
@@ -170,7 +177,7 @@ def oracle_time(graphs, anchors, T, n, iters=10, analytic=False):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--shape", default="uwb_only", choices=["uwb_only", "uwb_imu", "fusion1", "pose64", "selfcal"])
+    ap.add_argument("--shape", default="uwb_only", choices=["uwb_only", "uwb_imu", "uwb_twist", "fusion1", "pose64", "selfcal"])
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--cpu-n", type=int, default=256)
@@ -178,6 +185,7 @@ def main():
                     "'dense' = nv_max - 1, or a number")
     ap.add_argument("--poses", type=int, default=0, help="window length for the chain shapes (default: the profile's 10 / 12)")
     ap.add_argument("--jacobian", default="analytic", choices=["analytic", "numeric"])
+    ap.add_argument("--chain-threshold", type=int, default=-1, help="loc_window_set_chain_threshold (A/B runs: 1 = the lane-per-window chain kernels for every chain batch, 0 = the general kernel)")
     ap.add_argument("--natural", action="store_true", help="windows of <= 64 poses: keep the caller's pose order (no in-kernel minimum-degree ordering)")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-window latency launches (profiling: one kernel shape only)")
     ap.add_argument("--pmc-json", default=None, help="a tests/perf/pmc_summary.py output for THIS shape and batch: its f64 instruction counts "
@@ -216,7 +224,8 @@ def main():
             if ns: bw = max(bw, int(np.abs(wb.s_idx[b, :ns, 0] - wb.s_idx[b, :ns, 1]).max()))
     else:
         bw = -1 if a.bw == "dense" else int(a.bw)
-    solver = la.WindowSolver(anchors, a.batch, *wb.caps, maximum_iteration=10, bw_max=bw, jacobian=a.jacobian, natural_order=a.natural)
+    solver = la.WindowSolver(anchors, a.batch, *wb.caps, maximum_iteration=10, bw_max=bw, jacobian=a.jacobian, natural_order=a.natural,
+                             **({} if a.chain_threshold < 0 else {"chain_threshold": a.chain_threshold}))
     poses0 = wb.poses.copy()
     ms = []
     for r in range(a.reps + 1):

@@ -215,7 +215,7 @@ def _twist_batch(la, rng, B, T, with_imu, lever):
     (2, False, True, "analytic"),
     (24, False, True, "numeric"),     # two groups of 32 lanes
     (40, True, False, "analytic"),    # one group
-    (64, False, True, "analytic"),    # every lane a pose
+    (63, False, True, "analytic"),    # every lane a pose (63 poses + the middle pose once more)
 ])
 def test_wave6_se3_kernel_matches_oracle_and_general_kernel(gpu, T, with_imu, lever, jac):
     """wave6_lm_kernel<JAC, SE3 = true>: chain windows with an EdgeSE3 between consecutive poses — full 6x6 coupling blocks, the block
