@@ -250,6 +250,10 @@ int loc_window_set_chain_threshold(loc_window* w, int64_t min_batch);
  *   WAVE6   the 6-DoF sibling of WAVE3 (IMU / lidar priors, an antenna lever arm on the pose): chain windows of <= 64 poses without
  *            EdgeSE3 factors and with at most one range edge per pair of consecutive poses, any batch size (an explicit chain threshold
  *            hands larger batches to CHAIN).
+ *   WAVE6S  the same kernel with FULL coupling blocks (wave6_lm_kernel<JAC, SE3>): chain windows of <= 63 poses WITH an EdgeSE3 factor between
+ *            consecutive poses — Localization::addTwistEdge (localization.cpp:438-459, cfg/uwb_twist.yaml) — at most one per pair, at
+ *            most one range edge per pair; the block Cholesky runs from both ends of the chain towards the middle pose.  Switched by
+ *            option "wave6" as well.
  * All of them run the same LM and agree to the tolerances of DESIGN.md §3; result[6] / result[7] keep their meaning (the
  * lane-per-window kernels eliminate in pose order: result[7] = nv * 65536 + 2 nv - 1). */
 enum { LOC_WINDOW_KERNEL_NONE = -1, LOC_WINDOW_KERNEL_GENERAL = 0, LOC_WINDOW_KERNEL_CHAIN = 1, LOC_WINDOW_KERNEL_CHAIN3 = 2, LOC_WINDOW_KERNEL_ARROW3 = 3, LOC_WINDOW_KERNEL_TREE = 4,

@@ -195,7 +195,7 @@ struct W6Lds {
     double* ev;     // [nr_max][5]   measurement, information, lever arm of endpoint 0
     double* fix;    // [nr_max][3]   the fixed endpoint of an anchor edge
     double* pv;     // [np_max][18]  Z^-1 as R (9), t (3); information diagonal (6)
-    double* sv;     // SE3: [48][64] the EdgeSE3 record of the pair (p - 1, p) in column p: Z^-1 as R t (12), information (36)
+    double* sv;     // SE3: [48][64] the EdgeSE3 record of edge e in column e: Z^-1 as R t (12), information (36)
     int* eidx;      // [nr_max][2]
     int* epos;      // [nr_max][2]
     int* pidx;      // [np_max]
@@ -491,18 +491,18 @@ __global__ void __launch_bounds__(64) wave6_lm_kernel(const WindowArgs a) {
     W6Se3 se = {-1, 0, 0, false};
     if (SE3) {
         // lane e takes edge e's index row (one round trip for all of them), then every lane looks for the edge between its pose and its sender
-        const int ns = a.counts[inst * 4 + 3];
         const int32_t* sidx = a.s_idx + (size_t)inst * cp.ns_max * 4;
         int ei = -1, ej = -1, er = 0;
-        if (lane < ns) { ei = sidx[4 * lane]; ej = sidx[4 * lane + 1]; er = sidx[4 * lane + 2]; }
+        if (lane < cp.ns_max) { ei = sidx[4 * lane]; ej = sidx[4 * lane + 1]; er = sidx[4 * lane + 2]; }   // (requested before the count has arrived)
+        const int ns = a.counts[inst * 4 + 3];
+        if (lane < ns) {   // edge e's record -> column e (one pass over it; which lane evaluates it is found out meanwhile)
+            const double* val = a.s_val + ((size_t)inst * cp.ns_max + lane) * 48;
+#pragma unroll
+            for (int k = 0; k < 48; ++k) l.sv[k * 64 + lane] = val[k];
+        }
         for (int e = 0; e < ns && e < 64; ++e) {
             const int i2 = __builtin_amdgcn_readlane(ei, e), j2 = __builtin_amdgcn_readlane(ej, e), r2 = __builtin_amdgcn_readlane(er, e);
             if (pose && qq >= 0 && ((i2 == pp && j2 == qq) || (i2 == qq && j2 == pp))) { se.e = e; se.i = i2; se.j = j2; se.robust = r2 != 0; }
-        }
-        if (lane < W && se.e >= 0) {
-            const double* val = a.s_val + ((size_t)inst * cp.ns_max + se.e) * 48;
-#pragma unroll
-            for (int k = 0; k < 48; ++k) l.sv[k * 64 + lane] = val[k];
         }
     }
     w6_sync();
@@ -583,7 +583,7 @@ __global__ void __launch_bounds__(64) wave6_lm_kernel(const WindowArgs a) {
                 for (int k = 0; k < 36; ++k) K[k] = 0.0;
                 if (se.e >= 0) {
                     double rterm;
-                    const double chi = w6_se3<true>(l, l.pose + (size_t)cur * nvm * 12, se, lg, pp, own, oth, K, rterm);
+                    const double chi = w6_se3<true>(l, l.pose + (size_t)cur * nvm * 12, se, se.e, pp, own, oth, K, rterm);
                     if (grp == 0) { rs = rterm; cs = chi; }
                 }
                 cur_chi += w6_sum(rs);
@@ -978,7 +978,7 @@ __global__ void __launch_bounds__(64) wave6_lm_kernel(const WindowArgs a) {
                 w6_edges<false, JAC>(l, E0, nvm, nr, np, slot, lane, tm, temp_chi, plain2);
                 if (SE3) {   // the EdgeSE3 factors, lane = later pose (group 0's lanes)
                     double rs = 0.0, cs = 0.0;
-                    if (grp == 0 && se.e >= 0) cs = w6_se3<false>(l, l.pose + (size_t)slot * nvm * 12, se, lg, pp, nullptr, nullptr, nullptr, rs);
+                    if (grp == 0 && se.e >= 0) cs = w6_se3<false>(l, l.pose + (size_t)slot * nvm * 12, se, se.e, pp, nullptr, nullptr, nullptr, rs);
                     temp_chi += w6_sum(rs);
                     plain2 += w6_sum(cs);
                 }

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-4 rocprofv3 evidence on the GPU box:  tools/profile_r04.sh OUTDIR [cfg2|cfg3|cfg5|cfg4|cfg1|all ...]   (run from the repo root; summaries land
+# Round-4 rocprofv3 evidence on the GPU box:  tools/profile_r04.sh OUTDIR [cfg2|cfg3|cfg5|cfg4|cfg1|twist|all ...]   (run from the repo root; summaries land
 # in OUTDIR: copy them to profiles/r04_final/).  Per workload: --kernel-trace --stats once, then separate --pmc passes (never combined with a trace
 # domain).  Every window workload runs in the REFERENCE's configuration (numeric Jacobians), the snapshot / fusion kernels in both modes.
 #   cfg2  headline snapshot kernel (bench.py itself: numeric = `value`, and --jacobian analytic)        cfg3  fusion kernel
@@ -46,6 +46,10 @@ if want cfg4; then
   profile cfg4_1024 arrow3_lm_kernel -- python3 $W --shape selfcal --batch 1024 --cache /tmp/wb_sc1024.npz
   python3 $W --shape selfcal --batch 128 --tile 32 --cache /tmp/wb_sc128.npz > /dev/null
   profile cfg4_128 arrow3_lm_kernel -- python3 $W --shape selfcal --batch 128 --cache /tmp/wb_sc128.npz
+fi
+if want twist; then   # cfg/uwb_twist.yaml's 15-pose window (EdgeSE3 between consecutive poses) as a batch: wave6_lm_kernel<JAC, SE3>
+  python3 $W --shape uwb_twist --batch 65536 --tile 1024 --cache /tmp/wb_tw.npz > /dev/null
+  profile twist_windows wave6_lm_kernel -- python3 $W --shape uwb_twist --batch 65536 --cache /tmp/wb_tw.npz
 fi
 if want cfg1; then
   python3 $W --shape uwb_only --batch 65536 --tile 4096 --cache /tmp/wb_t10.npz --bw 1 > /dev/null
