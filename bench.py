@@ -51,7 +51,8 @@ _WIN_COMMON = ("window_kernel.h", "device_math.h", "numeric_jacobian.h")
 # per leg: the sources of the kernel that leg runs (one translation unit per kernel since round 4)
 WINDOW_LEG_SOURCES = {"cfg1_windows": ("wave3_kernel.hip",) + _WIN_COMMON,
                       "cfg4": ("arrow3_kernel.hip",) + _WIN_COMMON,
-                      "cfg5": ("tree_wave_kernel.hip", "se3_edge_device.h", "window_device.h") + _WIN_COMMON}
+                      "cfg5": ("tree_wave_kernel.hip", "se3_edge_device.h", "window_device.h") + _WIN_COMMON,
+                      "twist_windows": ("wave6_kernel.hip", "se3_edge_device.h", "window_device.h") + _WIN_COMMON}
 
 
 def window_traffic(leg, world):
@@ -547,6 +548,31 @@ def leg_cfg1_windows(D, args):
                        parity_fn=lambda n: bw.oracle_time(graphs, anchors, T, n, analytic=True)[1], n_parity=512, leg="cfg1_windows")
 
 
+def leg_twist_windows(D, args):
+    """cfg/uwb_twist.yaml's per-message problem as a batch: 15-pose windows with an anchor range and the smoothness edge per pose and a twist
+    EdgeSE3 between consecutive poses (Localization::addTwistEdge, localization.cpp:438-459), 65 536 windows in total — what
+    wave6_lm_kernel<JAC, SE3> (one wave per window, full 6x6 coupling blocks) does with the node's EdgeSE3 window when there are many."""
+    import numpy as np
+    from localization_amd.sharding import shard_bounds
+    sys.path.insert(0, os.path.join(ROOT, "tests", "perf"))
+    import bench_window as bw
+    total = 65536
+    lo, hi = shard_bounds(total, D.rank, D.world)
+    import localization_amd as la
+    n_mine, n_distinct = max(hi - lo, 1), 1024
+    small, graphs, anchors, T = bw.build(min(n_mine, n_distinct), "uwb_twist", seed=args.seed + 17 + 1000 * D.rank)
+    wb = la.WindowBatch(n_mine, *small.caps)
+    for name in ("counts", "poses", "r_idx", "r_val", "p_idx", "p_val", "s_idx", "s_val"):
+        src = getattr(small, name)
+        getattr(wb, name)[:] = np.resize(src, (n_mine,) + src.shape[1:])
+    # algorithmic bytes: 15 poses x 56 B in and out, 29 range edges x 24 B, 14 EdgeSE3 x 232 B (SURVEY §8(d)'s measurement size), chi2
+    return _window_leg(D, args, wb, anchors, 1, "5 632 B/window (15 poses x 56 B each way, 29 range edges x 24 B, 14 EdgeSE3 x 232 B, chi2)",
+                       "cfg/uwb_twist.yaml's sliding window as a batch: 15 poses, 29 range edges, 14 twist EdgeSE3 (Cauchy), 10 LM iterations",
+                       "window solves/sec", "windows/s", 5632.0, total,
+                       lambda n: bw.oracle_time(graphs, anchors, T, n)[1], 256,
+                       parity_fn=lambda n: bw.oracle_time(graphs, anchors, T, n, analytic=True)[1], n_parity=128, leg="twist_windows")
+
+
 def leg_cfg1_node(D, args):
     """BASELINE cfg1 the way the drop-in runs it (the reference's own CPU-runnable case): the range messages of the example recording
     (tests/golden/bag_example.npz, decoded from bag/data_example.bag by tools/decode_bag.py) through loc_node_add_range with
@@ -985,7 +1011,7 @@ def main():
 
     # ---- secondary legs (every rank takes part: they carry their own barriers) ------------------------------------------------
     other = "analytic" if args.jacobian == "numeric" else "numeric"
-    all_legs = ["cfg2_" + other, "cfg3", "cfg5", "cfg4", "cfg1_windows", "cfg1_node", "node_uwb_twist", "node_uwb_pose_T500"]
+    all_legs = ["cfg2_" + other, "cfg3", "cfg5", "cfg4", "cfg1_windows", "cfg1_node", "node_uwb_twist", "node_uwb_pose_T500", "twist_windows"]
     want = [] if args.legs == "none" else (all_legs if args.legs == "all" else args.legs.split(","))
     legs = {}
     for name in want:
@@ -1000,6 +1026,8 @@ def main():
                 out = leg_cfg4(D, args)
             elif name == "cfg1_windows":
                 out = leg_cfg1_windows(D, args)
+            elif name == "twist_windows":
+                out = leg_twist_windows(D, args)
             elif name == "cfg1_node":
                 out = leg_cfg1_node(D, args)
             elif name in ("node_uwb_twist", "node_uwb_pose_T500"):
