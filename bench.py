@@ -614,10 +614,12 @@ def leg_cfg1_node(D, args):
         track[jac] = np.array(xyz)
         out["reference_config" if jac == "numeric" else "analytic"] = {
             "jacobian": jac, "solves": len(call), "ms_per_message_median": float(np.median(c)), "p99": float(np.percentile(c, 99)), "max": float(c.max()),
-            "inside_library_median": {"pack_host": float(np.median(pt[:, 0])), "window_solve_call": float(np.median(pt[:, 1])), "of_which_kernel": float(np.median(pt[:, 2]))}}
+            "inside_library_median": {"pack_host": float(np.median(pt[:, 0])), "window_solve_call": float(np.median(pt[:, 1])), "of_which_launch_to_completion": float(np.median(pt[:, 2]))}}
     out["value"] = out["reference_config"]["ms_per_message_median"]
     out["value_note"] = ("the loc_node_add_range call of a message that triggers a solve, host buffers in, poses out (PCIe inclusive), in the REFERENCE's configuration "
-                         "(numeric Jacobians); the kernel is wave3_lm_kernel (one wave per window) whenever the window is translation-only, as this recording's is")
+                         "(numeric Jacobians); the kernel is wave3_lm_kernel (one wave per window) whenever the window is translation-only, as this recording's is; "
+                         "of_which_launch_to_completion: host clock around launch + synchronise (the node's handle runs without HIP events around its kernel: "
+                         "~4 us per message; the kernel's own duration: profiles/r04_final/cfg1_node_kernel_stats_head.csv)")
     # the same recording with cfg/uwb_imu.yaml's parameters: IMU orientation priors interleaved in recorded order + an antenna lever arm
     # (6-DoF windows of 12 poses: wave6_lm_kernel)
     kw_imu = dict(trajectory_length=12, maximum_velocity=3.0, distance_outlier=3.0, maximum_iteration=10, minimum_optimize_error=1000.0,
@@ -661,7 +663,7 @@ def leg_cfg1_node(D, args):
     node.close()
     out["uwb_imu"] = {"workload": "cfg/uwb_imu.yaml on the same recording: 12-pose 6-DoF window, IMU orientation priors, antenna lever arm; numeric Jacobians",
                       "solves": int(len(c_imu) + 20), "ms_per_message_median": float(np.median(c_imu)), "p99": float(np.percentile(c_imu, 99)),
-                      "last_solve_inside_library": {"pack_host": pt[0], "window_solve_call": pt[1], "of_which_kernel": pt[2]}}
+                      "last_solve_inside_library": {"pack_host": pt[0], "window_solve_call": pt[1], "of_which_launch_to_completion": pt[2]}}
     if not args.no_cpu_baseline and D.world == 1:   # (the CPU baseline is timed at N = 1 only: at N > 1 the other ranks would wait for it)
         from oracle import oracle as O
         ora_imu = O.LocalizationOracle(ids, pos, jac_mode=O.JAC_NUMERIC_G2O, antenna_offsets=ant_imu, **kw_imu)
@@ -748,7 +750,7 @@ def leg_node_se3(D, args, which):
         out = {"metric": "latency per range message (one sliding-window solve, EdgeSE3 chain)", "unit": "ms", "higher_is_better": False,
                "workload": "cfg/uwb_twist.yaml: 15-pose window, range edges + twist EdgeSE3 between consecutive poses, Cauchy, 12 LM iterations; numeric Jacobians",
                "value": float(np.median(lat)), "p99": float(np.percentile(lat, 99)), "solves": int(len(lat) + 20), "kernel": kind, "jacobian": "numeric",
-               "last_solve_inside_library": {"pack_host": pt[0], "window_solve_call": pt[1], "of_which_kernel": pt[2]}}
+               "last_solve_inside_library": {"pack_host": pt[0], "window_solve_call": pt[1], "of_which_launch_to_completion": pt[2]}}
         if not args.no_cpu_baseline and D.world == 1:
             from oracle import oracle as O
             ora = O.LocalizationOracle(ids, pos, jac_mode=O.JAC_NUMERIC_G2O, **cfg)
@@ -795,7 +797,7 @@ def leg_node_se3(D, args, which):
            "value": float(np.median(lat)), "solves_timed": len(lat), "first_solve_ms": float(first), "kernel": kind, "jacobian": "numeric",
            "outer_iterations": int(g["outer_iterations"]), "lm_trials": int(g["lm_trials"]), "ingest_ms_per_message_no_solve": ingest_ms,
            "inside_library_median": {"pack_host": float(np.median([p[0] for p in parts])), "window_solve_call": float(np.median([p[1] for p in parts])),
-                                     "of_which_kernel": float(np.median([p[2] for p in parts]))},
+                                     "of_which_launch_to_completion": float(np.median([p[2] for p in parts]))},
            "value_note": "repeated loc_node_solve calls on the filled window (each continues from the previous estimates, as consecutive messages would)"}
     node.close()
     if not args.no_cpu_baseline and D.world == 1:

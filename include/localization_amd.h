@@ -270,6 +270,8 @@ int loc_window_last_kernel_kind(const loc_window* w, int32_t* kind);
  *   "tree"             -1 default, 0 never, 2 the lane-per-window variant (tree_lm_kernel)
  *   "wave3" "wave6" "chain3" "zero_copy"   1 (default) / 0
  *   "topology_cache"   1 (default) / 0: reuse the structural verdict of the previous batch when counts and index tables hash the same
+ *   "kernel_events"    1 (default; LOCAMD_KERNEL_EVENTS) / 0: no HIP events around the launch of a zero-copy solve (a handful of small windows);
+ *                      loc_window_last_kernel_ms then reports launch-to-completion on the host clock.  The node's own handle runs with 0.
  * LOC_ERR_INVALID for an unknown name or value. */
 int loc_window_set_option(loc_window* w, const char* name, int64_t value);
 /* Host-side cost of the last loc_window_solve_host call, milliseconds: [0] argument validation, [1] structure analysis (kernel
@@ -359,7 +361,9 @@ int loc_node_solve(loc_node* n, loc_node_output* out);
 int loc_node_get_path(loc_node* n, int32_t node_id, double* out_T_by_8, int32_t capacity_poses);
 int32_t loc_node_number_measurements(const loc_node* n);
 /* Where the last solve's time went, milliseconds: [0] packing the window on the host, [1] the window solve call (copy in, launch, copy
- * out, synchronise), [2] of which the kernel (HIP events) — the reference prints the same figure per solve (CPPTimer, localization.cpp:166,191) */
+ * out, synchronise), [2] of which the kernel: launch to completion on the host clock — HIP events around the kernel when LOCAMD_KERNEL_EVENTS=1 was
+ * set when the node made its solver handle (they cost ~4 us per message).  The reference prints the same figure per solve (CPPTimer,
+ * localization.cpp:166,191) */
 int loc_node_last_timing(const loc_node* n, double* pack_solve_kernel_ms);
 /* LOC_WINDOW_KERNEL_* of the node's last solve (LOC_WINDOW_KERNEL_NONE before the first) */
 int loc_node_last_kernel_kind(const loc_node* n, int32_t* kind);

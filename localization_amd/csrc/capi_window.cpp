@@ -78,6 +78,7 @@ struct loc_window {
         int arrow3 = -1;                   // LOCAMD_ARROW3: -1 default (windows of more than 64 poses), 0 never, 1 whenever the batch qualifies
         int tree = -1;                     // LOCAMD_TREE: -1 default, 0 never, 2 the lane-per-window variant
         bool wave3 = true, wave6 = true, chain3 = true, zero_copy = true, topology_cache = true;
+        bool kernel_events = true;         // "kernel_events" 0: no HIP events around the launch of a zero-copy solve (loc_window_last_kernel_ms then reports launch-to-completion on the host clock)
     } opt;
     // structural verdict of the last host-path batch, keyed on a hash of (n, counts, index tables): a caller that replays one graph
     // with new measurements (the node's window between two slides, a Monte-Carlo batch) skips the chain / forest / arrowhead tests
@@ -201,6 +202,7 @@ int loc_window_create(loc_window** out, int32_t device, int64_t batch, const loc
         if (const char* v = getenv("LOCAMD_WAVE6")) o.wave6 = v[0] != '0';
         if (const char* v = getenv("LOCAMD_CHAIN3")) o.chain3 = v[0] != '0';
         if (getenv("LOCAMD_NO_ZERO_COPY")) o.zero_copy = false;
+        if (const char* v = getenv("LOCAMD_KERNEL_EVENTS")) o.kernel_events = atoi(v) != 0;
     }
     *out = w;
     return LOC_OK;
@@ -910,6 +912,7 @@ int loc_window_set_option(loc_window* w, const char* name, int64_t value) {
     if (k == "wave6") return flag(o.wave6);
     if (k == "chain3") return flag(o.chain3);
     if (k == "zero_copy") return flag(o.zero_copy);
+    if (k == "kernel_events") return flag(o.kernel_events);
     if (k == "topology_cache") { w->topo_cache.valid = false; return flag(o.topology_cache); }
     return locamd_fail(LOC_ERR_INVALID, "set_option: unknown option name");
 }
@@ -1013,18 +1016,21 @@ int loc_window_solve_host(loc_window* w, int64_t n, const int32_t* counts, doubl
             a.r_idx = (const int32_t*)(d + off[6]); a.p_idx = (const int32_t*)(d + off[7]); a.s_idx = (const int32_t*)(d + off[8]);
             a.anchors = zero_copy ? (const double*)(h + off[9]) : w->d_anchors; a.workspace = w->d_workspace;
             a.n_anchors = w->n_anchors; a.B = (int)n; a.iterations = w->iterations; a.caps = c;
-            LOC_HIP(hipEventRecord(w->ev0, st));
+            // (the two event records around a ~50 us kernel are not free; option "kernel_events" = 0 drops them for the zero-copy solve)
+            const bool events = w->opt.kernel_events || !zero_copy;
+            if (events) LOC_HIP(hipEventRecord(w->ev0, st));
             if (kind == LOC_WINDOW_KERNEL_ARROW3) LOC_HIP(upload_arrow_aux(w, 0, n, st));
             if (kind == LOC_WINDOW_KERNEL_TREE) LOC_HIP(upload_tree_sched(w, 0, st));
+            const auto t_launch = clk::now();
             hipError_t e = launch_any(w, 0, a, st, kind);
             if (e != hipSuccess) return locamd_fail_hip(e, "launch_window");
-            LOC_HIP(hipEventRecord(w->ev1, st));
+            if (events) LOC_HIP(hipEventRecord(w->ev1, st));
             if (!zero_copy) LOC_HIP(hipMemcpyAsync(h, d, off[2], hipMemcpyDeviceToHost, st));  // [poses | result]
             LOC_HIP(hipStreamSynchronize(st));
+            float ms = (float)ms_since(t_launch);
             std::memcpy(poses, h + off[0], N * c.nv_max * 12 * sizeof(double));
             std::memcpy(result, h + off[1], N * 8 * sizeof(double));
-            float ms = 0;
-            LOC_HIP(hipEventElapsedTime(&ms, w->ev0, w->ev1));
+            if (events) LOC_HIP(hipEventElapsedTime(&ms, w->ev0, w->ev1));
             w->last_ms = ms;
             w->t_run_ms = ms_since(t_run);
             return LOC_OK;

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -348,6 +349,9 @@ int solve_now(loc_node* n, loc_node_output* out) {
             if (rc != LOC_OK) return rc;
             rc = loc_window_set_jacobian(n->win, n->cfg.jacobian);
             if (rc != LOC_OK) return rc;
+            // (no HIP events around the node's ~50 us kernel unless asked for at creation: they cost ~4 us per message; loc_node_last_timing's
+            //  third figure is then launch-to-completion on the host clock)
+            if (!getenv("LOCAMD_KERNEL_EVENTS")) (void)loc_window_set_option(n->win, "kernel_events", 0);
             n->win_anchors = P.anchors;
         } else if (n->win_anchors != P.anchors) {
             // the fixed vertices the window sees (or just their order) change as the window slides: refresh the table,

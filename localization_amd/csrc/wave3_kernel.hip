@@ -243,6 +243,34 @@ __device__ __forceinline__ void w3_edges(const W3Lds& l, const W3Edge& E0, int n
     plain_chi = w3_sum(csum);
 }
 
+// TWO trial states scored in one pass (windows of <= 32 edges and <= 32 priors): state A by lanes 0 .. 31, state B by lanes 32 .. 63, every
+// lane with the edge of its position in its half.  The sums are the DPP tree of w3_sum read where a half has been summed — lanes 31 and 63
+// after the row_bcast:15 step — which is bit for bit what the whole-wave sum of ONE state gives (its other rows add zeros).
+template <int JAC>
+__device__ __forceinline__ void w3_edges_dual(const W3Lds& l, const W3Edge& E0, int nvm, int nr, int np, int bufA, int bufB, int lane,
+                                              double& chiA, double& plainA, double& chiB, double& plainB) {
+    double rsum = 0.0, csum = 0.0;
+    const int el = lane & 31;
+    const double* T = l.T + (size_t)(lane < 32 ? bufA : bufB) * nvm * 3;
+    if (el < nr) w3_edge<false, JAC>(l, T, E0, rsum, csum);
+    if (el < np) {
+        const double* s = T + l.pidx[el] * 3;
+        const double* v = l.pv + (size_t)el * 6;
+        double chi = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const double er = s[k] + v[k]; chi += er * (v[3 + k] * er); }
+        rsum += chi;
+        csum += chi;
+    }
+    rsum += w3_dpp<0x111, 0xF>(rsum); csum += w3_dpp<0x111, 0xF>(csum);
+    rsum += w3_dpp<0x112, 0xF>(rsum); csum += w3_dpp<0x112, 0xF>(csum);
+    rsum += w3_dpp<0x114, 0xF>(rsum); csum += w3_dpp<0x114, 0xF>(csum);
+    rsum += w3_dpp<0x118, 0xF>(rsum); csum += w3_dpp<0x118, 0xF>(csum);
+    rsum += w3_dpp<0x142, 0xA>(rsum); csum += w3_dpp<0x142, 0xA>(csum);
+    chiA = w3_bcast(rsum, 31); plainA = w3_bcast(csum, 31);
+    chiB = w3_bcast(rsum, 63); plainB = w3_bcast(csum, 63);
+}
+
 template <int JAC>
 __global__ void __launch_bounds__(64, 3) wave3_lm_kernel(const WindowArgs a) {
     const int lane = threadIdx.x;
@@ -332,7 +360,9 @@ __global__ void __launch_bounds__(64, 3) wave3_lm_kernel(const WindowArgs a) {
     w3_sync();
     W3Edge E0;
     E0.v0 = 0; E0.v1 = -1; E0.s0 = 0; E0.s1 = -1; E0.meas = 0.0; E0.info = 0.0; E0.fx = 0.0; E0.fy = 0.0; E0.fz = 0.0;
-    if (lane < nr) E0 = w3_load_edge(l, lane);
+    // (speculative trials are scored two at a time when a window's edges fit half a wave: the upper half keeps the same edges)
+    const bool dual = G >= 2 && nr <= 32 && np <= 32;
+    if ((dual ? (lane & 31) : lane) < nr) E0 = w3_load_edge(l, dual ? (lane & 31) : lane);
     W3_T(0);
 
     // ---- Levenberg-Marquardt (g2o: OptimizationAlgorithmLevenberg::solve), wave-uniform control flow ---------------
@@ -672,12 +702,23 @@ __global__ void __launch_bounds__(64, 3) wave3_lm_kernel(const WindowArgs a) {
         // ---- consume the trials in LM's order until one is accepted (or the iteration ends) -------------------------------------------
         bool iteration_over = false;
         double rho = 0.0;
+        double tchi[4] = {0.0, 0.0, 0.0, 0.0}, tplain[4] = {0.0, 0.0, 0.0, 0.0};
+        bool scored[4] = {false, false, false, false};
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             if (g < G && !iteration_over) {
                 const int slot = cur + 1 + g - (cur + 1 + g >= NSLOT ? NSLOT : 0);
-                double temp_chi, plain2;
-                w3_edges<false, JAC>(l, E0, nvm, nr, np, slot, lane, temp_chi, plain2);
+                if (!scored[g]) {
+                    if (g < 3 && dual && g + 1 < G) {   // this trial and the next one in one pass
+                        const int slot2 = cur + 2 + g - (cur + 2 + g >= NSLOT ? NSLOT : 0);
+                        w3_edges_dual<JAC>(l, E0, nvm, nr, np, slot, slot2, lane, tchi[g], tplain[g], tchi[g < 3 ? g + 1 : 3], tplain[g < 3 ? g + 1 : 3]);
+                        scored[g < 3 ? g + 1 : 3] = true;
+                    } else {
+                        w3_edges<false, JAC>(l, E0, nvm, nr, np, slot, lane, tchi[g], tplain[g]);
+                    }
+                }
+                double temp_chi = tchi[g];
+                const double plain2 = tplain[g];
                 last_plain = plain2;
                 ++trials;
                 jlast = g;

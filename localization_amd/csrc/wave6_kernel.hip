@@ -400,6 +400,30 @@ __device__ __forceinline__ void w6_edges(const W6Lds& l, const W6Edge& E0, int n
     plain_chi = w6_sum(csum);
 }
 
+// the sums of lanes 0 .. 31 and of lanes 32 .. 63: the DPP tree of w6_sum read after the row_bcast:15 step — bit for bit the whole-wave sum of
+// values that sit in one half only
+__device__ __forceinline__ void w6_half_sums(double v, double& lo, double& hi) {
+    v += w6_dpp<0x111, 0xF>(v);
+    v += w6_dpp<0x112, 0xF>(v);
+    v += w6_dpp<0x114, 0xF>(v);
+    v += w6_dpp<0x118, 0xF>(v);
+    v += w6_dpp<0x142, 0xA>(v);
+    lo = w6_bcast(v, 31); hi = w6_bcast(v, 63);
+}
+// TWO trial states scored in one pass (windows of <= 32 range edges and <= 32 priors): state A by lanes 0 .. 31, state B by lanes 32 .. 63, every
+// lane with the edge of its position in its half (wave3_kernel.hip: w3_edges_dual)
+template <int JAC>
+__device__ __forceinline__ void w6_edges_dual(const W6Lds& l, const W6Edge& E0, int nvm, int nr, int np, int bufA, int bufB, int lane, int tm,
+                                              double& chiA, double& plainA, double& chiB, double& plainB) {
+    double rsum = 0.0, csum = 0.0;
+    const int el = lane & 31;
+    const double* P = l.pose + (size_t)(lane < 32 ? bufA : bufB) * nvm * 12;
+    if (el < nr) w6_edge<false, JAC>(l, P, E0, tm, rsum, csum);
+    if (el < np) w6_prior<false>(l, P, el, rsum, csum);
+    w6_half_sums(rsum, chiA, chiB);
+    w6_half_sums(csum, plainA, plainB);
+}
+
 #define W6_TRI(r, c) ((r) * ((r) + 1) / 2 + (c))
 
 // the EdgeSE3 between a lane's pose and its sender, evaluated by that lane at the poses P: chi; FULL: its own / the sender's share of H
@@ -552,7 +576,9 @@ __global__ void __launch_bounds__(64) wave6_lm_kernel(const WindowArgs a) {
     w6_sync();
     W6Edge E0;
     E0.v0 = 0; E0.v1 = -1; E0.s0 = 0; E0.s1 = -1; E0.meas = 0.0; E0.info = 0.0; E0.ox = 0.0; E0.oy = 0.0; E0.oz = 0.0; E0.fx = 0.0; E0.fy = 0.0; E0.fz = 0.0;
-    if (lane < nr) E0 = w6_load_edge(l, lane);
+    // (speculative trials are scored two at a time when a window's edges fit half a wave: the upper half keeps the same edges)
+    const bool dual = G >= 2 && nr <= 32 && np <= 32;
+    if ((dual ? (lane & 31) : lane) < nr) E0 = w6_load_edge(l, dual ? (lane & 31) : lane);
     W6_T(0);
 
     // ---- Levenberg-Marquardt (g2o: OptimizationAlgorithmLevenberg::solve), wave-uniform control flow ---------------
@@ -970,18 +996,38 @@ __global__ void __launch_bounds__(64) wave6_lm_kernel(const WindowArgs a) {
         // ---- consume the trials in LM's order until one is accepted (or the iteration ends) -------------------------------------------
         bool iteration_over = false;
         double rho = 0.0;
+        double tchi[4] = {0.0, 0.0, 0.0, 0.0}, tplain[4] = {0.0, 0.0, 0.0, 0.0};
+        bool scored[4] = {false, false, false, false};
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             if (g < G && !iteration_over) {
                 const int slot = cur + 1 + g - (cur + 1 + g >= W6_NSLOT ? W6_NSLOT : 0);
-                double temp_chi, plain2;
-                w6_edges<false, JAC>(l, E0, nvm, nr, np, slot, lane, tm, temp_chi, plain2);
-                if (SE3) {   // the EdgeSE3 factors, lane = later pose (group 0's lanes)
-                    double rs = 0.0, cs = 0.0;
-                    if (grp == 0 && se.e >= 0) cs = w6_se3<false>(l, l.pose + (size_t)slot * nvm * 12, se, se.e, pp, nullptr, nullptr, nullptr, rs);
-                    temp_chi += w6_sum(rs);
-                    plain2 += w6_sum(cs);
+                if (!scored[g]) {
+                    if (g < 3 && dual && g + 1 < G) {   // this trial and the next one in one pass
+                        const int g1 = g < 3 ? g + 1 : 3;
+                        const int slot2 = cur + 2 + g - (cur + 2 + g >= W6_NSLOT ? W6_NSLOT : 0);
+                        w6_edges_dual<JAC>(l, E0, nvm, nr, np, slot, slot2, lane, tm, tchi[g], tplain[g], tchi[g1], tplain[g1]);
+                        if (SE3) {   // the EdgeSE3 factors: the lanes of the first group of each half
+                            double rs = 0.0, cs = 0.0;
+                            if ((lane & 31) < W && se.e >= 0) cs = w6_se3<false>(l, l.pose + (size_t)(lane < 32 ? slot : slot2) * nvm * 12, se, se.e, pp, nullptr, nullptr, nullptr, rs);
+                            double ra, rb, ca, cb;
+                            w6_half_sums(rs, ra, rb);
+                            w6_half_sums(cs, ca, cb);
+                            tchi[g] += ra; tplain[g] += ca; tchi[g1] += rb; tplain[g1] += cb;
+                        }
+                        scored[g1] = true;
+                    } else {
+                        w6_edges<false, JAC>(l, E0, nvm, nr, np, slot, lane, tm, tchi[g], tplain[g]);
+                        if (SE3) {   // the EdgeSE3 factors, group 0's lanes
+                            double rs = 0.0, cs = 0.0;
+                            if (grp == 0 && se.e >= 0) cs = w6_se3<false>(l, l.pose + (size_t)slot * nvm * 12, se, se.e, pp, nullptr, nullptr, nullptr, rs);
+                            tchi[g] += w6_sum(rs);
+                            tplain[g] += w6_sum(cs);
+                        }
+                    }
                 }
+                double temp_chi = tchi[g];
+                const double plain2 = tplain[g];
                 last_plain = plain2;
                 ++trials;
                 jlast = g;

@@ -111,7 +111,7 @@ def main():
                                              "note": "the loc_node_add_* call of a message that triggers a solve, through this harness's ctypes wrapper: what a caller of the library waits for"}
         pt = np.array(parts[1:])
         rep["ms_per_solve_parts_median"] = {"pack_host": float(np.median(pt[:, 0])), "window_solve_call": float(np.median(pt[:, 1])),
-                                            "of_which_kernel": float(np.median(pt[:, 2])),
+                                            "of_which_launch_to_completion": float(np.median(pt[:, 2])),
                                             "note": "inside the library (loc_node_last_timing); the rest of ms_per_solve_incl_feed is this Python harness (decoding the next messages of the bag, ctypes)"}
     if truth and realtime:
         t8 = np.array([[e["stamp"], *e["pose"]] for e in truth])
