@@ -7,7 +7,8 @@ import localization_amd as la
 import bench_window as bw
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 n_distinct = min(B, 16)
-small, graphs, anchors, nv = bw.build_selfcal(n_distinct, np.random.default_rng(11))
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 256   # chain poses (cfg4: 256)
+small, graphs, anchors, nv = bw.build_selfcal(n_distinct, np.random.default_rng(11), T=T)
 wb = la.WindowBatch(B, *small.caps)
 for name in ("counts", "poses", "r_idx", "r_val", "p_idx", "p_val", "s_idx", "s_val"):
     src = getattr(small, name); getattr(wb, name)[:] = np.resize(src, (B,) + src.shape[1:])
