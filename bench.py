@@ -800,6 +800,14 @@ def leg_node_se3(D, args, which):
                                      "of_which_launch_to_completion": float(np.median([p[2] for p in parts]))},
            "value_note": "repeated loc_node_solve calls on the filled window (each continues from the previous estimates, as consecutive messages would)"}
     node.close()
+    pm = os.path.join(ROOT, "profiles", "r04_final", "node_pose_T500_pmc.json")
+    if os.path.exists(pm):   # (rocprofv3 --pmc passes over tools/dev/node_pose_T500.py = this leg without its CPU baseline: tools/profile_r04.sh t500)
+        pj = json.load(open(pm))
+        out["pmc"] = {"hbm_side_bytes_per_solve": (2.0 * pj["FETCH_SIZE"] + pj["WRITE_SIZE"]) * 1024.0, "valu_wave_instructions_per_solve": pj["SQ_INSTS_VALU"],
+                      "vmem_read_instructions_per_solve": pj["SQ_INSTS_VMEM_RD"], "waves": pj["SQ_WAVES"],
+                      "waiting_share_of_wave_cycles": pj["SQ_WAIT_ANY"] / pj["SQ_WAVE_CYCLES"], "valu_share_of_wave_cycles": pj["SQ_ACTIVE_INST_VALU"] / pj["SQ_WAVE_CYCLES"],
+                      "source": "profiles/r04_final/node_pose_T500_pmc.json, node_pose_T500_kernel_stats_head.csv (round 4: window_lm_kernel<.., 8 waves>, 3.4 ms per launch under rocprofv3)",
+                      "note": "ONE workgroup of eight waves on one CU: the solve is a chain of dependent L2 round trips (H lives in the kernel's global workspace at this size), not bandwidth"}
     if not args.no_cpu_baseline and D.world == 1:
         from oracle import oracle as O
         ora = O.LocalizationOracle(ids, pos, jac_mode=O.JAC_NUMERIC_G2O, **cfg)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-4 rocprofv3 evidence on the GPU box:  tools/profile_r04.sh OUTDIR [cfg2|cfg3|cfg5|cfg4|cfg1|twist|all ...]   (run from the repo root; summaries land
+# Round-4 rocprofv3 evidence on the GPU box:  tools/profile_r04.sh OUTDIR [cfg2|cfg3|cfg5|cfg4|cfg1|twist|t500|all ...]   (run from the repo root; summaries land
 # in OUTDIR: copy them to profiles/r04_final/).  Per workload: --kernel-trace --stats once, then separate --pmc passes (never combined with a trace
 # domain).  Every window workload runs in the REFERENCE's configuration (numeric Jacobians), the snapshot / fusion kernels in both modes.
 #   cfg2  headline snapshot kernel (bench.py itself: numeric = `value`, and --jacobian analytic)        cfg3  fusion kernel
@@ -50,6 +50,9 @@ fi
 if want twist; then   # cfg/uwb_twist.yaml's 15-pose window (EdgeSE3 between consecutive poses) as a batch: wave6_lm_kernel<JAC, SE3>
   python3 $W --shape uwb_twist --batch 65536 --tile 1024 --cache /tmp/wb_tw.npz > /dev/null
   profile twist_windows wave6_lm_kernel -- python3 $W --shape uwb_twist --batch 65536 --cache /tmp/wb_tw.npz
+fi
+if want t500; then   # the node's 500-pose key-frame window (cfg/uwb_pose.yaml at its own trajectory_length): window_lm_kernel, eight waves
+  profile node_pose_T500 window_lm_kernel -- python3 tools/dev/node_pose_T500.py
 fi
 if want cfg1; then
   python3 $W --shape uwb_only --batch 65536 --tile 4096 --cache /tmp/wb_t10.npz --bw 1 > /dev/null
