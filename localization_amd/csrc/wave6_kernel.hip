@@ -14,15 +14,19 @@
 // of a pair is then the rank-1 product (w J_p) J_{p-1}^T = u v^T of 6-vectors, the Schur complement of pose p is A_p - alpha_p u u^T,
 // and Sherman-Morrison turns the sequential elimination into a recurrence on TWO SCALARS per pose while every pose factors its own
 // 6x6 block at once (see "The solve" in the kernel).  Everything else stays on window_lm_kernel.  Measured: cfg/uwb_imu.yaml's
-// twelve-pose window 0.10 ms (window_lm_kernel 0.40), 0.12 ms per range message through the node (the oracle: 0.26 ms).
+// twelve-pose window 0.083 ms (window_lm_kernel 0.40), 0.117 ms per range message through the node (the oracle: 0.26 ms).
 //
 // SE3 = true (round 4): the same windows WITH an EdgeSE3 factor between consecutive poses — Localization::addTwistEdge
-// (localization.cpp:438-459, 560-605; cfg/uwb_twist.yaml), at most one per pair.  The coupling block of a pair is then a full 6x6
-// (H_p,p-1 of the EdgeSE3 + the range edge's rank-1 part), so the elimination is the plain block-tridiagonal Cholesky — S_p = A_p -
-// W_p^T W_p, W_p = G_{p-1}^-1 K_p^T — handed from lane to lane by DPP: every repetition every lane takes its neighbour's factor (21 + 6
-// numbers) and redoes its own step, after repetition r the poses 0 .. r hold final values.  The EdgeSE3 of the pair (p - 1, p) is
-// linearised by lane p (its record in LDS, [entry][lane]), the share of pose p - 1 goes down one lane by DPP.  Everything else —
-// records, gather, speculative trials, LM — is shared with the rank-1 kernel.
+// (localization.cpp:438-459, 560-605; cfg/uwb_twist.yaml), at most one per pair, <= 63 poses.  The coupling block of a pair is then a full
+// 6x6 (the EdgeSE3's + the range edge's rank-1 part), so the elimination is the plain block-tridiagonal Cholesky — with q the pose
+// eliminated just before p (its "sender"): W_p = G_q^-1 K_p^T, S_p = A_p - W_p^T W_p = G_p G_p^T — run from BOTH ends of the chain
+// towards the middle pose in the same instructions (poses 0 .. m in lanes 0 .. m, poses n - 1 .. m + 1 in lanes m + 1 .. n - 1, the middle
+// pose once more in lane n) and handed from lane to lane by DPP: every repetition every lane takes the factor of the lane before it
+// (21 + 6 numbers) and redoes its own step; after ceil(n / 2) repetitions both chains are final and the middle pose's two lanes add
+// their Schur complements.  The EdgeSE3 between a pose and its sender is linearised by the pose's lane (its record in LDS,
+// [entry][edge]), the sender's share goes down one lane by DPP.  Everything else — records, gather, speculative trials (scored two per
+// pass), LM — is shared with the rank-1 kernel.  Measured: cfg/uwb_twist.yaml's 15-pose window 0.29 ms (window_lm_kernel 0.64), 0.32 ms
+// per range message through the node (the oracle: 0.34 ms), 4.5e6 windows/s in batches (chain_lm_kernel: 2.7e6).
 #include "se3_edge_device.h"
 
 #include <float.h>
