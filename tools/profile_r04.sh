@@ -23,18 +23,17 @@ profile() {   # profile TAG KERNEL_SUBSTRING -- command ...
     rocprofv3 --pmc $P --output-format csv -d "$OUT/pmc${i}_$TAG" -o p -- "$@" > /dev/null 2>&1 || echo "[profile_r04] $TAG pmc pass $i failed"
   done
   python3 tests/perf/pmc_summary.py "$KER" "$OUT"/pmc*_"$TAG" > "$OUT/${TAG}_pmc.json"
+  if [ -n "$ALSO_TAG" ]; then python3 tests/perf/pmc_summary.py "$ALSO_KER" "$OUT"/pmc*_"$TAG" > "$OUT/${ALSO_TAG}_pmc.json"; cp "$OUT/${TAG}_kernel_stats_head.csv" "$OUT/${ALSO_TAG}_kernel_stats_head.csv"; fi
   rm -rf "$OUT/trace_$TAG" "$OUT"/pmc*_"$TAG"
   echo "[profile_r04] $TAG done: $(head -2 "$OUT/${TAG}_kernel_stats_head.csv" | tail -1 | cut -c1-160)"
 }
-SHORT="--steps 3 --warmup 1 --no-cpu-baseline --legs none --datagen numpy"
+SHORT="--steps 12 --warmup 3 --no-cpu-baseline --legs none --datagen numpy"   # (enough launches for the trace average to be a warm one)
 if want cfg2; then
   profile cfg2_numeric snapshot_lm_kernel -- python3 bench.py $SHORT
   profile cfg2_analytic snapshot_lm_kernel -- python3 bench.py $SHORT --jacobian analytic
 fi
-if want cfg3; then
-  FUS="tests/perf/bench_fusion.py --steps 2 --cpu-tags 64 --cpu-epochs 4"
-  profile cfg3_numeric fusion_lm_kernel -- python3 $FUS --jacobian numeric
-  profile cfg3_analytic fusion_lm_kernel -- python3 $FUS
+if want cfg3; then   # the bench's own cfg3 leg (both modes in one run: fusion_lm_kernel<1> = numeric = `value`, <0> = analytic)
+  ALSO_TAG=cfg3_analytic ALSO_KER="fusion_lm_kernel<0>" profile cfg3_numeric "fusion_lm_kernel<1>" -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --legs cfg3 --datagen numpy
 fi
 W="tests/perf/bench_window.py --reps 3 --no-latency --cpu-n 0 --jacobian numeric"
 if want cfg5; then
