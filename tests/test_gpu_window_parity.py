@@ -749,3 +749,16 @@ def test_window_options_and_topology_cache(gpu):
     solver.solve(c)
     assert solver.last_host_timing()[3] is False
     solver.close()
+    # "kernel_events" = 0 (what the node's own handle runs with): a handful of small windows solved from the staging block without HIP
+    # events around the kernel — the same bits, and loc_window_last_kernel_ms reports launch to completion on the host clock
+    small = _chain_batch(la, 2, T, 4)
+    want = la.WindowBatch(2, *small.caps)
+    for name in ("counts", "poses", "r_idx", "r_val", "p_idx", "p_val", "s_idx", "s_val"): getattr(want, name)[:] = getattr(small, name)
+    s2 = la.WindowSolver(ANCH, 2, *small.caps, jacobian="numeric")
+    r_with = s2.solve(want).copy()
+    ms_with = s2.last_kernel_ms()
+    s2.set_option("kernel_events", 0)
+    r_without = s2.solve(small).copy()
+    assert s2.last_kernel_kind() == "wave3_lm_kernel" and np.array_equal(small.poses, want.poses) and np.array_equal(r_with, r_without)
+    assert 0.0 < ms_with < 5.0 and 0.0 < s2.last_kernel_ms() < 5.0
+    s2.close()
