@@ -19,6 +19,7 @@ pytestmark = pytest.mark.gpu
     (10, "numeric", False),    # the reference's Jacobian mode
     (1, "numeric", False),     # a lone pose with four ranges
     (12, "analytic", True),    # + lidar-style z priors (translation-only information)
+    (16, "numeric", True),     # two groups of 32 lanes, 31 edges: the two trial states scored in one pass
     (20, "numeric", True),
     (64, "analytic", False),   # every lane a pose
     (64, "numeric", True),     # ... and two passes over the edges (more than 64 of them)

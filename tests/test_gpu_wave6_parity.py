@@ -51,6 +51,7 @@ def _chain_batch(la, rng, B, T, with_imu, lever, lidar=False):
     (12, True, True, "numeric", False),     # ... in the reference's Jacobian mode
     (10, False, True, "analytic", False),   # a lever arm alone makes the poses turn
     (1, True, True, "numeric", False),      # a lone pose
+    (16, True, True, "numeric", False),     # two groups of 32 lanes, 31 range edges: the two trial states still scored in one pass
     (20, True, True, "numeric", True),      # cfg/uwb_imu_lidar.yaml: two priors per pose; two groups of 32 lanes
     (40, True, False, "analytic", False),   # one group: every lane a pose or idle
     (64, True, True, "analytic", False),    # every lane a pose, three passes over the edges (91 KB of LDS per window)
@@ -213,6 +214,7 @@ def _twist_batch(la, rng, B, T, with_imu, lever):
     (15, False, True, "analytic"),
     (10, True, True, "numeric"),      # with IMU priors and a lever arm
     (2, False, True, "analytic"),
+    (16, False, True, "numeric"),     # two groups of 32 lanes, 31 range edges: the two trial states still scored in one pass
     (24, False, True, "numeric"),     # two groups of 32 lanes
     (40, True, False, "analytic"),    # one group
     (63, False, True, "analytic"),    # every lane a pose (63 poses + the middle pose once more)
